@@ -1,0 +1,142 @@
+"""ORACLE (test infrastructure): the DiffuEraser.forward pipeline + the in-tree orchestration, fp32 on CPU.
+
+Follows reference diffuerase.py:20-114 (in-tree: dilation, model call, resize-back + feather composite) and
+SURVEY.md section 3.3 / App. D for the third-party `DiffuEraser.forward` it calls at diffuerase.py:62-67
+(PARITY UNPINNED for the third-party part -- see oracle/model_ref.py header).
+
+Chunking is build-defined (the reference lists chunk+overlap+blend as a TODO, README.md:76): independent
+`chunk`-frame clips starting at s_i = min((chunk-overlap)*i, T-chunk), blended by a sequential linear cross-fade
+in fp32 pixel space, in chunk order.
+"""
+import numpy as np
+import torch
+
+from . import imageops_ref as I
+from . import model_ref as M
+
+
+def model_size(H0, W0, max_img_size):
+    """Inference size: max side <= max_img_size, both sides floored to multiples of 8."""
+    Hs, Ws = H0, W0
+    if max(H0, W0) > max_img_size:
+        s = max_img_size / float(max(H0, W0))
+        Hs, Ws = int(round(H0 * s)), int(round(W0 * s))
+    return max(8, Hs - Hs % 8), max(8, Ws - Ws % 8)
+
+
+def chunk_plan(T, chunk, overlap):
+    if T <= chunk:
+        return [(0, T)]
+    starts, i = [], 0
+    while True:
+        s = min((chunk - overlap) * i, T - chunk)
+        starts.append(s)
+        if s + chunk >= T:
+            break
+        i += 1
+    return [(s, s + chunk) for s in starts]
+
+
+def blend_weights(plan):
+    """Per chunk: fp32 weight of the NEW chunk for each of its frames under the sequential cross-fade
+    (frames beyond the running coverage get 1).  w_new(k) = (k+1)/(O+1) over the O overlapping frames."""
+    out, covered = [], 0
+    for (s, e) in plan:
+        w = np.ones(e - s, np.float32)
+        O = max(0, covered - s)
+        for k in range(O):
+            w[k] = np.float32(k + 1) / np.float32(O + 1)
+        out.append(w)
+        covered = max(covered, e)
+    return out
+
+
+def chunk_noise(seed, index, shape):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(int(seed) * 1000003 + int(index))
+    return torch.randn(shape, generator=g, dtype=torch.float32)
+
+
+def to_model_tensor(frames_u8):
+    x = torch.from_numpy(np.stack(frames_u8)).permute(0, 3, 1, 2).float()
+    return x / 127.5 - 1.0
+
+
+def denoise_chunk(P, img, m, prior, noise, steps, ucfg, vcfg, scheduler="ddim", tcd_noise=None, trace=None):
+    """One clip: img/prior [F,3,H,W] in [-1,1], m [F,1,H,W] in {0,1} -> decoded [F,3,H,W] in [0,1]."""
+    ac = M.alphas_cumprod()
+    text = M.text_states(P, ucfg)
+    prior_lat = M.vae_encode(P, prior, vcfg)
+    cond_lat = M.vae_encode(P, img * (1.0 - m), vcfg)
+    h, w = prior_lat.shape[-2:]
+    m_lat = torch.nn.functional.interpolate(m, size=(h, w), mode="nearest")
+    ts = M.ddim_timesteps(steps) if scheduler == "ddim" else M.tcd_timesteps(steps)
+    lat = M.add_noise(prior_lat, noise, ts[0], ac)
+    if trace is not None:
+        trace.update(prior_lat=prior_lat, cond_lat=cond_lat, m_lat=m_lat, lat0=lat.clone())
+    for i, t in enumerate(ts):
+        brush = M.brushnet_forward(P, torch.cat([lat, cond_lat, m_lat], 1), t, text, ucfg)
+        eps = M.unet_forward(P, lat, t, text, ucfg, brush)
+        if trace is not None and i == 0:
+            trace.update(eps0=eps.clone())
+        if scheduler == "ddim":
+            lat = M.ddim_step(lat, eps, t, steps, ac)
+        else:
+            lat = M.tcd_step(lat, eps, t, ts[i + 1] if i + 1 < len(ts) else None, ac,
+                             tcd_noise[i] if tcd_noise is not None else torch.zeros_like(lat))
+    if trace is not None:
+        trace.update(lat_final=lat.clone())
+    dec = M.vae_decode(P, lat, vcfg)
+    return (dec / 2 + 0.5).clamp(0, 1)
+
+
+def diffueraser_forward(frames, masks2d, priori, max_img_size=960, steps=50, chunk=32, overlap=8, seed=42,
+                        weight_seed=0, ucfg=None, vcfg=None, scheduler="ddim", P=None, return_float=False):
+    """Restatement of `DiffuEraser.forward(frames, masks, priori, max_img_size=, ...)` (call site reference
+    diffuerase.py:62-67): list of uint8 RGB frames at the inference size."""
+    from videovanish_amd.config import UNetConfig, VAEConfig
+    ucfg = ucfg or UNetConfig()
+    vcfg = vcfg or VAEConfig()
+    P = P or M.Params(weight_seed)
+    T = len(frames)
+    H0, W0 = frames[0].shape[:2]
+    H, W = model_size(H0, W0, max_img_size)
+    fr = [I.resize_bilinear_u8(f, W, H) for f in frames]
+    pr = [I.resize_bilinear_u8(f, W, H) for f in priori]
+    mk = [I.resize_nearest_u8(np.where(m > 0, 255, 0).astype(np.uint8), W, H) for m in masks2d]
+    plan = chunk_plan(T, chunk, overlap)
+    wts = blend_weights(plan)
+    acc = torch.zeros(T, 3, H, W)
+    with torch.no_grad():
+        for ci, (s, e) in enumerate(plan):
+            img = to_model_tensor(fr[s:e])
+            prior = to_model_tensor(pr[s:e])
+            m = torch.from_numpy(np.stack(mk[s:e]) > 0).float()[:, None]
+            noise = chunk_noise(seed, ci, (e - s, 4, H // 8, W // 8))
+            dec = denoise_chunk(P, img, m, prior, noise, steps, ucfg, vcfg, scheduler)
+            w = torch.from_numpy(wts[ci])[:, None, None, None]
+            acc[s:e] = (acc[s:e] * (1.0 - w)) + (dec * w)        # sequential cross-fade, fp32, chunk order
+    out = []
+    pix = acc.permute(0, 2, 3, 1).contiguous().numpy()
+    if return_float:
+        return pix
+    for t in range(T):
+        out.append(I.blur_compose(pix[t], fr[t], mk[t]))
+    return out
+
+
+def run_infill_on_frames(frames_rgb, mask_frames, mask_dilation_iter=8, propainer_frames=None, max_img_size=960,
+                         keep_unmasked_original=True, feather_px=3, compat_reference_early_return=False, **kw):
+    """Restatement of reference diffuerase.py:20-114 with the model call replaced by diffueraser_forward above.
+    `propainer_frames` must be supplied (the flow-propagation prior has its own oracle in flowprop_ref.py)."""
+    H0, W0 = frames_rgb[0].shape[:2]
+    dil = I.collapse_and_dilate(mask_frames, mask_dilation_iter)               # :27-31
+    out = diffueraser_forward(frames_rgb, dil, propainer_frames, max_img_size=max_img_size, **kw)   # :62-67
+    for i, f in enumerate(out):                                                 # :70-112
+        if f.shape[0] != H0 or f.shape[1] != W0:
+            out[i] = I.resize_bilinear_u8(f, W0, H0)
+        if keep_unmasked_original:
+            out[i] = I.composite(out[i], frames_rgb[i], I.feather_alpha(dil[i], feather_px))
+        if compat_reference_early_return:                                       # :114 (return inside the loop)
+            break
+    return out

@@ -1,0 +1,53 @@
+"""Architecture / run configuration of the DiffuEraser hot path (reference call site
+diffuerase.py:39-45 names the SD-1.5 / sd-vae-ft-mse / diffuEraser checkpoints whose shapes these are)."""
+from dataclasses import dataclass, field
+from typing import Tuple
+
+
+@dataclass(frozen=True)
+class UNetConfig:
+    block_out: Tuple[int, ...] = (320, 640, 1280, 1280)
+    attn_levels: Tuple[bool, ...] = (True, True, True, False)   # CrossAttn x3, plain Down (up path mirrors)
+    layers_per_block: int = 2
+    heads: int = 8
+    cross_dim: int = 768
+    text_len: int = 77
+    groups: int = 32
+    in_ch: int = 4
+    out_ch: int = 4
+    brush_in_ch: int = 9          # 4 noisy latents + 4 masked-image latents + 1 mask
+    motion_max_seq: int = 32
+    zero_conv_gain: float = 0.5
+
+    @property
+    def temb_dim(self):
+        return 4 * self.block_out[0]
+
+
+@dataclass(frozen=True)
+class VAEConfig:
+    block_out: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    groups: int = 32
+    latent_ch: int = 4
+    scaling: float = 0.18215
+
+
+# small-but-structurally-complete configs for fast parity tests (same block types, fewer/narrower levels)
+TINY_UNET = UNetConfig(block_out=(64, 128), attn_levels=(True, False), layers_per_block=1, heads=2, cross_dim=64,
+                       text_len=7, groups=8)
+SMALL_UNET = UNetConfig(block_out=(320, 640), attn_levels=(True, False), layers_per_block=1, heads=8, cross_dim=768)
+TINY_VAE = VAEConfig(block_out=(32, 64), layers_per_block=1, groups=8)
+SMALL_VAE = VAEConfig(block_out=(128, 256), layers_per_block=1)
+
+
+@dataclass(frozen=True)
+class RunConfig:
+    steps: int = 50
+    chunk: int = 32
+    overlap: int = 8
+    seed: int = 42
+    weight_seed: int = 0
+    dtype: str = "bf16"           # MFMA operand type: "bf16" | "fp16"
+    unet: UNetConfig = field(default_factory=UNetConfig)
+    vae: VAEConfig = field(default_factory=VAEConfig)
