@@ -112,7 +112,8 @@ def diffueraser_forward(frames, masks2d, priori, max_img_size=960, steps=50, chu
             img = to_model_tensor(fr[s:e])
             prior = to_model_tensor(pr[s:e])
             m = torch.from_numpy(np.stack(mk[s:e]) > 0).float()[:, None]
-            noise = chunk_noise(seed, ci, (e - s, 4, H // 8, W // 8))
+            f = 2 ** (len(vcfg.block_out) - 1)                # VAE down-factor (8 for the SD VAE)
+            noise = chunk_noise(seed, ci, (e - s, 4, H // f, W // f))
             dec = denoise_chunk(P, img, m, prior, noise, steps, ucfg, vcfg, scheduler)
             w = torch.from_numpy(wts[ci])[:, None, None, None]
             acc[s:e] = (acc[s:e] * (1.0 - w)) + (dec * w)        # sequential cross-fade, fp32, chunk order
