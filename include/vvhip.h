@@ -1,0 +1,174 @@
+/* vvhip.h -- C ABI of libvvhip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the VideoVanish
+ * DiffuEraser hot path.
+ *
+ * The reference (calledit/VideoVanish) has no FFI of its own: its hot path `run_infill_on_frames`
+ * (reference diffuerase.py:20-114) calls third-party PyTorch modules (`DiffuEraser.forward`,
+ * diffuerase.py:62-67; `Propainter.forward`, diffuerase.py:52-57) whose arithmetic torch dispatches to
+ * cuDNN / SDPA library kernels.  Each entry point below replaces one such library-op class on that path
+ * (SURVEY.md section 2.1 table, section 8b "C-ABI the replacement must export"); the reference-side call that
+ * ends up in it is cited per function.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd; the Python host passes tensor.data_ptr()) unless it is
+ *     named host_*;  no ownership is transferred, nothing is allocated or freed inside;
+ *   - every launcher is asynchronous on `stream` (a hipStream_t passed as void*; 0 = default stream) and is
+ *     safe to capture into a hipGraph (no sync, no allocation);
+ *   - return value: 0 = launched, negative = VV_E_* (nothing launched); vv_last_error() gives the message of the
+ *     calling thread's last failure; no C++ exception ever crosses this boundary;
+ *   - activations are frames-major NHWC: [F][H][W][C] == a row-major [M = F*H*W][C] matrix;
+ *   - "h16" = the 16-bit MFMA operand type selected by `dtype` (VV_BF16 or VV_F16); accumulation, norm
+ *     statistics, softmax and the residual trunk are fp32.
+ */
+#ifndef VVHIP_H
+#define VVHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VV_ABI_VERSION 1
+
+enum { VV_BF16 = 0, VV_F16 = 1, VV_F32 = 2, VV_U8 = 3 };
+enum { VV_OK = 0, VV_E_ARG = -1, VV_E_UNSUPPORTED = -2, VV_E_LAUNCH = -3 };
+enum { VV_EPI_NONE = 0, VV_EPI_GEGLU = 1 };
+
+int vv_abi_version(void);
+const char* vv_last_error(void);
+/* Number of HIP devices visible / name of device `dev` (host-side probe; fails loudly with VV_E_LAUNCH). */
+int vv_device_count(void);
+int vv_device_name(int dev, char* host_buf, int buflen);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K1/K6  implicit-GEMM convolution / linear layer on MFMA (v_mfma_f32_16x16x32_{bf16,f16}).
+ *   out[m][n] = epi( sum_k A[m][k] * W[n][k] + bias[n] + rowvec[f(m)][n] + res0[m][n] + res1[m][n] )
+ * A is gathered on the fly (im2col in LDS) from one or two NHWC sources (channel concat), optionally through a
+ * nearest-neighbour resize (fused upsample) and with zero padding;  k = (ky*ks + kx)*Cin + c.
+ * Replaces: torch conv2d / linear inside UNet+BrushNet ResBlocks, transformer projections, GEGLU feed-forward,
+ * VAE convs (all reached from reference diffuerase.py:62-67 -> DiffuEraser.forward).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* in0;      /* NHWC source 0 */
+    const void* in1;      /* NHWC source 1 (channel concat after in0) or NULL */
+    int32_t in_dtype;     /* VV_BF16/VV_F16 (must equal dtype) or VV_F32 (converted while staging) */
+    int32_t C0, C1;       /* channels of in0 / in1; Cin = C0 + C1; both multiples of 8 */
+    int32_t F;            /* frames (outermost dim) */
+    int32_t Hin, Win;     /* stored spatial size of the sources */
+    int32_t Hv, Wv;       /* virtual size after nearest resize (== Hin,Win when no resize) */
+    int32_t Hout, Wout;   /* output spatial size; M = F*Hout*Wout */
+    int32_t ksize;        /* 1 or 3 */
+    int32_t stride;       /* 1 or 2 */
+    int32_t pad_t, pad_l; /* top/left zero padding (bottom/right implied by bounds) */
+    const void* weight;   /* h16 [Npad][Kpad], Kpad % 64 == 0, rows >= N are zero, Npad % tileN == 0 */
+    int32_t N;            /* real output channels */
+    int32_t K;            /* real reduction length = ksize*ksize*Cin */
+    int32_t Kpad;         /* leading dimension of weight */
+    int32_t Npad;         /* padded rows of weight */
+    const float* bias;    /* [N] or NULL */
+    const float* rowvec;  /* [F][N] per-frame additive vector (time embedding) or NULL */
+    const void* res0;     /* [M][N] residual or NULL */
+    const void* res1;     /* [M][N] second residual or NULL */
+    int32_t res_dtype;    /* VV_F32 or h16, both residuals */
+    void* out;            /* [M][Nout], Nout = N (or N/2 for GEGLU), leading dimension ldo */
+    int32_t out_dtype;    /* VV_F32 or h16 */
+    int32_t ldo;
+    int32_t epilogue;     /* VV_EPI_* ; GEGLU expects weight rows interleaved in blocks of 16: [v0..15 g0..15 v16..] */
+    float out_scale;      /* multiplies the accumulated product+bias before residuals (1.0f = none) */
+} vv_conv_params;
+int vv_conv_gemm(const vv_conv_params* host_p, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K2  GroupNorm (+SiLU) and LayerNorm (+positional embedding), fp32 statistics, h16 output.
+ * Replaces torch group_norm / layer_norm / silu in every ResBlock, transformer and motion module.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* in0; const void* in1;   /* NHWC sources (channel concat) */
+    int32_t in_dtype;                   /* VV_F32 or h16 */
+    int32_t C0, C1;                     /* multiples of 4 */
+    int32_t F, HW;                      /* frames, pixels per frame */
+    int32_t groups;
+    int32_t pool_frames;                /* 1: statistics pooled over all F frames (motion module norm) */
+    float eps;
+    const float* gamma; const float* beta;   /* [C] */
+    int32_t silu;
+    float* stats_ws;                    /* workspace: F * (nsplit + 1) * groups * 2 floats, nsplit = vv_groupnorm_nsplit() */
+    void* out; int32_t out_dtype;       /* [F*HW][C] h16 (or fp32) */
+} vv_groupnorm_params;
+int vv_groupnorm_nsplit(int HW, int C);
+int vv_groupnorm(const vv_groupnorm_params* host_p, int dtype, void* stream);
+
+/* LayerNorm over the last dim of a [M][C] fp32 matrix, eps 1e-5; out = LN(x)*gamma+beta (+ pe[(m / rows_per_frame)][c]). */
+int vv_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, const float* pe,
+                 int rows_per_frame, void* out, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K3/K4/K5  fused attention: online-softmax flash attention on MFMA with LDS-staged K/V tiles
+ * (S^T = K Q^T so every lane owns one query column; V read through ds_read_b64_tr_b16).
+ *   element (b, h, i, c) of q lives at q[b*q_bs + h*D + i*q_rs + c]  (same for k, v, o with their strides)
+ * spatial self-attention : b = frame, i = pixel (rows of the fused QKV GEMM output, row stride 3C)
+ * cross-attention        : K/V have Nkv = 77 rows, kv batch stride 0 (one text tensor for all frames)
+ * temporal attention     : b = pixel, i = frame  (q_bs = 3C, q_rs = HW*3C): the (f,hw)->(hw,f) gather is fused
+ * VAE mid-block attention: heads = 1, D = 512
+ * Replaces torch scaled_dot_product_attention in Transformer2D / motion modules / VAE.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* q; const void* k; const void* v; void* o;   /* h16 */
+    int64_t q_bs, k_bs, v_bs, o_bs;   /* batch strides (elements) */
+    int64_t q_rs, k_rs, v_rs, o_rs;   /* row strides (elements) */
+    int32_t B, heads, Nq, Nkv, D;     /* D in {32,40,64,80,160,512} */
+    float scale;                      /* softmax scale (D^-1/2) */
+} vv_attn_params;
+int vv_attention(const vv_attn_params* host_p, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K12  scheduler / latent elementwise (fp32).  Replaces scheduler.add_noise / scheduler.step.
+ * ------------------------------------------------------------------------------------------------------------ */
+/* out = ca*x + cb*y   (add_noise: ca=sqrt(abar), cb=sqrt(1-abar);  generic axpby, in place allowed) */
+int vv_axpby_f32(const float* x, const float* y, float ca, float cb, float* out, int64_t n, void* stream);
+/* DDIM / TCD update: x0 = (x - sb_t*eps)/sa_t ; out = c_x0*x0 + c_eps*eps + c_z*z (z may be NULL) */
+int vv_sched_step(const float* x, const float* eps, const float* z, float sa_t, float sb_t, float c_x0, float c_eps,
+                  float c_z, float* out, int64_t n, void* stream);
+/* trunk += addend (fp32 += fp32 or h16) */
+int vv_add_inplace(float* x, const void* y, int y_dtype, int64_t n, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K11  uint8 image steps on the path (integer / fixed-point; bit-exact against the oracle).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* reference diffuerase.py:27-31: any(mask>0 over `ch` channels) then `iters` 3x3-cross dilations (iters<1: fill
+ * whole frame iff any pixel set).  masks [T][H][W][ch] u8 -> out [T][H][W] u8 in {0,255}; tmp same size as out. */
+int vv_mask_collapse_dilate(const uint8_t* masks, int T, int H, int W, int ch, int iters, uint8_t* out, uint8_t* tmp,
+                            int32_t* flags /* [T] workspace */, void* stream);
+/* cv2.resize INTER_LINEAR / INTER_NEAREST on uint8 (reference diffuerase.py:73,86), T images [Hs][Ws][ch]. */
+int vv_resize_bilinear_u8(const uint8_t* src, int T, int Hs, int Ws, int ch, uint8_t* dst, int Hd, int Wd, void* stream);
+int vv_resize_nearest_u8(const uint8_t* src, int T, int Hs, int Ws, int ch, uint8_t* dst, int Hd, int Wd, void* stream);
+/* reference diffuerase.py:77-112: alpha from the 5x5-chamfer distance transforms of mask / inverse mask (16.16 fixed
+ * point, evaluated in a (2R+1)^2 window, R = ceil(feather_px): alpha saturates beyond), then
+ * out = clip(rint(alpha*inp + (1-alpha)*orig)).  feather_px <= 0: hard composite. */
+int vv_feather_composite(const uint8_t* inpainted, const uint8_t* orig, const uint8_t* mask2d, int T, int H, int W,
+                         float feather_px, uint8_t* out, void* stream);
+/* windowed 5x5 chamfer distance transform: distance to the nearest ZERO pixel where it is <= R, else a large
+ * constant ((INT_MAX>>2)/65536); fp32 */
+int vv_chamfer_dt(const uint8_t* bin, int T, int H, int W, int R, float* out, void* stream);
+
+/* model-side pre/post */
+/* frames u8 [T][H][W][3], mask u8 [T][H][W] -> img (x/127.5-1) and masked img (img*(1-m)) as h16 NHWC with C=8
+ * (channels 3..7 zero) ready for the VAE conv_in; either output may be NULL. */
+int vv_preprocess(const uint8_t* frames, const uint8_t* mask2d, int T, int H, int W, void* img, void* masked, int dtype,
+                  void* stream);
+/* BrushNet input: [lat(4) | cond(4) | mask_nearest(1) | 0 x7] -> h16 [F][h][w][16]; mask sampled at (y*fy, x*fx) */
+int vv_brushnet_input(const float* lat, const float* cond, const uint8_t* mask2d, int F, int h, int w, int H, int W,
+                      void* out16, int dtype, void* stream);
+/* fp32 NHWC [..][cin] -> h16 [..][cpad] (zero padded channels), used for conv_in of latents */
+int vv_pad_channels(const float* x, int64_t rows, int cin, int cpad, float scale, void* out, int dtype, void* stream);
+/* decoded [T][H][W][ld] fp32 (first 3 channels) -> pix01 = clamp(x/2+0.5,0,1) blended into acc:
+ * acc = acc*(1-w[t]) + pix*w[t]  (separately rounded fp32 products, no FMA contraction) */
+int vv_decode_blend(const float* dec, int ld, const float* w, int T, int64_t HW, float* acc, void* stream);
+/* m' = 1-(1-m)(1-blur21(m)); out = rint(255*(pix*m' + orig/255*(1-m'))) u8.  host_taps21: the 21 normalised
+ * Gaussian taps (sigma 3.5, cv2.getGaussianKernel(21,0)) as fp32 in HOST memory; tmp: T*H*W floats (device). */
+int vv_blur_compose(const float* pix01, const uint8_t* orig, const uint8_t* mask2d, int T, int H, int W,
+                    const float* host_taps21, float* tmp, uint8_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VVHIP_H */

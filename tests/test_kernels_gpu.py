@@ -1,0 +1,314 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against plain fp32 torch on the CPU.
+
+Operands are pre-rounded to the MFMA operand type (bf16 / fp16) on both sides, so the comparison isolates the
+kernel's indexing and accumulation: tolerance = fp32 accumulation-order noise (+ one h16 rounding when the kernel
+stores h16)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [("bf16", torch.bfloat16, 2 ** -8), ("fp16", torch.float16, 2 ** -11)]
+
+
+def _r(t, td):
+    return t.to(td).float()
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("dname,td,ulp", DT)
+@pytest.mark.parametrize("case", [
+    dict(F=2, H=9, W=11, cin=64, cout=160, k=3, stride=1),
+    dict(F=3, H=12, W=10, cin=128, cout=128, k=3, stride=2),
+    dict(F=2, H=7, W=5, cin=320, cout=320, k=1, stride=1),
+    dict(F=1, H=6, W=6, cin=64, cout=4, k=3, stride=1),           # tiny-N tile (conv_out)
+    dict(F=2, H=5, W=6, cin=8, cout=64, k=3, stride=1),           # padded conv_in style (K=72 -> 128)
+    dict(F=1, H=17, W=19, cin=64, cout=320, k=3, stride=1, f32in=True),
+    dict(F=2, H=33, W=29, cin=192, cout=96, k=3, stride=1),       # N padded to 128, several M tiles
+])
+def test_conv_gemm(gpu, dname, td, ulp, case):
+    from videovanish_amd import hip, packing
+    dt = hip.dtype_id(dname)
+    g = torch.Generator().manual_seed(1)
+    Fr, H, W, cin, cout, k, stride = (case[x] for x in ("F", "H", "W", "cin", "cout", "k", "stride"))
+    x = torch.randn(Fr, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    f32in = case.get("f32in", False)
+    ref = F.conv2d(_r(x, td), _r(w, td), b, stride=stride, padding=k // 2)
+    Ho, Wo = ref.shape[-2:]
+    wp, K = packing.pack_conv(w, td)
+    xin = _nhwc(x).to(gpu) if f32in else _nhwc(x).to(td).to(gpu)
+    out = hip.conv_gemm(dt, xin, wp.to(gpu), cout, K, F=Fr, Hin=H, Win=W, Hout=Ho, Wout=Wo, ksize=k, stride=stride, pad_t=k // 2,
+                        pad_l=k // 2, bias=b.to(gpu), out_dtype=torch.float32)
+    got = out.cpu().reshape(Fr, Ho, Wo, cout).permute(0, 3, 1, 2)
+    tol = 2e-4
+    assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dname,td,ulp", DT)
+def test_conv_gemm_epilogues(gpu, dname, td, ulp):
+    """concat input + fused nearest upsample + temb rowvec + two residuals + h16 output; asymmetric pad; GEGLU."""
+    from videovanish_amd import hip, packing
+    dt = hip.dtype_id(dname)
+    g = torch.Generator().manual_seed(2)
+    Fr, h, w, H, W, c0, c1, cout = 2, 6, 5, 11, 9, 64, 128, 160
+    a = torch.randn(Fr, c0, h, w, generator=g)
+    s = torch.randn(Fr, c1, h, w, generator=g)
+    wt = torch.randn(cout, c0 + c1, 3, 3, generator=g) / math.sqrt((c0 + c1) * 9)
+    bias = torch.randn(cout, generator=g)
+    temb = torch.randn(Fr, cout, generator=g)
+    r0 = torch.randn(Fr, cout, H, W, generator=g)
+    r1 = torch.randn(Fr, cout, H, W, generator=g)
+    xin = torch.cat([_r(a, td), _r(s, td)], 1)
+    up = F.interpolate(xin, size=(H, W), mode="nearest")
+    ref = F.conv2d(up, _r(wt, td), bias, padding=1) + temb[:, :, None, None] + r0 + r1
+    wp, K = packing.pack_conv(wt, td)
+    kw = dict(x1=_nhwc(s).to(td).to(gpu), F=Fr, Hin=h, Win=w, Hv=H, Wv=W, ksize=3, pad_t=1, pad_l=1, bias=bias.to(gpu))
+    out = hip.conv_gemm(dt, _nhwc(a).to(td).to(gpu), wp.to(gpu), cout, K, rowvec=temb.to(gpu), res0=_nhwc(r0).to(gpu),
+                        res1=_nhwc(r1).to(gpu), out_dtype=torch.float32, **kw)
+    got = out.cpu().reshape(Fr, H, W, cout).permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() <= 3e-4 * ref.abs().max().item()
+    # h16 output path
+    out16 = hip.conv_gemm(dt, _nhwc(a).to(td).to(gpu), wp.to(gpu), cout, K, **kw)
+    ref16 = F.conv2d(up, _r(wt, td), bias, padding=1)
+    got16 = out16.float().cpu().reshape(Fr, H, W, cout).permute(0, 3, 1, 2)
+    assert (got16 - ref16).abs().max().item() <= 2 * ulp * ref16.abs().max().item()
+    # VAE-encoder style downsample: pad (0,1,0,1), stride 2, pad 0
+    x = torch.randn(2, 64, 10, 12, generator=g)
+    wd = torch.randn(128, 64, 3, 3, generator=g) / 24.0
+    refd = F.conv2d(F.pad(_r(x, td), (0, 1, 0, 1)), _r(wd, td), None, stride=2)
+    wpd, Kd = packing.pack_conv(wd, td)
+    outd = hip.conv_gemm(dt, _nhwc(x).to(td).to(gpu), wpd.to(gpu), 128, Kd, F=2, Hin=10, Win=12, Hout=5, Wout=6, ksize=3, stride=2,
+                         pad_t=0, pad_l=0, out_dtype=torch.float32)
+    gotd = outd.cpu().reshape(2, 5, 6, 128).permute(0, 3, 1, 2)
+    assert (gotd - refd).abs().max().item() <= 3e-4 * refd.abs().max().item()
+    # GEGLU linear
+    M, C = 300, 64
+    x = torch.randn(M, C, generator=g)
+    w8 = torch.randn(8 * C, C, generator=g) / math.sqrt(C)
+    b8 = torch.randn(8 * C, generator=g)
+    hfull = F.linear(_r(x, td), _r(w8, td), b8)
+    v, gate = hfull.chunk(2, -1)
+    refg = v * F.gelu(gate)
+    wi, bi = packing.geglu_interleave(w8, b8)
+    wpk = packing.pack_matrix(wi, td, geglu=True)
+    outg = hip.conv_gemm(dt, x.to(td).to(gpu), wpk.to(gpu), 8 * C, C, F=1, Hin=M, Win=1, bias=bi.to(gpu), epilogue=hip.EPI_GEGLU,
+                         out_dtype=torch.float32)
+    assert outg.shape == (M, 4 * C)
+    assert (outg.cpu() - refg).abs().max().item() <= 3e-4 * refg.abs().max().item()
+
+
+@pytest.mark.parametrize("dname,td,ulp", DT)
+@pytest.mark.parametrize("C,groups,HW,Fr,pool,f32in", [(320, 32, 150, 2, False, True), (64, 8, 37, 3, True, True),
+                                                       (640, 32, 90, 2, False, False), (2560, 32, 20, 1, False, True)])
+def test_groupnorm(gpu, dname, td, ulp, C, groups, HW, Fr, pool, f32in):
+    from videovanish_amd import hip
+    dt = hip.dtype_id(dname)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(Fr, HW, C, generator=g) * 2 + 0.5
+    if not f32in:
+        x = _r(x, td)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    xc = x.permute(0, 2, 1)  # [F,C,HW]
+    if pool:
+        ref = F.group_norm(xc.permute(1, 0, 2).reshape(1, C, Fr * HW), groups, gamma, beta, 1e-6).reshape(C, Fr, HW).permute(1, 0, 2)
+    else:
+        ref = F.group_norm(xc, groups, gamma, beta, 1e-6)
+    ref = F.silu(ref).permute(0, 2, 1)
+    half = C // 2 // 8 * 8
+    xg = x.to(gpu) if f32in else x.to(td).to(gpu)
+    for split in (False, True):
+        if split:
+            out = hip.groupnorm(dt, xg[..., :half].contiguous(), gamma.to(gpu), beta.to(gpu), groups, 1e-6, x1=xg[..., half:].contiguous(),
+                                F=Fr, HW=HW, silu=True, pool_frames=pool, out_dtype=torch.float32)
+        else:
+            out = hip.groupnorm(dt, xg, gamma.to(gpu), beta.to(gpu), groups, 1e-6, F=Fr, HW=HW, silu=True, pool_frames=pool,
+                                out_dtype=torch.float32)
+        assert (out.cpu().reshape(Fr, HW, C) - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    out16 = hip.groupnorm(dt, xg, gamma.to(gpu), beta.to(gpu), groups, 1e-6, F=Fr, HW=HW, silu=True, pool_frames=pool)
+    assert (out16.float().cpu().reshape(Fr, HW, C) - ref).abs().max().item() <= 2 * ulp * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("dname,td,ulp", DT)
+@pytest.mark.parametrize("M,C,rpf", [(37, 320, 5), (10, 1280, 2), (9, 64, 3)])
+def test_layernorm(gpu, dname, td, ulp, M, C, rpf):
+    from videovanish_amd import hip
+    dt = hip.dtype_id(dname)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(M, C, generator=g) * 3 + 1
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    pe = torch.randn((M + rpf - 1) // rpf, C, generator=g)
+    ref = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    out = hip.layernorm(dt, x.to(gpu), gamma.to(gpu), beta.to(gpu))
+    assert (out.float().cpu() - ref).abs().max().item() <= 2 * ulp * ref.abs().max().item()
+    ref2 = ref + pe.repeat_interleave(rpf, 0)[:M]
+    out2 = hip.layernorm(dt, x.to(gpu), gamma.to(gpu), beta.to(gpu), pe=pe.to(gpu), rows_per_frame=rpf)
+    assert (out2.float().cpu() - ref2).abs().max().item() <= 2 * ulp * ref2.abs().max().item()
+
+
+def _attn_ref(q, k, v):
+    d = q.shape[-1]
+    s = (q @ k.transpose(-1, -2)) * d ** -0.5
+    return torch.softmax(s, -1) @ v
+
+
+@pytest.mark.parametrize("dname,td,ulp", DT)
+@pytest.mark.parametrize("B,heads,Nq,Nkv,D", [(2, 8, 200, 200, 40), (1, 8, 130, 130, 80), (2, 8, 70, 70, 160), (1, 1, 150, 150, 512),
+                                              (2, 2, 100, 77, 32), (3, 8, 64, 77, 40), (1, 2, 129, 129, 64)])
+def test_attention_spatial(gpu, dname, td, ulp, B, heads, Nq, Nkv, D):
+    """fused-QKV layout for self attention; separate K/V with batch stride 0 for cross attention (Nq != Nkv)."""
+    from videovanish_amd import hip
+    dt = hip.dtype_id(dname)
+    g = torch.Generator().manual_seed(5)
+    C = heads * D
+    q = _r(torch.randn(B, Nq, heads, D, generator=g), td)
+    shared_kv = Nq != Nkv
+    kb = 1 if shared_kv else B
+    k = _r(torch.randn(kb, Nkv, heads, D, generator=g) * 1.5, td)
+    v = _r(torch.randn(kb, Nkv, heads, D, generator=g), td)
+    ref = _attn_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2)      # [B,Nq,heads,D]
+    out = torch.empty(B, Nq, C, dtype=td, device=gpu)
+    if shared_kv:
+        kv = torch.cat([k.reshape(1, Nkv, C), v.reshape(1, Nkv, C)], -1).to(td).to(gpu)           # [1,Nkv,2C]
+        qd = q.reshape(B, Nq, C).to(td).to(gpu)
+        hip.attention(dt, qd, kv, kv, out, B=B, heads=heads, Nq=Nq, Nkv=Nkv, D=D, q_bs=Nq * C, k_bs=0, v_bs=0, o_bs=Nq * C, q_rs=C,
+                      k_rs=2 * C, v_rs=2 * C, o_rs=C, v_off=C)
+    else:
+        qkv = torch.cat([q.reshape(B, Nq, C), k.reshape(B, Nkv, C), v.reshape(B, Nkv, C)], -1).to(td).to(gpu)   # [B,N,3C]
+        hip.attention(dt, qkv, qkv, qkv, out, B=B, heads=heads, Nq=Nq, Nkv=Nkv, D=D, q_bs=Nq * 3 * C, k_bs=Nq * 3 * C, v_bs=Nq * 3 * C,
+                      o_bs=Nq * C, q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C, k_off=C, v_off=2 * C)
+    got = out.float().cpu().reshape(B, Nq, heads, D)
+    assert (got - ref).abs().max().item() <= 4 * ulp * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dname,td,ulp", DT)
+@pytest.mark.parametrize("Fr,HW,heads,D", [(32, 50, 8, 40), (8, 33, 8, 80), (22, 20, 8, 160), (5, 12, 2, 32)])
+def test_attention_temporal(gpu, dname, td, ulp, Fr, HW, heads, D):
+    """b = pixel, i = frame: rows of the [F*HW, 3C] QKV matrix are gathered with stride HW*3C."""
+    from videovanish_amd import hip
+    dt = hip.dtype_id(dname)
+    g = torch.Generator().manual_seed(6)
+    C = heads * D
+    qkv = _r(torch.randn(Fr, HW, 3, heads, D, generator=g), td)
+    q, k, v = (qkv[:, :, i].permute(1, 2, 0, 3) for i in range(3))       # [HW,heads,F,D]
+    ref = _attn_ref(q, k, v).permute(2, 0, 1, 3)                          # [F,HW,heads,D]
+    buf = qkv.reshape(Fr * HW, 3 * C).to(td).to(gpu)
+    out = torch.empty(Fr * HW, C, dtype=td, device=gpu)
+    hip.attention(dt, buf, buf, buf, out, B=HW, heads=heads, Nq=Fr, Nkv=Fr, D=D, q_bs=3 * C, k_bs=3 * C, v_bs=3 * C, o_bs=C, q_rs=HW * 3 * C,
+                  k_rs=HW * 3 * C, v_rs=HW * 3 * C, o_rs=HW * C, k_off=C, v_off=2 * C)
+    got = out.float().cpu().reshape(Fr, HW, heads, D)
+    assert (got - ref).abs().max().item() <= 4 * ulp * max(1.0, ref.abs().max().item())
+
+
+def test_attention_online_softmax_rescale(gpu):
+    """Force the running max to jump at a late KV tile (guide rule 26): spike one key far above the rest."""
+    from videovanish_amd import hip
+    td, dt = torch.bfloat16, hip.BF16
+    g = torch.Generator().manual_seed(7)
+    B, heads, N, D = 1, 8, 400, 40
+    C = heads * D
+    q = _r(torch.randn(B, N, heads, D, generator=g), td)
+    k = _r(torch.randn(B, N, heads, D, generator=g), td)
+    v = _r(torch.randn(B, N, heads, D, generator=g), td)
+    k[0, 333] = q[0, 17] * 6.0          # key 333 (6th tile) dominates for query 17 and shifts many maxima
+    k[0, 5] = -q[0, 200] * 6.0
+    ref = _attn_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2)
+    qkv = torch.cat([q.reshape(B, N, C), k.reshape(B, N, C), v.reshape(B, N, C)], -1).to(td).to(gpu)
+    out = torch.empty(B, N, C, dtype=td, device=gpu)
+    hip.attention(dt, qkv, qkv, qkv, out, B=B, heads=heads, Nq=N, Nkv=N, D=D, q_bs=N * 3 * C, k_bs=N * 3 * C, v_bs=N * 3 * C, o_bs=N * C,
+                  q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C, k_off=C, v_off=2 * C)
+    got = out.float().cpu().reshape(B, N, heads, D)
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 2 ** -6 * max(1.0, ref.abs().max().item())
+
+
+def test_elementwise(gpu):
+    from videovanish_amd import hip
+    g = torch.Generator().manual_seed(8)
+    x, e, z = (torch.randn(5, 7, 9, 4, generator=g) for _ in range(3))
+    out = hip.axpby(x.to(gpu), e.to(gpu), 0.3, 0.7).cpu()
+    assert torch.equal(out, np.float32(0.3) * x + np.float32(0.7) * e)
+    sa, sb, c0, c1, c2 = 0.9, 0.43, 0.95, 0.31, 0.2
+    ref = np.float32(c0) * ((x - np.float32(sb) * e) / np.float32(sa)) + np.float32(c1) * e
+    assert torch.equal(hip.sched_step(x.to(gpu), e.to(gpu), None, sa, sb, c0, c1).cpu(), ref)
+    assert torch.equal(hip.sched_step(x.to(gpu), e.to(gpu), z.to(gpu), sa, sb, c0, c1, c2).cpu(), ref + np.float32(c2) * z)
+    y = torch.randn(5, 7, 9, 4, generator=g)
+    xa = x.clone().to(gpu)
+    hip.add_inplace(hip.BF16, xa, y.to(gpu))
+    assert torch.equal(xa.cpu(), x + y)
+    xb = x.clone().to(gpu)
+    hip.add_inplace(hip.BF16, xb, y.to(torch.bfloat16).to(gpu))
+    assert torch.equal(xb.cpu(), x + y.to(torch.bfloat16).float())
+    # pad_channels / brushnet_input / preprocess / decode_blend
+    lat = torch.randn(2, 5, 6, 4, generator=g)
+    pc = hip.pad_channels(hip.BF16, lat.to(gpu), 8, 1.0).float().cpu()
+    assert torch.equal(pc[..., :4], lat.to(torch.bfloat16).float()) and (pc[..., 4:] == 0).all()
+    cond = torch.randn(2, 5, 6, 4, generator=g)
+    mask = (torch.rand(2, 40, 48, generator=g) > 0.5).to(torch.uint8) * 255
+    bi = hip.brushnet_input(hip.BF16, lat.to(gpu), cond.to(gpu), mask.to(gpu), 40, 48).float().cpu()
+    mref = F.interpolate((mask > 0).float()[:, None], size=(5, 6), mode="nearest")[:, 0]
+    assert torch.equal(bi[..., :4], lat.to(torch.bfloat16).float()) and torch.equal(bi[..., 4:8], cond.to(torch.bfloat16).float())
+    assert torch.equal(bi[..., 8], mref) and (bi[..., 9:] == 0).all()
+    fr = torch.randint(0, 256, (2, 40, 48, 3), generator=g, dtype=torch.uint8)
+    img, msk = hip.preprocess(hip.F16, fr.to(gpu), mask.to(gpu))
+    iref = (fr.float() / 127.5 - 1.0)
+    assert torch.equal(img.float().cpu()[..., :3], iref.to(torch.float16).float()) and (img.float().cpu()[..., 3:] == 0).all()
+    assert torch.equal(msk.float().cpu()[..., :3], (iref * (1 - (mask > 0).float()[..., None])).to(torch.float16).float())
+    dec = torch.randn(2, 40, 48, 16, generator=g)
+    acc = torch.rand(2, 40, 48, 3, generator=g)
+    w = torch.tensor([0.25, 1.0])
+    pix = (dec[..., :3] / 2 + 0.5).clamp(0, 1)
+    refb = acc * (1.0 - w)[:, None, None, None] + pix * w[:, None, None, None]
+    got = hip.decode_blend(dec.to(gpu), w.to(gpu), acc.clone().to(gpu)).cpu()
+    assert torch.equal(got, refb)
+
+
+def test_image_kernels_bit_exact(gpu):
+    from oracle import imageops_ref as I
+    from videovanish_amd import hip, imageops
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_intree.npz"))
+    masks = torch.from_numpy(fx["masks"]).to(gpu)
+    for k in (0, 1, 3, 8):
+        got = hip.mask_collapse_dilate(masks, k).cpu().numpy()
+        assert (got == fx[f"dilated_k{k}"]).all(), k
+    empty = torch.zeros_like(masks)
+    assert (hip.mask_collapse_dilate(empty, 0).cpu().numpy() == 0).all()
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (3, 37, 53, 3), dtype=np.uint8)
+    for (Hd, Wd) in [(40, 56), (24, 31), (37, 53), (111, 80)]:
+        got = hip.resize_u8(torch.from_numpy(img).to(gpu), Hd, Wd).cpu().numpy()
+        ref = np.stack([I.resize_bilinear_u8(f, Wd, Hd) for f in img])
+        assert (got == ref).all(), (Hd, Wd)
+        gotn = hip.resize_u8(torch.from_numpy(img).to(gpu), Hd, Wd, mode="nearest").cpu().numpy()
+        refn = np.stack([I.resize_nearest_u8(f, Wd, Hd) for f in img])
+        assert (gotn == refn).all(), (Hd, Wd)
+    # chamfer DT inside the window radius + feather composite
+    m = (rng.random((2, 45, 50)) < 0.3).astype(np.uint8) * 255
+    m[0, 10:30, 10:35] = 255
+    R = 5
+    got = hip.chamfer_dt(torch.from_numpy(m).to(gpu), R).cpu().numpy()
+    for t in range(2):
+        ref = I.distance_transform_l2_5(m[t])
+        sel = ref <= R
+        assert (got[t][sel] == ref[sel]).all()
+        assert (got[t][~sel] > R).all()
+    inp = rng.integers(0, 256, (2, 45, 50, 3), dtype=np.uint8)
+    orig = rng.integers(0, 256, (2, 45, 50, 3), dtype=np.uint8)
+    for feather in (3.0, 1.0, 0.0, 2.5):
+        got = hip.feather_composite(torch.from_numpy(inp).to(gpu), torch.from_numpy(orig).to(gpu), torch.from_numpy(m).to(gpu), feather).cpu().numpy()
+        ref = np.stack([I.composite(inp[t], orig[t], I.feather_alpha(m[t], feather)) for t in range(2)])
+        assert (got == ref).all(), feather
+    pix = rng.random((2, 45, 50, 3), dtype=np.float32)
+    got = hip.blur_compose(torch.from_numpy(pix).to(gpu), torch.from_numpy(orig).to(gpu), torch.from_numpy(m).to(gpu),
+                           imageops.gaussian_taps_21()).cpu().numpy()
+    ref = np.stack([I.blur_compose(pix[t], orig[t], m[t]) for t in range(2)])
+    assert (got == ref).all()

@@ -1,0 +1,163 @@
+"""CPU tests: the oracle against the golden vectors captured from the real reference module
+(tests/golden/make_reference_fixtures.py), and oracle self-consistency."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import imageops_ref as I
+from oracle import model_ref as M
+from oracle import pipeline_ref as R
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return np.load(os.path.join(G, "reference_intree.npz"))
+
+
+@pytest.fixture(scope="module")
+def calls():
+    return json.load(open(os.path.join(G, "reference_calls.json")))
+
+
+@pytest.mark.parametrize("k", [0, 1, 3, 8])
+def test_dilation_matches_reference(fx, k):
+    """reference diffuerase.py:27-31 (real scipy) == oracle cross dilation, incl. k=0 'until convergence'."""
+    got = np.stack(I.collapse_and_dilate(list(fx["masks"]), k))
+    assert got.dtype == np.uint8 and (got == fx[f"dilated_k{k}"]).all()
+
+
+def test_dilation_empty_mask(fx):
+    z = [np.zeros_like(fx["masks"][0])] * 3
+    assert (np.stack(I.collapse_and_dilate(z, 0)) == fx["dilated_empty_k0"]).all()
+    assert (np.stack(I.collapse_and_dilate(z, 2)) == fx["dilated_empty_k2"]).all()
+
+
+@pytest.mark.parametrize("k", [0, 1, 3, 8])
+def test_composite_arithmetic_matches_reference(fx, k):
+    """reference diffuerase.py:99-112 run on known d_in/d_out planes (stub distanceTransform) == oracle."""
+    frames = fx["frames"]
+    mo = fx[f"model_out_k{k}"][0]
+    H0, W0 = frames[0].shape[:2]
+    rz = mo[(np.arange(H0) * mo.shape[0] // H0)][:, (np.arange(W0) * mo.shape[1] // W0)]   # the stub resize used at capture
+    a = I.feather_alpha(fx[f"dilated_k{k}"][0], 3, fx[f"d_in_k{k}"], fx[f"d_out_k{k}"])
+    assert (I.composite(rz, frames[0], a) == fx[f"result0_k{k}"]).all()
+
+
+def test_hard_composite_and_nokeep(fx):
+    d3 = I.collapse_and_dilate(list(fx["masks"]), 3)
+    r = I.composite(fx["model_out_hard"][0], fx["frames"][0], I.feather_alpha(d3[0], 0))
+    assert (r == fx["result0_hard"]).all()
+    assert (fx["result0_nokeep"] == fx["model_out_hard"][0]).all() or fx["result0_nokeep"].shape == fx["frames"][0].shape
+
+
+def test_reference_call_contract(calls):
+    """What crosses the third-party boundary (reference diffuerase.py:39-45,52-57,62-67) and the prog sequence."""
+    c = calls["k8"]
+    assert c["prog"] == [[5, "dilating frames"], [10, "loading weights"], [20, "running propainter prior"],
+                         [50, "running DiffuEraser"], [90, "resizing and merging finished frames"]]
+    assert c["de_ctor"][0] == ["cpu", "stable-diffusion-v1-5/stable-diffusion-v1-5", "stabilityai/sd-vae-ft-mse", "lixiaowen/diffuEraser"]
+    assert c["de_ctor"][1] == {"ckpt": "2-Step"}
+    assert c["de_fwd"]["kw"] == {"max_img_size": 960, "mask_dilation_iter": 0, "guidance_scale": None}
+    assert c["pp_fwd"]["kw"] == {"ref_stride": 10, "neighbor_length": 10, "subvideo_length": 50, "mask_dilation": 0}
+    assert c["de_fwd"]["mask_shape"] == [40, 56] and c["de_fwd"]["mask_dtype"] == "uint8"
+    assert c["out_shapes"][0] == [40, 56, 3] and c["out_shapes"][1] == [32, 48, 3]     # early return: only frame 0 resized
+    assert calls["prior_given"]["pp_called"] is False
+    assert [p[0] for p in calls["prior_given"]["prog"]] == [5, 10, 50, 90]
+
+
+def test_chamfer_closed_form_equals_two_pass():
+    rng = np.random.default_rng(0)
+    for dens in (0.02, 0.5):
+        m = np.where(rng.random((28, 33)) < dens, 0, 255).astype(np.uint8)
+        dt = I.distance_transform_l2_5(m)
+        zs = np.argwhere(m == 0)
+        bf = np.array([[min(I.chamfer_metric_fixed(x - zx, y - zy) for zy, zx in zs) for x in range(33)] for y in range(28)],
+                      dtype=np.float32) * np.float32(1 / 65536)
+        assert (bf == dt).all()
+    assert I.distance_transform_l2_5(np.full((5, 6), 255, np.uint8)).min() > 1000    # no zero pixel: saturates
+    k = I.chamfer_metric_fixed
+    assert (k(1, 0), k(1, 1), k(2, 1)) == (65536, 91750, 143976)
+
+
+def test_resize_identity_and_shapes():
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (17, 23, 3), dtype=np.uint8)
+    assert (I.resize_bilinear_u8(img, 23, 17) == img).all()
+    up = I.resize_bilinear_u8(img, 46, 34)
+    assert up.shape == (34, 46, 3) and abs(int(up.mean()) - int(img.mean())) <= 2
+    const = np.full((9, 9, 3), 77, np.uint8)
+    assert (I.resize_bilinear_u8(const, 20, 31) == 77).all()
+    assert (I.resize_nearest_u8(img, 23, 17) == img).all()
+
+
+def test_chunk_plan_properties():
+    for T in (1, 8, 32, 33, 40, 60, 64, 256, 257, 1024):
+        plan = R.chunk_plan(T, 32, 8)
+        cov = np.zeros(T, int)
+        for s, e in plan:
+            assert 0 <= s < e <= T and (e - s == 32 or T < 32)
+            cov[s:e] += 1
+        assert (cov >= 1).all()
+        w = R.blend_weights(plan)
+        tot = np.zeros(T, np.float64)           # sequential cross-fade == convex combination: weights sum to 1
+        for (s, e), ww in zip(plan, w):
+            tot[s:e] = tot[s:e] * (1 - ww) + ww
+        assert np.allclose(tot, 1.0)
+    assert len(R.chunk_plan(256, 32, 8)) == 11 and len(R.chunk_plan(1024, 32, 8)) == 43
+
+
+def test_schedulers():
+    ac = M.alphas_cumprod()
+    assert M.ddim_timesteps(50)[:2] == [981, 961] and M.ddim_timesteps(50)[-1] == 1
+    assert M.tcd_timesteps(2) == [999, 499]
+    x, e = torch.randn(3, 4), torch.randn(3, 4)
+    # DDIM step with eps consistent with x0 returns the exact re-noised x0
+    x0 = torch.randn(3, 4)
+    t = 981
+    xt = M.add_noise(x0, e, t, ac)
+    xp = M.ddim_step(xt, e, t, 50, ac)
+    assert torch.allclose(xp, M.add_noise(x0, e, t - 20, ac), atol=1e-5)
+
+
+def test_model_oracle_determinism_and_shapes():
+    from videovanish_amd.config import TINY_UNET, TINY_VAE
+    P1, P2 = M.Params(0), M.Params(0)
+    torch.manual_seed(0)
+    lat = torch.randn(3, 4, 6, 5)
+    text = M.text_states(P1, TINY_UNET)
+    x9 = torch.cat([lat, lat * 0.5, torch.ones(3, 1, 6, 5)], 1)
+    with torch.no_grad():
+        b = M.brushnet_forward(P1, x9, 500, text, TINY_UNET)
+        e1 = M.unet_forward(P1, lat, 500, text, TINY_UNET, b)
+        e2 = M.unet_forward(P2, lat, 500, M.text_states(P2, TINY_UNET), TINY_UNET, M.brushnet_forward(P2, x9, 500, text, TINY_UNET))
+        z = M.vae_encode(P1, torch.rand(2, 3, 16, 24) * 2 - 1, TINY_VAE)
+        d = M.vae_decode(P1, z, TINY_VAE)
+    assert e1.shape == lat.shape and torch.equal(e1, e2) and torch.isfinite(e1).all()
+    assert len(b[0]) == 1 + 2 * 1 + 1 and len(b[2]) == 2 * 2 + 1          # down skips, up outputs (tiny config)
+    assert z.shape == (2, 4, 8, 12) and d.shape == (2, 3, 16, 24)
+    # motion module couples frames: changing one frame changes the others' eps
+    lat2 = lat.clone(); lat2[0] += 1.0
+    with torch.no_grad():
+        e3 = M.unet_forward(P1, lat2, 500, text, TINY_UNET, b)
+    assert (e3[2] - e1[2]).abs().max() > 1e-4
+
+
+def test_pipeline_oracle_end_to_end_tiny():
+    from videovanish_amd.config import TINY_UNET, TINY_VAE
+    rng = np.random.default_rng(1234)
+    T, H, W = 5, 24, 32
+    frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(T)]
+    masks = []
+    for t in range(T):
+        m = np.zeros((H, W, 3), np.uint8); m[6:14, 8 + 2 * t:16 + 2 * t] = 255; masks.append(m)
+    out = R.run_infill_on_frames(frames, masks, 2, [f.copy() for f in frames], steps=2, chunk=4, overlap=2, ucfg=TINY_UNET, vcfg=TINY_VAE)
+    assert len(out) == T and all(o.shape == (H, W, 3) and o.dtype == np.uint8 for o in out)
+    dil = I.collapse_and_dilate(masks, 2)
+    far = I.distance_transform_l2_5(np.bitwise_not(dil[0])) >= 3        # >= feather_px outside the mask: untouched
+    assert (out[0][far] == frames[0][far]).all()
+    assert (out[0][dil[0] > 0] != frames[0][dil[0] > 0]).any()

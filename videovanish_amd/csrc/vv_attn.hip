@@ -1,0 +1,260 @@
+// K3/K4/K5: flash attention on MFMA for gfx950 (spatial self-attention, 77-token cross-attention, temporal
+// attention over the frame axis, VAE mid-block attention).  See include/vvhip.h (vv_attention).
+//
+// Per wave: QT tiles of 16 queries.  S^T = K Q^T (mfma 16x16x32: A = K rows from LDS, B = Q held in registers),
+// so every lane owns ONE query column: the online-softmax max/sum/rescale are lane-local plus two cross-lane
+// exchanges, and the accumulator registers of S^T are -- after exp2 and packing -- directly the B operand of
+// O^T = V^T P^T.  V^T operands come from the row-major V tile through ds_read_b64_tr_b16 (hardware transpose).
+// Head dims that are not MFMA multiples are zero-padded in LDS only (K-dim to 32, V-dim to 16).
+#include "vv_common.h"
+
+namespace {
+
+__device__ __forceinline__ uint2 ds_read_tr16(const unsigned char* lds_ptr) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)lds_ptr);
+    return __builtin_bit_cast(uint2, v);
+}
+
+template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH>
+__global__ __launch_bounds__(NW * 64) void attn_kernel(const vv_attn_params p, const int nqt) {
+    constexpr int DK = (D + 31) / 32 * 32, DKC = DK / 8, KS = DK / 32;
+    constexpr int DV = (D + 15) / 16 * 16, DVC = DV / 8, NDT = DV / 16;
+    constexpr int KT = KVT / 16, US = KVT / 32;
+    constexpr int PK = DK * 2 + 16, PV = DV * 2 + 16;
+    constexpr int NT = NW * 64;
+    constexpr int KCH = (KVT * DKC + NT - 1) / NT, VCH = (KVT * DVC + NT - 1) / NT;
+    constexpr int BQ = NW * QT * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sK = smem;
+    unsigned char* sV = smem + KVT * PK;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    int bid = blockIdx.x;
+    const int qt = bid % nqt; bid /= nqt;
+    const int h = bid % p.heads; const int b = bid / p.heads;
+
+    const unsigned short* Q = (const unsigned short*)p.q + (int64_t)b * p.q_bs + (int64_t)h * D;
+    const unsigned short* Kp = (const unsigned short*)p.k + (int64_t)b * p.k_bs + (int64_t)h * D;
+    const unsigned short* Vp = (const unsigned short*)p.v + (int64_t)b * p.v_bs + (int64_t)h * D;
+    unsigned short* O = (unsigned short*)p.o + (int64_t)b * p.o_bs + (int64_t)h * D;
+
+    const int q0 = qt * BQ + wave * QT * 16;
+    // ---- Q fragments (B operand of S^T): lane holds Q[q0 + j*16 + li][s*32 + lg*8 .. +7]
+    uint4 qf[QT][KS];
+#pragma unroll
+    for (int j = 0; j < QT; ++j)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int q = q0 + j * 16 + li, d0 = s * 32 + lg * 8;
+            qf[j][s] = (q < p.Nq && d0 < D) ? *(const uint4*)(Q + (int64_t)q * p.q_rs + d0) : make_uint4(0, 0, 0, 0);
+        }
+
+    f32x4 oacc[NDT][QT];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int j = 0; j < QT; ++j) oacc[d][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int j = 0; j < QT; ++j) { mrun[j] = -1e30f; lrun[j] = 0.f; }
+    const float c = p.scale * 1.4426950408889634f;
+
+    uint4 rk[KCH], rv[VCH];
+    auto load_kv = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int idx = t + NT * i;
+            const int row = idx / DKC, ch = idx - row * DKC;
+            const int key = kv0 + row;
+            rk[i] = (idx < KVT * DKC && key < p.Nkv && ch * 8 < D) ? *(const uint4*)(Kp + (int64_t)key * p.k_rs + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            const int idx = t + NT * i;
+            const int row = idx / DVC, ch = idx - row * DVC;
+            const int key = kv0 + row;
+            rv[i] = (idx < KVT * DVC && key < p.Nkv && ch * 8 < D) ? *(const uint4*)(Vp + (int64_t)key * p.v_rs + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_kv = [&]() {
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int idx = t + NT * i;
+            const int row = idx / DKC, ch = idx - row * DKC;
+            if (KVT * DKC % NT == 0 || idx < KVT * DKC) *(uint4*)(sK + row * PK + ch * 16) = rk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            const int idx = t + NT * i;
+            const int row = idx / DVC, ch = idx - row * DVC;
+            if (KVT * DVC % NT == 0 || idx < KVT * DVC) *(uint4*)(sV + row * PV + ch * 16) = rv[i];
+        }
+    };
+
+    const int ntiles = (p.Nkv + KVT - 1) / KVT;
+    load_kv(0);
+    store_kv();
+    __syncthreads();
+    for (int it = 0; it < ntiles; ++it) {
+        const int kv0 = it * KVT;
+        if (PREFETCH && it + 1 < ntiles) load_kv(kv0 + KVT);
+
+        // ---- S^T = K Q^T
+        f32x4 sacc[KT][QT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int j = 0; j < QT; ++j) sacc[kt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const uint4 kf = *(const uint4*)(sK + (kt * 16 + li) * PK + (s * 4 + lg) * 16);
+#pragma unroll
+                for (int j = 0; j < QT; ++j) sacc[kt][j] = T::mfma(kf, qf[j][s], sacc[kt][j]);
+            }
+        }
+        // ---- mask keys beyond Nkv (last tile only)
+        if (kv0 + KVT > p.Nkv) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kv0 + kt * 16 + lg * 4 + r >= p.Nkv) {
+#pragma unroll
+                        for (int j = 0; j < QT; ++j) sacc[kt][j][r] = -1e30f;
+                    }
+        }
+        // ---- online softmax (per query column = per lane, replicated over the 4 lane groups)
+        uint4 pb[US][QT];
+#pragma unroll
+        for (int j = 0; j < QT; ++j) {
+            float mx = sacc[0][j][0];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kt][j][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[j], mx);
+            const float alpha = exp2f((mrun[j] - mnew) * c);
+            mrun[j] = mnew;
+            const float mc = mnew * c;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f(sacc[kt][j][r] * c - mc);
+                    sacc[kt][j][r] = e;
+                    ps += e;
+                }
+            lrun[j] = lrun[j] * alpha + ps;
+#pragma unroll
+            for (int d = 0; d < NDT; ++d) oacc[d][j] *= alpha;
+#pragma unroll
+            for (int u = 0; u < US; ++u)
+                pb[u][j] = make_uint4(pack2<T>(sacc[2 * u][j][0], sacc[2 * u][j][1]), pack2<T>(sacc[2 * u][j][2], sacc[2 * u][j][3]),
+                                      pack2<T>(sacc[2 * u + 1][j][0], sacc[2 * u + 1][j][1]), pack2<T>(sacc[2 * u + 1][j][2], sacc[2 * u + 1][j][3]));
+        }
+        // ---- O^T += V^T P^T   (A = V^T via transposed LDS reads; k-slot order matches the packing of pb)
+#pragma unroll
+        for (int u = 0; u < US; ++u) {
+#pragma unroll
+            for (int d = 0; d < NDT; ++d) {
+                const unsigned char* a0 = sV + (u * 32 + 4 * lg + (li >> 2)) * PV + (d * 16 + 4 * (li & 3)) * 2;
+                const uint2 lo = ds_read_tr16(a0);
+                const uint2 hi = ds_read_tr16(a0 + 16 * PV);
+                const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                for (int j = 0; j < QT; ++j) oacc[d][j] = T::mfma(vf, pb[u][j], oacc[d][j]);
+            }
+        }
+        __syncthreads();
+        if (it + 1 < ntiles) {
+            if (!PREFETCH) load_kv(kv0 + KVT);
+            store_kv();
+            __syncthreads();
+        }
+    }
+    // ---- finalize: O[q][d] = O^T[d][q] / l
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+        float l = lrun[j];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int q = q0 + j * 16 + li;
+        if (q < p.Nq) {
+#pragma unroll
+            for (int d = 0; d < NDT; ++d) {
+                const int dd = d * 16 + lg * 4;
+                if (dd < D) {
+                    const uint2 o2 = make_uint2(pack2<T>(oacc[d][j][0] * inv, oacc[d][j][1] * inv), pack2<T>(oacc[d][j][2] * inv, oacc[d][j][3] * inv));
+                    *(uint2*)(O + (int64_t)q * p.o_rs + dd) = o2;
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH>
+int attn_launch(const vv_attn_params& p, hipStream_t st) {
+    constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
+    constexpr int PK = DK * 2 + 16, PV = DV * 2 + 16;
+    constexpr int BQ = NW * QT * 16;
+    const size_t lds = (size_t)KVT * (PK + PV);
+    const int nqt = (p.Nq + BQ - 1) / BQ;
+    const int64_t nblk = (int64_t)p.B * p.heads * nqt;
+    if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_attention: grid too large");
+    auto kern = attn_kernel<T, D, QT, KVT, NW, PREFETCH>;
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            VV_FAIL(VV_E_LAUNCH, "vv_attention: cannot set dynamic LDS size %zu", lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NW * 64), lds, st, p, nqt);
+    VV_CHECK_LAUNCH("vv_attention");
+    return VV_OK;
+}
+
+template <typename T, int D>
+int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
+    if constexpr (D >= 512) {
+        return attn_launch<T, D, 1, 32, 4, false>(p, st);
+    } else {
+        // short sequences (temporal attention over <=32 frames, tiny test shapes): one wave per block, 32-key tiles
+        if (p.Nq <= 32 && p.Nkv <= 32) return attn_launch<T, D, 2, 32, 1, true>(p, st);
+        return attn_launch<T, D, 2, 64, 4, true>(p, st);
+    }
+}
+
+template <typename T>
+int attn_by_d(const vv_attn_params& p, hipStream_t st) {
+    switch (p.D) {
+        case 32: return attn_dispatch<T, 32>(p, st);
+        case 40: return attn_dispatch<T, 40>(p, st);
+        case 64: return attn_dispatch<T, 64>(p, st);
+        case 80: return attn_dispatch<T, 80>(p, st);
+        case 160: return attn_dispatch<T, 160>(p, st);
+        case 512: return attn_dispatch<T, 512>(p, st);
+        default: VV_FAIL(VV_E_UNSUPPORTED, "vv_attention: head dim %d not built (32,40,64,80,160,512)", p.D);
+    }
+}
+
+}  // namespace
+
+extern "C" int vv_attention(const vv_attn_params* pp, int dtype, void* stream) {
+    if (!pp) VV_FAIL(VV_E_ARG, "vv_attention: null params");
+    const vv_attn_params& p = *pp;
+    if (!p.q || !p.k || !p.v || !p.o) VV_FAIL(VV_E_ARG, "vv_attention: null pointer");
+    if (p.B <= 0 || p.heads <= 0 || p.Nq <= 0 || p.Nkv <= 0) VV_FAIL(VV_E_ARG, "vv_attention: empty problem");
+    if ((p.q_rs | p.k_rs | p.v_rs | p.o_rs | p.q_bs | p.k_bs | p.v_bs | p.o_bs) & 3) VV_FAIL(VV_E_ARG, "vv_attention: strides must be multiples of 4 elements (q/k/v: 8)");
+    if ((p.q_rs | p.k_rs | p.v_rs | p.q_bs | p.k_bs | p.v_bs) & 7) VV_FAIL(VV_E_ARG, "vv_attention: q/k/v strides must be multiples of 8 elements");
+    if (dtype == VV_BF16) return attn_by_d<BF16>(p, (hipStream_t)stream);
+    if (dtype == VV_F16) return attn_by_d<F16>(p, (hipStream_t)stream);
+    VV_FAIL(VV_E_ARG, "vv_attention: bad dtype");
+}

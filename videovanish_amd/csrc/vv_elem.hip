@@ -1,0 +1,161 @@
+// K12 + model-side pre/post elementwise kernels (HBM-bound, vectorised where the layout allows).
+// Floating-point contraction is OFF in this file: the blend / scheduler arithmetic is specified as separately
+// rounded fp32 operations so that single-GPU, multi-GPU and the CPU oracle agree bit for bit.
+#include "vv_common.h"
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int EB = 256;
+inline dim3 grid_for(int64_t n, int per = 1) {
+    int64_t b = (n + (int64_t)EB * per - 1) / ((int64_t)EB * per);
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return dim3((unsigned)b);
+}
+
+__global__ void axpby_kernel(const float* x, const float* y, float ca, float cb, float* out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) out[i] = ca * x[i] + cb * y[i];
+}
+
+__global__ void sched_step_kernel(const float* x, const float* eps, const float* z, float sa_t, float sb_t, float c_x0, float c_eps,
+                                  float c_z, float* out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) {
+        const float e = eps[i];
+        const float x0 = (x[i] - sb_t * e) / sa_t;
+        float v = c_x0 * x0 + c_eps * e;
+        if (z) v = v + c_z * z[i];
+        out[i] = v;
+    }
+}
+
+template <typename T>
+__global__ void add_inplace_kernel(float* x, const void* y, int y_f32, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB)
+        x[i] = x[i] + (y_f32 ? ((const float*)y)[i] : T::to_f32(((const unsigned short*)y)[i]));
+}
+
+template <typename T>
+__global__ void preprocess_kernel(const uint8_t* frames, const uint8_t* mask, int64_t npix, unsigned short* img, unsigned short* masked) {
+    for (int64_t i = blockIdx.x * (int64_t)EB + threadIdx.x; i < npix; i += (int64_t)gridDim.x * EB) {
+        float v[8], w[8];
+        const float keep = (mask && mask[i] > 0) ? 0.f : 1.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { v[c] = (float)frames[i * 3 + c] / 127.5f - 1.0f; w[c] = v[c] * keep; }
+#pragma unroll
+        for (int c = 3; c < 8; ++c) { v[c] = 0.f; w[c] = 0.f; }
+        if (img) *(uint4*)(img + i * 8) = pack8<T>(v);
+        if (masked) *(uint4*)(masked + i * 8) = pack8<T>(w);
+    }
+}
+
+template <typename T>
+__global__ void brushnet_input_kernel(const float* lat, const float* cond, const uint8_t* mask, int F, int h, int w, int H, int W, unsigned short* out) {
+    const int64_t n = (int64_t)F * h * w;
+    for (int64_t i = blockIdx.x * (int64_t)EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) {
+        const int x = (int)(i % w); const int64_t r = i / w; const int y = (int)(r % h); const int f = (int)(r / h);
+        const int ys = (int)(((int64_t)y * H) / h), xs = (int)(((int64_t)x * W) / w);
+        float v[16];
+        const float4 a = *(const float4*)(lat + i * 4), b = *(const float4*)(cond + i * 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        v[8] = mask[((int64_t)f * H + ys) * W + xs] > 0 ? 1.f : 0.f;
+#pragma unroll
+        for (int c = 9; c < 16; ++c) v[c] = 0.f;
+        *(uint4*)(out + i * 16) = pack8<T>(v);
+        *(uint4*)(out + i * 16 + 8) = pack8<T>(v + 8);
+    }
+}
+
+template <typename T>
+__global__ void pad_channels_kernel(const float* x, int64_t rows, int cin, int cpad, float scale, unsigned short* out) {
+    const int64_t n = rows * cpad;
+    for (int64_t i = blockIdx.x * (int64_t)EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) {
+        const int c = (int)(i % cpad); const int64_t r = i / cpad;
+        out[i] = T::from_f32(c < cin ? x[r * cin + c] * scale : 0.f);
+    }
+}
+
+__global__ void decode_blend_kernel(const float* dec, int ld, const float* w, int T, int64_t HW, float* acc) {
+    const int64_t n = (int64_t)T * HW;
+    for (int64_t i = blockIdx.x * (int64_t)EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) {
+        const float wt = w[i / HW];
+        const float om = 1.0f - wt;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float p = dec[i * ld + c] / 2.0f + 0.5f;
+            p = fminf(fmaxf(p, 0.f), 1.f);
+            const float a = acc[i * 3 + c] * om;
+            const float b = p * wt;
+            acc[i * 3 + c] = a + b;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vv_axpby_f32(const float* x, const float* y, float ca, float cb, float* out, int64_t n, void* stream) {
+    if (!x || !y || !out || n < 0) VV_FAIL(VV_E_ARG, "vv_axpby_f32: bad args");
+    if (n == 0) return VV_OK;
+    hipLaunchKernelGGL(axpby_kernel, grid_for(n), dim3(EB), 0, (hipStream_t)stream, x, y, ca, cb, out, n);
+    VV_CHECK_LAUNCH("vv_axpby_f32");
+    return VV_OK;
+}
+
+extern "C" int vv_sched_step(const float* x, const float* eps, const float* z, float sa_t, float sb_t, float c_x0, float c_eps, float c_z,
+                             float* out, int64_t n, void* stream) {
+    if (!x || !eps || !out || n < 0) VV_FAIL(VV_E_ARG, "vv_sched_step: bad args");
+    if (n == 0) return VV_OK;
+    hipLaunchKernelGGL(sched_step_kernel, grid_for(n), dim3(EB), 0, (hipStream_t)stream, x, eps, z, sa_t, sb_t, c_x0, c_eps, c_z, out, n);
+    VV_CHECK_LAUNCH("vv_sched_step");
+    return VV_OK;
+}
+
+extern "C" int vv_add_inplace(float* x, const void* y, int y_dtype, int64_t n, int dtype, void* stream) {
+    if (!x || !y || n < 0) VV_FAIL(VV_E_ARG, "vv_add_inplace: bad args");
+    if (y_dtype != VV_F32 && y_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_add_inplace: y_dtype mismatch");
+    if (n == 0) return VV_OK;
+    if (dtype == VV_BF16) hipLaunchKernelGGL(add_inplace_kernel<BF16>, grid_for(n), dim3(EB), 0, (hipStream_t)stream, x, y, y_dtype == VV_F32, n);
+    else if (dtype == VV_F16) hipLaunchKernelGGL(add_inplace_kernel<F16>, grid_for(n), dim3(EB), 0, (hipStream_t)stream, x, y, y_dtype == VV_F32, n);
+    else VV_FAIL(VV_E_ARG, "vv_add_inplace: bad dtype");
+    VV_CHECK_LAUNCH("vv_add_inplace");
+    return VV_OK;
+}
+
+extern "C" int vv_preprocess(const uint8_t* frames, const uint8_t* mask2d, int T, int H, int W, void* img, void* masked, int dtype, void* stream) {
+    if (!frames || T <= 0 || H <= 0 || W <= 0 || (!img && !masked)) VV_FAIL(VV_E_ARG, "vv_preprocess: bad args");
+    if (masked && !mask2d) VV_FAIL(VV_E_ARG, "vv_preprocess: masked output needs a mask");
+    const int64_t n = (int64_t)T * H * W;
+    if (dtype == VV_BF16) hipLaunchKernelGGL(preprocess_kernel<BF16>, grid_for(n), dim3(EB), 0, (hipStream_t)stream, frames, mask2d, n, (unsigned short*)img, (unsigned short*)masked);
+    else if (dtype == VV_F16) hipLaunchKernelGGL(preprocess_kernel<F16>, grid_for(n), dim3(EB), 0, (hipStream_t)stream, frames, mask2d, n, (unsigned short*)img, (unsigned short*)masked);
+    else VV_FAIL(VV_E_ARG, "vv_preprocess: bad dtype");
+    VV_CHECK_LAUNCH("vv_preprocess");
+    return VV_OK;
+}
+
+extern "C" int vv_brushnet_input(const float* lat, const float* cond, const uint8_t* mask2d, int F, int h, int w, int H, int W, void* out16,
+                                 int dtype, void* stream) {
+    if (!lat || !cond || !mask2d || !out16 || F <= 0 || h <= 0 || w <= 0) VV_FAIL(VV_E_ARG, "vv_brushnet_input: bad args");
+    const int64_t n = (int64_t)F * h * w;
+    if (dtype == VV_BF16) hipLaunchKernelGGL(brushnet_input_kernel<BF16>, grid_for(n), dim3(EB), 0, (hipStream_t)stream, lat, cond, mask2d, F, h, w, H, W, (unsigned short*)out16);
+    else if (dtype == VV_F16) hipLaunchKernelGGL(brushnet_input_kernel<F16>, grid_for(n), dim3(EB), 0, (hipStream_t)stream, lat, cond, mask2d, F, h, w, H, W, (unsigned short*)out16);
+    else VV_FAIL(VV_E_ARG, "vv_brushnet_input: bad dtype");
+    VV_CHECK_LAUNCH("vv_brushnet_input");
+    return VV_OK;
+}
+
+extern "C" int vv_pad_channels(const float* x, int64_t rows, int cin, int cpad, float scale, void* out, int dtype, void* stream) {
+    if (!x || !out || rows <= 0 || cin <= 0 || cpad < cin) VV_FAIL(VV_E_ARG, "vv_pad_channels: bad args");
+    const int64_t n = rows * cpad;
+    if (dtype == VV_BF16) hipLaunchKernelGGL(pad_channels_kernel<BF16>, grid_for(n), dim3(EB), 0, (hipStream_t)stream, x, rows, cin, cpad, scale, (unsigned short*)out);
+    else if (dtype == VV_F16) hipLaunchKernelGGL(pad_channels_kernel<F16>, grid_for(n), dim3(EB), 0, (hipStream_t)stream, x, rows, cin, cpad, scale, (unsigned short*)out);
+    else VV_FAIL(VV_E_ARG, "vv_pad_channels: bad dtype");
+    VV_CHECK_LAUNCH("vv_pad_channels");
+    return VV_OK;
+}
+
+extern "C" int vv_decode_blend(const float* dec, int ld, const float* w, int T, int64_t HW, float* acc, void* stream) {
+    if (!dec || !w || !acc || T <= 0 || HW <= 0 || ld < 3) VV_FAIL(VV_E_ARG, "vv_decode_blend: bad args");
+    hipLaunchKernelGGL(decode_blend_kernel, grid_for((int64_t)T * HW), dim3(EB), 0, (hipStream_t)stream, dec, ld, w, T, HW, acc);
+    VV_CHECK_LAUNCH("vv_decode_blend");
+    return VV_OK;
+}

@@ -1,0 +1,233 @@
+// K2: GroupNorm(+SiLU) and LayerNorm(+positional embedding) for frames-major NHWC activations.  HBM-bound:
+// every element is read twice (statistics pass, apply pass) with 16/32-byte vector loads and written once as h16.
+#include "vv_common.h"
+
+namespace {
+
+struct GNGeom {
+    int C8;          // 8-channel chunks per pixel
+    int krows;      // pixel rows handled per block pass
+    int threads;     // active threads = krows * C8
+    int rows_per_split;
+    int nsplit;
+};
+
+__host__ __device__ inline GNGeom gn_geom(int HW, int C) {
+    GNGeom g;
+    g.C8 = C / 8;
+    g.krows = g.C8 >= 256 ? 1 : 256 / g.C8;
+    g.threads = g.krows * g.C8;
+    int rows = 32768 / C; if (rows < g.krows) rows = g.krows;
+    rows = (rows + g.krows - 1) / g.krows * g.krows;
+    int ns = (HW + rows - 1) / rows;
+    if (ns > 128) { ns = 128; rows = ((HW + ns - 1) / ns + g.krows - 1) / g.krows * g.krows; ns = (HW + rows - 1) / rows; }
+    g.rows_per_split = rows; g.nsplit = ns;
+    return g;
+}
+
+template <typename T>
+__device__ __forceinline__ void gn_load8(const vv_groupnorm_params& p, int64_t pix, int chunk, float* v) {
+    int c = chunk * 8;
+    const unsigned char* src = (const unsigned char*)p.in0;
+    int Cs = p.C0;
+    if (c >= p.C0) { src = (const unsigned char*)p.in1; c -= p.C0; Cs = p.C1; }
+    const int64_t off = pix * Cs + c;
+    if (p.in_dtype == VV_F32) {
+        const float4* g = (const float4*)(src + off * 4);
+        *(float4*)&v[0] = g[0]; *(float4*)&v[4] = g[1];
+    } else {
+        unpack8<T>(*(const uint4*)(src + off * 2), v);
+    }
+}
+
+template <typename T>
+__global__ void gn_stats_kernel(const vv_groupnorm_params p, const GNGeom g) {
+    __shared__ float sh[2 * 64];
+    const int t = threadIdx.x, split = blockIdx.x, f = blockIdx.y;
+    const int C = p.C0 + p.C1, cpg = C / p.groups;
+    for (int i = t; i < 2 * p.groups; i += blockDim.x) sh[i] = 0.f;
+    __syncthreads();
+    if (t < g.threads) {
+        const int chunk = t % g.C8, r0 = t / g.C8;
+        float s[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        const int rbeg = split * g.rows_per_split;
+        const int rend = min(rbeg + g.rows_per_split, p.HW);
+        for (int r = rbeg + r0; r < rend; r += g.krows) {
+            float v[8];
+            gn_load8<T>(p, (int64_t)f * p.HW + r, chunk, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+        }
+        // combine the 8 channels into their groups (a chunk may straddle up to 8 groups when cpg is small)
+        int c = chunk * 8;
+        float ss = 0.f, qq = 0.f;
+        int gcur = c / cpg;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ge = (c + e) / cpg;
+            if (ge != gcur) { atomicAdd(&sh[2 * gcur], ss); atomicAdd(&sh[2 * gcur + 1], qq); ss = 0.f; qq = 0.f; gcur = ge; }
+            ss += s[e]; qq += q[e];
+        }
+        atomicAdd(&sh[2 * gcur], ss); atomicAdd(&sh[2 * gcur + 1], qq);
+    }
+    __syncthreads();
+    float* ws = p.stats_ws + ((int64_t)f * g.nsplit + split) * p.groups * 2;
+    for (int i = t; i < 2 * p.groups; i += blockDim.x) ws[i] = sh[i];
+}
+
+// one block per frame (or one block when statistics pool over the clip): partials -> mean / rstd
+__global__ void gn_finalize_kernel(const vv_groupnorm_params p, const GNGeom g) {
+    const int grp = threadIdx.x;
+    if (grp >= p.groups) return;
+    const int C = p.C0 + p.C1, cpg = C / p.groups;
+    const int f0 = p.pool_frames ? 0 : blockIdx.x, f1 = p.pool_frames ? p.F : blockIdx.x + 1;
+    double s = 0.0, q = 0.0;
+    for (int f = f0; f < f1; ++f)
+        for (int sp = 0; sp < g.nsplit; ++sp) {
+            const float* ws = p.stats_ws + (((int64_t)f * g.nsplit + sp) * p.groups + grp) * 2;
+            s += ws[0]; q += ws[1];
+        }
+    const double n = (double)(f1 - f0) * p.HW * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float* fin = p.stats_ws + (int64_t)p.F * g.nsplit * p.groups * 2;
+    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    if (p.pool_frames) {
+        for (int f = 0; f < p.F; ++f) { fin[((int64_t)f * p.groups + grp) * 2] = (float)mean; fin[((int64_t)f * p.groups + grp) * 2 + 1] = rstd; }
+    } else {
+        fin[((int64_t)blockIdx.x * p.groups + grp) * 2] = (float)mean; fin[((int64_t)blockIdx.x * p.groups + grp) * 2 + 1] = rstd;
+    }
+}
+
+template <typename T>
+__global__ void gn_apply_kernel(const vv_groupnorm_params p, const GNGeom g) {
+    const int t = threadIdx.x, split = blockIdx.x, f = blockIdx.y;
+    if (t >= g.threads) return;
+    const int C = p.C0 + p.C1, cpg = C / p.groups;
+    const int chunk = t % g.C8, r0 = t / g.C8;
+    const float* fin = p.stats_ws + (int64_t)p.F * g.nsplit * p.groups * 2 + (int64_t)f * p.groups * 2;
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = chunk * 8 + e, grp = c / cpg;
+        const float mean = fin[2 * grp], rstd = fin[2 * grp + 1];
+        a[e] = rstd * p.gamma[c];
+        b[e] = p.beta[c] - mean * a[e];
+    }
+    const int rbeg = split * g.rows_per_split;
+    const int rend = min(rbeg + g.rows_per_split, p.HW);
+    for (int r = rbeg + r0; r < rend; r += g.krows) {
+        float v[8];
+        const int64_t pix = (int64_t)f * p.HW + r;
+        gn_load8<T>(p, pix, chunk, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = v[e] * a[e] + b[e];
+            v[e] = p.silu ? silu_f(y) : y;
+        }
+        const int64_t o = pix * C + chunk * 8;
+        if (p.out_dtype == VV_F32) { float4* d = (float4*)((float*)p.out + o); d[0] = *(float4*)&v[0]; d[1] = *(float4*)&v[4]; }
+        else *(uint4*)((unsigned short*)p.out + o) = pack8<T>(v);
+    }
+}
+
+// LayerNorm: one wave per row, row held in registers (C <= 64*4*NCH)
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int M, int C, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ pe, int rows_per_frame,
+                                                        unsigned short* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int C4 = C >> 2;
+    const float4* xr = (const float4*)(x + (int64_t)row * C);
+    float4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < C4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C4) {
+            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)C + 1e-5f);
+    const float4* per = pe ? (const float4*)(pe + (int64_t)(row / rows_per_frame) * C) : nullptr;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C4) {
+            const float4 g = ((const float4*)gamma)[c], b = ((const float4*)beta)[c];
+            float4 y;
+            y.x = (v[i].x - mean) * rstd * g.x + b.x; y.y = (v[i].y - mean) * rstd * g.y + b.y;
+            y.z = (v[i].z - mean) * rstd * g.z + b.z; y.w = (v[i].w - mean) * rstd * g.w + b.w;
+            if (per) { const float4 e = per[c]; y.x += e.x; y.y += e.y; y.z += e.z; y.w += e.w; }
+            uint2 o2 = make_uint2(pack2<T>(y.x, y.y), pack2<T>(y.z, y.w));
+            *(uint2*)(out + (int64_t)row * C + 4 * c) = o2;
+        }
+    }
+}
+
+template <typename T>
+int gn_launch(const vv_groupnorm_params& p, hipStream_t st) {
+    const int C = p.C0 + p.C1;
+    const GNGeom g = gn_geom(p.HW, C);
+    const int threads = (g.threads + 63) / 64 * 64;
+    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.pool_frames ? 1 : p.F), dim3(64), 0, st, p, g);
+    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
+    VV_CHECK_LAUNCH("vv_groupnorm");
+    return VV_OK;
+}
+
+}  // namespace
+
+extern "C" int vv_groupnorm_nsplit(int HW, int C) { return gn_geom(HW, C).nsplit; }
+
+extern "C" int vv_groupnorm(const vv_groupnorm_params* pp, int dtype, void* stream) {
+    if (!pp) VV_FAIL(VV_E_ARG, "vv_groupnorm: null params");
+    const vv_groupnorm_params& p = *pp;
+    const int C = p.C0 + p.C1;
+    if (dtype != VV_BF16 && dtype != VV_F16) VV_FAIL(VV_E_ARG, "vv_groupnorm: bad dtype");
+    if (!p.in0 || !p.out || !p.gamma || !p.beta || !p.stats_ws) VV_FAIL(VV_E_ARG, "vv_groupnorm: null pointer");
+    if (p.C0 <= 0 || p.C0 % 8 || p.C1 % 8 || (p.C1 > 0 && !p.in1)) VV_FAIL(VV_E_ARG, "vv_groupnorm: channels must be multiples of 8 (C0=%d C1=%d)", p.C0, p.C1);
+    if (p.groups <= 0 || p.groups > 64 || C % p.groups) VV_FAIL(VV_E_ARG, "vv_groupnorm: groups=%d C=%d", p.groups, C);
+    if (C / 8 > 1024) VV_FAIL(VV_E_UNSUPPORTED, "vv_groupnorm: C=%d too large", C);
+    if (p.in_dtype != VV_F32 && p.in_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_groupnorm: in_dtype mismatch");
+    if (p.out_dtype != VV_F32 && p.out_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_groupnorm: out_dtype mismatch");
+    if (p.F <= 0 || p.HW <= 0) VV_FAIL(VV_E_ARG, "vv_groupnorm: empty input");
+    return dtype == VV_BF16 ? gn_launch<BF16>(p, (hipStream_t)stream) : gn_launch<F16>(p, (hipStream_t)stream);
+}
+
+extern "C" int vv_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, const float* pe, int rows_per_frame,
+                            void* out, int dtype, void* stream) {
+    if (!x || !gamma || !beta || !out) VV_FAIL(VV_E_ARG, "vv_layernorm: null pointer");
+    if (M <= 0 || C <= 0 || C % 4) VV_FAIL(VV_E_ARG, "vv_layernorm: M=%d C=%d (C must be a multiple of 4)", M, C);
+    if (C > 2048) VV_FAIL(VV_E_UNSUPPORTED, "vv_layernorm: C=%d > 2048", C);
+    if (pe && rows_per_frame <= 0) VV_FAIL(VV_E_ARG, "vv_layernorm: rows_per_frame");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((M + 3) / 4), blk(256);
+    unsigned short* o = (unsigned short*)out;
+#define LN_LAUNCH(TT, N) hipLaunchKernelGGL((layernorm_kernel<TT, N>), grid, blk, 0, st, x, M, C, gamma, beta, pe, rows_per_frame, o)
+    if (dtype == VV_BF16) { if (C <= 512) LN_LAUNCH(BF16, 2); else if (C <= 1280) LN_LAUNCH(BF16, 5); else LN_LAUNCH(BF16, 8); }
+    else if (dtype == VV_F16) { if (C <= 512) LN_LAUNCH(F16, 2); else if (C <= 1280) LN_LAUNCH(F16, 5); else LN_LAUNCH(F16, 8); }
+    else VV_FAIL(VV_E_ARG, "vv_layernorm: bad dtype");
+#undef LN_LAUNCH
+    VV_CHECK_LAUNCH("vv_layernorm");
+    return VV_OK;
+}

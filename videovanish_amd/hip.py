@@ -1,0 +1,268 @@
+"""ctypes binding of libvvhip.so (include/vvhip.h).  PyTorch is used only for device memory and streams.
+
+There is NO fallback: if the shared library is missing or a launcher reports an error, a RuntimeError is raised
+(the GUI turns exceptions into a dialog -- reference videovanish.py:121-128,1341-1343).
+"""
+import ctypes as C
+import os
+
+import torch
+
+BF16, F16, F32, U8 = 0, 1, 2, 3
+EPI_NONE, EPI_GEGLU = 0, 1
+_DT = {"bf16": BF16, "fp16": F16}
+_TORCH_H16 = {BF16: torch.bfloat16, F16: torch.float16}
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libvvhip.so")
+_lib = None
+
+
+class ConvParams(C.Structure):
+    _fields_ = [("in0", C.c_void_p), ("in1", C.c_void_p), ("in_dtype", C.c_int32), ("C0", C.c_int32), ("C1", C.c_int32),
+                ("F", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Hv", C.c_int32), ("Wv", C.c_int32),
+                ("Hout", C.c_int32), ("Wout", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32),
+                ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("weight", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32),
+                ("Kpad", C.c_int32), ("Npad", C.c_int32), ("bias", C.c_void_p), ("rowvec", C.c_void_p),
+                ("res0", C.c_void_p), ("res1", C.c_void_p), ("res_dtype", C.c_int32), ("out", C.c_void_p),
+                ("out_dtype", C.c_int32), ("ldo", C.c_int32), ("epilogue", C.c_int32), ("out_scale", C.c_float)]
+
+
+class GroupNormParams(C.Structure):
+    _fields_ = [("in0", C.c_void_p), ("in1", C.c_void_p), ("in_dtype", C.c_int32), ("C0", C.c_int32), ("C1", C.c_int32),
+                ("F", C.c_int32), ("HW", C.c_int32), ("groups", C.c_int32), ("pool_frames", C.c_int32), ("eps", C.c_float),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("silu", C.c_int32), ("stats_ws", C.c_void_p),
+                ("out", C.c_void_p), ("out_dtype", C.c_int32)]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
+                ("q_bs", C.c_int64), ("k_bs", C.c_int64), ("v_bs", C.c_int64), ("o_bs", C.c_int64),
+                ("q_rs", C.c_int64), ("k_rs", C.c_int64), ("v_rs", C.c_int64), ("o_rs", C.c_int64),
+                ("B", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nkv", C.c_int32), ("D", C.c_int32),
+                ("scale", C.c_float)]
+
+
+EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name", "vv_conv_gemm", "vv_groupnorm_nsplit",
+           "vv_groupnorm", "vv_layernorm", "vv_attention", "vv_axpby_f32", "vv_sched_step", "vv_add_inplace",
+           "vv_mask_collapse_dilate", "vv_resize_bilinear_u8", "vv_resize_nearest_u8", "vv_feather_composite", "vv_chamfer_dt",
+           "vv_preprocess", "vv_brushnet_input", "vv_pad_channels", "vv_decode_blend", "vv_blur_compose"]
+
+
+def lib():
+    """Load libvvhip.so (once).  Raises RuntimeError when it has not been built -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(_LIB_PATH):
+            raise RuntimeError(f"videovanish_amd: HIP extension missing ({_LIB_PATH}); run videovanish_amd/csrc/build.sh "
+                               "or __graft_entry__.build() -- there is no CPU fallback")
+        L = C.CDLL(_LIB_PATH)
+        L.vv_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            if not hasattr(L, name):
+                raise RuntimeError(f"libvvhip.so does not export {name}")
+        v = L.vv_abi_version()
+        if v != 1:
+            raise RuntimeError(f"libvvhip.so ABI version {v} != 1")
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib().vv_last_error().decode()}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def dt_of(t):
+    return {torch.bfloat16: BF16, torch.float16: F16, torch.float32: F32, torch.uint8: U8}[t.dtype]
+
+
+def h16(dtype):
+    return _TORCH_H16[dtype]
+
+
+def dtype_id(name):
+    return _DT[name]
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("videovanish_amd.hip: tensors must live on the GPU (no CPU fallback)")
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("videovanish_amd.hip: tensors must be contiguous")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, Wv=None, Hout=None, Wout=None, ksize=1,
+              stride=1, pad_t=0, pad_l=0, bias=None, rowvec=None, res0=None, res1=None, out=None, out_dtype=None,
+              epilogue=EPI_NONE, out_scale=1.0, C0=None, C1=0):
+    """Launch vv_conv_gemm.  x0/x1: NHWC activations ([F,Hin,Win,C] or any shape with C last); weight: [Npad,Kpad] h16."""
+    _need_cuda(x0, x1, weight, bias, rowvec, res0, res1, out)
+    Hv = Hin if Hv is None else Hv
+    Wv = Win if Wv is None else Wv
+    Hout = Hv if Hout is None else Hout
+    Wout = Wv if Wout is None else Wout
+    C0 = x0.shape[-1] if C0 is None else C0
+    if x1 is not None:
+        C1 = x1.shape[-1]
+    M = F * Hout * Wout
+    nout = N // 2 if epilogue == EPI_GEGLU else N
+    if out is None:
+        od = h16(dtype) if out_dtype is None else out_dtype
+        out = torch.empty((M, nout), dtype=od, device=x0.device)
+    p = ConvParams(in0=x0.data_ptr(), in1=x1.data_ptr() if x1 is not None else 0, in_dtype=dt_of(x0), C0=C0, C1=C1, F=F, Hin=Hin,
+                   Win=Win, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout, ksize=ksize, stride=stride, pad_t=pad_t, pad_l=pad_l,
+                   weight=weight.data_ptr(), N=N, K=K, Kpad=weight.shape[1], Npad=weight.shape[0],
+                   bias=bias.data_ptr() if bias is not None else 0, rowvec=rowvec.data_ptr() if rowvec is not None else 0,
+                   res0=res0.data_ptr() if res0 is not None else 0, res1=res1.data_ptr() if res1 is not None else 0,
+                   res_dtype=dt_of(res0) if res0 is not None else F32, out=out.data_ptr(), out_dtype=dt_of(out), ldo=out.shape[-1],
+                   epilogue=epilogue, out_scale=out_scale)
+    _check(lib().vv_conv_gemm(C.byref(p), dtype, _stream()), "vv_conv_gemm")
+    return out
+
+
+def groupnorm(dtype, x0, gamma, beta, groups, eps, *, x1=None, F, HW, silu=False, pool_frames=False, out_dtype=None):
+    _need_cuda(x0, x1, gamma, beta)
+    C0 = x0.shape[-1]
+    C1 = x1.shape[-1] if x1 is not None else 0
+    Ctot = C0 + C1
+    nsplit = lib().vv_groupnorm_nsplit(HW, Ctot)
+    ws = torch.empty(F * (nsplit + 1) * groups * 2, dtype=torch.float32, device=x0.device)
+    out = torch.empty((F * HW, Ctot), dtype=h16(dtype) if out_dtype is None else out_dtype, device=x0.device)
+    p = GroupNormParams(in0=x0.data_ptr(), in1=x1.data_ptr() if x1 is not None else 0, in_dtype=dt_of(x0), C0=C0, C1=C1, F=F, HW=HW,
+                        groups=groups, pool_frames=int(pool_frames), eps=eps, gamma=gamma.data_ptr(), beta=beta.data_ptr(),
+                        silu=int(silu), stats_ws=ws.data_ptr(), out=out.data_ptr(), out_dtype=dt_of(out))
+    _check(lib().vv_groupnorm(C.byref(p), dtype, _stream()), "vv_groupnorm")
+    return out
+
+
+def layernorm(dtype, x, gamma, beta, pe=None, rows_per_frame=1):
+    _need_cuda(x, gamma, beta, pe)
+    M, Cc = x.shape
+    out = torch.empty((M, Cc), dtype=h16(dtype), device=x.device)
+    _check(lib().vv_layernorm(_p(x), M, Cc, _p(gamma), _p(beta), _p(pe), rows_per_frame, _p(out), dtype, _stream()), "vv_layernorm")
+    return out
+
+
+def attention(dtype, q, k, v, out, *, B, heads, Nq, Nkv, D, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, q_off=0, k_off=0, v_off=0):
+    """q/k/v/out: h16 tensors (any shape); element offsets *_off select a column block inside a fused QKV buffer."""
+    _need_cuda(q, k, v, out)
+    es = 2
+    p = AttnParams(q=q.data_ptr() + q_off * es, k=k.data_ptr() + k_off * es, v=v.data_ptr() + v_off * es, o=out.data_ptr(),
+                   q_bs=q_bs, k_bs=k_bs, v_bs=v_bs, o_bs=o_bs, q_rs=q_rs, k_rs=k_rs, v_rs=v_rs, o_rs=o_rs, B=B, heads=heads, Nq=Nq,
+                   Nkv=Nkv, D=D, scale=float(D) ** -0.5)
+    _check(lib().vv_attention(C.byref(p), dtype, _stream()), "vv_attention")
+    return out
+
+
+def axpby(x, y, ca, cb, out=None):
+    _need_cuda(x, y, out)
+    out = torch.empty_like(x) if out is None else out
+    _check(lib().vv_axpby_f32(_p(x), _p(y), C.c_float(ca), C.c_float(cb), _p(out), C.c_int64(x.numel()), _stream()), "vv_axpby_f32")
+    return out
+
+
+def sched_step(x, eps, z, sa_t, sb_t, c_x0, c_eps, c_z=0.0, out=None):
+    _need_cuda(x, eps, z, out)
+    out = torch.empty_like(x) if out is None else out
+    _check(lib().vv_sched_step(_p(x), _p(eps), _p(z), C.c_float(sa_t), C.c_float(sb_t), C.c_float(c_x0), C.c_float(c_eps), C.c_float(c_z),
+                               _p(out), C.c_int64(x.numel()), _stream()), "vv_sched_step")
+    return out
+
+
+def add_inplace(dtype, x, y):
+    _need_cuda(x, y)
+    assert x.dtype == torch.float32 and x.numel() == y.numel()
+    _check(lib().vv_add_inplace(_p(x), _p(y), dt_of(y), C.c_int64(x.numel()), dtype, _stream()), "vv_add_inplace")
+    return x
+
+
+def mask_collapse_dilate(masks, iters):
+    """masks [T,H,W,ch] u8 -> [T,H,W] u8 {0,255}  (reference diffuerase.py:27-31)."""
+    _need_cuda(masks)
+    if masks.dim() == 3:
+        masks = masks[..., None].contiguous()
+    T, H, W, ch = masks.shape
+    out = torch.empty((T, H, W), dtype=torch.uint8, device=masks.device)
+    tmp = torch.empty_like(out)
+    flags = torch.empty(T, dtype=torch.int32, device=masks.device)
+    _check(lib().vv_mask_collapse_dilate(_p(masks), T, H, W, ch, int(iters), _p(out), _p(tmp), _p(flags), _stream()), "vv_mask_collapse_dilate")
+    return out
+
+
+def resize_u8(src, Hd, Wd, mode="bilinear"):
+    _need_cuda(src)
+    s4 = src if src.dim() == 4 else src[..., None]
+    T, Hs, Ws, ch = s4.shape
+    dst = torch.empty((T, Hd, Wd, ch), dtype=torch.uint8, device=src.device)
+    fn = lib().vv_resize_bilinear_u8 if mode == "bilinear" else lib().vv_resize_nearest_u8
+    _check(fn(_p(src), T, Hs, Ws, ch, _p(dst), Hd, Wd, _stream()), "vv_resize_u8")
+    return dst if src.dim() == 4 else dst[..., 0]
+
+
+def feather_composite(inpainted, orig, mask2d, feather_px):
+    _need_cuda(inpainted, orig, mask2d)
+    T, H, W, _ = inpainted.shape
+    out = torch.empty_like(inpainted)
+    _check(lib().vv_feather_composite(_p(inpainted), _p(orig), _p(mask2d), T, H, W, C.c_float(feather_px), _p(out), _stream()), "vv_feather_composite")
+    return out
+
+
+def chamfer_dt(bin_u8, R):
+    _need_cuda(bin_u8)
+    T, H, W = bin_u8.shape
+    out = torch.empty((T, H, W), dtype=torch.float32, device=bin_u8.device)
+    _check(lib().vv_chamfer_dt(_p(bin_u8), T, H, W, R, _p(out), _stream()), "vv_chamfer_dt")
+    return out
+
+
+def preprocess(dtype, frames, mask2d, want_img=True, want_masked=True):
+    _need_cuda(frames, mask2d)
+    T, H, W, _ = frames.shape
+    img = torch.empty((T, H, W, 8), dtype=h16(dtype), device=frames.device) if want_img else None
+    msk = torch.empty((T, H, W, 8), dtype=h16(dtype), device=frames.device) if want_masked else None
+    _check(lib().vv_preprocess(_p(frames), _p(mask2d), T, H, W, _p(img), _p(msk), dtype, _stream()), "vv_preprocess")
+    return img, msk
+
+
+def brushnet_input(dtype, lat, cond, mask2d, H, W):
+    _need_cuda(lat, cond, mask2d)
+    F, h, w, _ = lat.shape
+    out = torch.empty((F, h, w, 16), dtype=h16(dtype), device=lat.device)
+    _check(lib().vv_brushnet_input(_p(lat), _p(cond), _p(mask2d), F, h, w, H, W, _p(out), dtype, _stream()), "vv_brushnet_input")
+    return out
+
+
+def pad_channels(dtype, x, cpad, scale=1.0):
+    _need_cuda(x)
+    cin = x.shape[-1]
+    rows = x.numel() // cin
+    out = torch.empty(x.shape[:-1] + (cpad,), dtype=h16(dtype), device=x.device)
+    _check(lib().vv_pad_channels(_p(x), C.c_int64(rows), cin, cpad, C.c_float(scale), _p(out), dtype, _stream()), "vv_pad_channels")
+    return out
+
+
+def decode_blend(dec, w, acc):
+    """dec [T,H,W,ld] fp32 ; w [T] fp32 ; acc [T,H,W,3] fp32 updated in place."""
+    _need_cuda(dec, w, acc)
+    T, H, W, ld = dec.shape
+    _check(lib().vv_decode_blend(_p(dec), ld, _p(w), T, C.c_int64(H * W), _p(acc), _stream()), "vv_decode_blend")
+    return acc
+
+
+def blur_compose(pix01, orig, mask2d, taps21):
+    _need_cuda(pix01, orig, mask2d)
+    T, H, W, _ = pix01.shape
+    tmp = torch.empty((T, H, W), dtype=torch.float32, device=pix01.device)
+    out = torch.empty((T, H, W, 3), dtype=torch.uint8, device=pix01.device)
+    taps = (C.c_float * 21)(*[float(x) for x in taps21])
+    _check(lib().vv_blur_compose(_p(pix01), _p(orig), _p(mask2d), T, H, W, taps, _p(tmp), _p(out), _stream()), "vv_blur_compose")
+    return out
