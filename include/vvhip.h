@@ -128,6 +128,8 @@ int vv_axpby_f32(const float* x, const float* y, float ca, float cb, float* out,
 /* DDIM / TCD update: x0 = (x - sb_t*eps)/sa_t ; out = c_x0*x0 + c_eps*eps + c_z*z (z may be NULL) */
 int vv_sched_step(const float* x, const float* eps, const float* z, float sa_t, float sb_t, float c_x0, float c_eps,
                   float c_z, float* out, int64_t n, void* stream);
+/* out = x * sigmoid(x) (time-embedding MLP activation), fp32 */
+int vv_silu_f32(const float* x, float* out, int64_t n, void* stream);
 /* trunk += addend (fp32 += fp32 or h16) */
 int vv_add_inplace(float* x, const void* y, int y_dtype, int64_t n, int dtype, void* stream);
 

@@ -1,0 +1,162 @@
+"""GPU parity of the assembled model (HIP kernels through the C ABI) against the fp32 CPU oracle, same seeded
+inputs and weights.  Tolerances are stated per test: the MFMA operands are bf16/fp16 (8 / 11 significant bits) while
+the oracle is fp32 end to end, so these are genuine reduced-precision bounds, not accumulation-order noise."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from videovanish_amd.config import SMALL_UNET, SMALL_VAE, TINY_UNET, TINY_VAE, RunConfig, UNetConfig, VAEConfig
+
+REPORT = os.environ.get("VV_PARITY_REPORT")
+
+
+def _log(name, **kw):
+    msg = name + ": " + ", ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in kw.items())
+    print(msg)
+    if REPORT:
+        with open(REPORT, "a") as f:
+            f.write(msg + "\n")
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / b.abs().max()).item(), ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+CASES = [("tiny", TINY_UNET, TINY_VAE, 5, 6, 7), ("small", SMALL_UNET, SMALL_VAE, 4, 9, 6)]
+
+
+@pytest.mark.parametrize("dname,tol_max,tol_rms", [("bf16", 0.08, 0.02), ("fp16", 0.012, 0.003)])
+@pytest.mark.parametrize("cname,ucfg,vcfg,Fr,h,w", CASES)
+def test_denoiser_one_step(gpu, dname, tol_max, tol_rms, cname, ucfg, vcfg, Fr, h, w):
+    """eps = UNet(lat | BrushNet(...)) for one clip; relative max-abs / rms error vs the fp32 oracle."""
+    from oracle import model_ref as M
+    from videovanish_amd.nn import Ctx
+    from videovanish_amd.unet import Denoiser
+    P = M.Params(0)
+    g = torch.Generator().manual_seed(11)
+    lat = torch.randn(Fr, 4, h, w, generator=g)
+    cond = torch.randn(Fr, 4, h, w, generator=g)
+    f = 8
+    mask = (torch.rand(Fr, h * f, w * f, generator=g) > 0.6).to(torch.uint8) * 255
+    m_lat = torch.nn.functional.interpolate((mask > 0).float()[:, None], size=(h, w), mode="nearest")
+    text = M.text_states(P, ucfg)
+    t = 621
+    with torch.no_grad():
+        br = M.brushnet_forward(P, torch.cat([lat, cond, m_lat], 1), t, text, ucfg)
+        ref = M.unet_forward(P, lat, t, text, ucfg, br)
+    ctx = Ctx("cuda:0", dname, 0)
+    den = Denoiser(ctx, ucfg, ctx.src.normal("text_states", (1, ucfg.text_len, ucfg.cross_dim)))
+    eps = den(_nhwc(lat).to(gpu), _nhwc(cond).to(gpu), mask.to(gpu), t, Fr, h, w, h * f, w * f)
+    got = eps.cpu().permute(0, 3, 1, 2)
+    emax, erms = _rel(got, ref)
+    _log(f"denoiser[{cname},{dname}]", rel_max=emax, rel_rms=erms, ref_absmax=ref.abs().max().item())
+    assert torch.isfinite(got).all()
+    assert emax <= tol_max and erms <= tol_rms
+
+
+@pytest.mark.parametrize("dname,tol", [("bf16", 0.05), ("fp16", 0.008)])
+@pytest.mark.parametrize("vname,vcfg,Fr,H,W", [("tiny", TINY_VAE, 3, 24, 40), ("small", SMALL_VAE, 2, 32, 48)])
+def test_vae_roundtrip(gpu, dname, tol, vname, vcfg, Fr, H, W):
+    from oracle import model_ref as M
+    from videovanish_amd import hip
+    from videovanish_amd.nn import Ctx
+    from videovanish_amd.vae import VAE
+    P = M.Params(0)
+    g = torch.Generator().manual_seed(12)
+    fr = torch.randint(0, 256, (Fr, H, W, 3), generator=g, dtype=torch.uint8)
+    img = fr.float().permute(0, 3, 1, 2) / 127.5 - 1.0
+    with torch.no_grad():
+        zr = M.vae_encode(P, img, vcfg)
+        dr = M.vae_decode(P, zr, vcfg)
+    ctx = Ctx("cuda:0", dname, 0)
+    vae = VAE(ctx, vcfg)
+    img8, _ = hip.preprocess(ctx.dt, fr.to(gpu), None, want_masked=False)
+    z = vae.encode(img8.view(Fr * H * W, 8), Fr, H, W)
+    emax, erms = _rel(z.cpu().permute(0, 3, 1, 2), zr)
+    _log(f"vae_encode[{vname},{dname}]", rel_max=emax, rel_rms=erms)
+    assert emax <= tol
+    d = vae.decode(_nhwc(zr).to(gpu), Fr, zr.shape[2], zr.shape[3])      # decode the ORACLE latents: isolates the decoder
+    dmax, drms = _rel(d.cpu().permute(0, 3, 1, 2), dr)
+    _log(f"vae_decode[{vname},{dname}]", rel_max=dmax, rel_rms=drms)
+    assert dmax <= tol
+
+
+def _clip(T, H, W, seed=1234):
+    rng = np.random.default_rng(seed)
+    frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(T)]
+    masks = []
+    for t in range(T):
+        m = np.zeros((H, W, 3), np.uint8)
+        m[H // 4: H // 2, W // 4 + 2 * t: W // 2 + 2 * t] = 255
+        masks.append(m)
+    prior = []
+    for f, m in zip(frames, masks):
+        p = f.copy()
+        p[m[..., 0] > 0] = f.reshape(-1, 3).mean(0).astype(np.uint8)
+        prior.append(p)
+    return frames, masks, prior
+
+
+@pytest.mark.parametrize("dname,tol_pix", [("bf16", 0.06), ("fp16", 0.01)])
+def test_chunk_pipeline_vs_oracle(gpu, dname, tol_pix):
+    """Whole DiffuEraser.forward (encode, 3 DDIM steps, decode, 2 overlapping chunks, blend) on the tiny config:
+    float pixels in [0,1] before uint8 quantisation; per-pixel max-abs tolerance stated above."""
+    from oracle import pipeline_ref as R
+    from videovanish_amd.pipeline import DiffuEraserHIP
+    T, H, W = 6, 32, 40
+    frames, masks, prior = _clip(T, H, W)
+    m2d = [np.any(m > 0, axis=2).astype(np.uint8) * 255 for m in masks]
+    kw = dict(steps=3, chunk=4, overlap=2, seed=7)
+    ref = R.diffueraser_forward(frames, m2d, prior, ucfg=TINY_UNET, vcfg=TINY_VAE, return_float=True, **kw)
+    run = RunConfig(steps=3, chunk=4, overlap=2, seed=7, dtype=dname, unet=TINY_UNET, vae=TINY_VAE)
+    model = DiffuEraserHIP(run)
+    got, (lo, hi) = model.forward(frames, m2d, prior, return_float=True)
+    assert (lo, hi) == (0, T)
+    err = np.abs(got - ref)
+    _log(f"pipeline_float[tiny,{dname}]", max_abs=float(err.max()), mean_abs=float(err.mean()))
+    assert err.max() <= tol_pix
+    out = model.forward(frames, m2d, prior)
+    refu = R.diffueraser_forward(frames, m2d, prior, ucfg=TINY_UNET, vcfg=TINY_VAE, **kw)
+    du = np.abs(np.stack(out).astype(int) - np.stack(refu).astype(int))
+    _log(f"pipeline_u8[tiny,{dname}]", max_abs_u8=int(du.max()), frac_differ=float((du > 0).mean()))
+    assert du.max() <= int(round(tol_pix * 255)) + 1
+    unm = np.stack(m2d) == 0
+    far = np.stack([R.I.distance_transform_l2_5(np.bitwise_not(m)) for m in m2d]) > 12
+    assert (np.stack(out)[far & unm] == np.stack(frames)[far & unm]).all()      # far from the mask: original pixels
+
+
+def test_drop_in_run_infill_on_frames(gpu):
+    """The drop-in module: same call as the GUI makes (reference videovanish.py:1518), checked against the oracle's
+    restatement of reference diffuerase.py:20-114 incl. the prog sequence and the early-return compat mode."""
+    import diffuerase
+    from oracle import pipeline_ref as R
+    T, H, W = 5, 40, 48
+    frames, masks, prior = _clip(T, H, W, seed=99)
+    run = RunConfig(steps=2, chunk=4, overlap=2, seed=3, dtype="fp16", unet=TINY_UNET, vae=TINY_VAE)
+    diffuerase.configure(run)
+    progs = []
+    out = diffuerase.run_infill_on_frames(frames, masks, mask_dilation_iter=3, propainer_frames=prior, max_img_size=32,
+                                          keep_unmasked_original=True, prog=lambda p, s: progs.append((p, s)), num_inference_steps=2,
+                                          scheduler="ddim")
+    ref = R.run_infill_on_frames(frames, masks, 3, prior, max_img_size=32, steps=2, chunk=4, overlap=2, seed=3, ucfg=TINY_UNET,
+                                 vcfg=TINY_VAE)
+    assert len(out) == T and all(o.shape == (H, W, 3) and o.dtype == np.uint8 for o in out)
+    du = np.abs(np.stack(out).astype(int) - np.stack(ref).astype(int))
+    _log("drop_in_u8[tiny,fp16]", max_abs_u8=int(du.max()), frac_differ=float((du > 0).mean()))
+    assert du.max() <= 4
+    assert [p for p, _ in progs if p in (5, 10, 50, 90)][:4] == [5, 10, 50, 90] and all(isinstance(s, str) and s for _, s in progs)
+    dil = R.I.collapse_and_dilate(masks, 3)
+    far = np.stack([R.I.distance_transform_l2_5(np.bitwise_not(m)) for m in dil]) >= 3
+    assert (np.stack(out)[far] == np.stack(frames)[far]).all()                   # keep_unmasked_original
+    out2 = diffuerase.run_infill_on_frames(frames, masks, mask_dilation_iter=3, propainer_frames=prior, max_img_size=32,
+                                           num_inference_steps=2, scheduler="ddim", compat_reference_early_return=True)
+    assert out2[0].shape == (H, W, 3) and out2[1].shape == (32, 32 * W // H // 8 * 8, 3) or out2[1].shape[0] <= 32   # frames 1.. at model size
+    diffuerase.configure(None)

@@ -38,7 +38,7 @@ TINY_UNET = UNetConfig(block_out=(64, 128), attn_levels=(True, False), layers_pe
                        text_len=7, groups=8)
 SMALL_UNET = UNetConfig(block_out=(320, 640), attn_levels=(True, False), layers_per_block=1, heads=8, cross_dim=768)
 TINY_VAE = VAEConfig(block_out=(32, 64), layers_per_block=1, groups=8)
-SMALL_VAE = VAEConfig(block_out=(128, 256), layers_per_block=1)
+SMALL_VAE = VAEConfig(block_out=(128, 512), layers_per_block=1)     # mid attention at the real head dim 512
 
 
 @dataclass(frozen=True)

@@ -29,6 +29,10 @@ __global__ void sched_step_kernel(const float* x, const float* eps, const float*
     }
 }
 
+__global__ void silu_kernel(const float* x, float* out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) out[i] = silu_f(x[i]);
+}
+
 template <typename T>
 __global__ void add_inplace_kernel(float* x, const void* y, int y_f32, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB)
@@ -107,6 +111,14 @@ extern "C" int vv_sched_step(const float* x, const float* eps, const float* z, f
     if (n == 0) return VV_OK;
     hipLaunchKernelGGL(sched_step_kernel, grid_for(n), dim3(EB), 0, (hipStream_t)stream, x, eps, z, sa_t, sb_t, c_x0, c_eps, c_z, out, n);
     VV_CHECK_LAUNCH("vv_sched_step");
+    return VV_OK;
+}
+
+extern "C" int vv_silu_f32(const float* x, float* out, int64_t n, void* stream) {
+    if (!x || !out || n < 0) VV_FAIL(VV_E_ARG, "vv_silu_f32: bad args");
+    if (n == 0) return VV_OK;
+    hipLaunchKernelGGL(silu_kernel, grid_for(n), dim3(EB), 0, (hipStream_t)stream, x, out, n);
+    VV_CHECK_LAUNCH("vv_silu_f32");
     return VV_OK;
 }
 

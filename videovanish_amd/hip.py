@@ -43,7 +43,7 @@ class AttnParams(C.Structure):
 
 
 EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name", "vv_conv_gemm", "vv_groupnorm_nsplit",
-           "vv_groupnorm", "vv_layernorm", "vv_attention", "vv_axpby_f32", "vv_sched_step", "vv_add_inplace",
+           "vv_groupnorm", "vv_layernorm", "vv_attention", "vv_axpby_f32", "vv_silu_f32", "vv_sched_step", "vv_add_inplace",
            "vv_mask_collapse_dilate", "vv_resize_bilinear_u8", "vv_resize_nearest_u8", "vv_feather_composite", "vv_chamfer_dt",
            "vv_preprocess", "vv_brushnet_input", "vv_pad_channels", "vv_decode_blend", "vv_blur_compose"]
 
@@ -175,6 +175,13 @@ def sched_step(x, eps, z, sa_t, sb_t, c_x0, c_eps, c_z=0.0, out=None):
     out = torch.empty_like(x) if out is None else out
     _check(lib().vv_sched_step(_p(x), _p(eps), _p(z), C.c_float(sa_t), C.c_float(sb_t), C.c_float(c_x0), C.c_float(c_eps), C.c_float(c_z),
                                _p(out), C.c_int64(x.numel()), _stream()), "vv_sched_step")
+    return out
+
+
+def silu(x):
+    _need_cuda(x)
+    out = torch.empty_like(x)
+    _check(lib().vv_silu_f32(_p(x), _p(out), C.c_int64(x.numel()), _stream()), "vv_silu_f32")
     return out
 
 

@@ -1,0 +1,243 @@
+"""HIP-backed layers of the DiffuEraser stack.  Every arithmetic op is a launch of a libvvhip kernel through the
+C ABI (videovanish_amd.hip); torch only owns the device buffers.
+
+Activation convention: a 2-D tensor [M, C] = frames-major NHWC with M = F*H*W.  The residual trunk is fp32; tensors
+that feed an MFMA contraction are h16 (bf16 / fp16, chosen by Ctx.dtype).
+"""
+import torch
+
+from . import hip, packing
+from .weights import SyntheticWeights
+
+
+class Ctx:
+    """Per-process model context: device, MFMA operand dtype, weight source."""
+
+    def __init__(self, device="cuda:0", dtype="bf16", weight_seed=0, weights=None):
+        hip.lib()  # fail loudly before anything else if the extension is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("videovanish_amd: no HIP device visible (there is no CPU fallback)")
+        self.device = torch.device(device)
+        self.dt = hip.dtype_id(dtype)
+        self.h16 = hip.h16(self.dt)
+        self.src = weights if weights is not None else SyntheticWeights(weight_seed)
+
+    def dev(self, t, dtype=None):
+        return t.to(dtype if dtype is not None else t.dtype).contiguous().to(self.device)
+
+
+class Conv:
+    """conv2d / linear as implicit GEMM.  `in_pad`: activations carry zero-padded channels (conv_in layers)."""
+
+    def __init__(self, ctx, name, cin, cout, k=3, gain=1.0, cin_pad=None, bias=True, weight=None, bias_t=None, rows=None, geglu=False):
+        self.ctx, self.k, self.cout = ctx, k, cout
+        if weight is None:
+            weight, b = ctx.src.conv(name, cin, cout, k, gain)
+            bias_t = b if bias else None
+        if rows is not None:                      # keep only the first `rows` output channels (VAE quant_conv mean half)
+            weight, bias_t, self.cout = weight[:rows], (bias_t[:rows] if bias_t is not None else None), rows
+        if geglu:
+            w2, bias_t = packing.geglu_interleave(weight.reshape(weight.shape[0], -1), bias_t)
+            wp, self.K = packing.pack_matrix(w2, ctx.h16, geglu=True), w2.shape[1]
+        else:
+            wp, self.K = packing.pack_conv(weight, ctx.h16, cin_pad)
+        self.geglu = geglu
+        self.w = ctx.dev(wp)
+        self.b = ctx.dev(bias_t.float()) if bias_t is not None else None
+
+    def __call__(self, x0, F, H, W, x1=None, stride=1, Hv=None, Wv=None, Hout=None, Wout=None, pad=None, bias=True, rowvec=None,
+                 res0=None, res1=None, out_dtype=torch.float32, out=None, scale=1.0, bias_override=None):
+        k = self.k
+        pad = (k // 2) if pad is None else pad
+        Hv = H if Hv is None else Hv
+        Wv = W if Wv is None else Wv
+        if Hout is None:
+            Hout = (Hv + 2 * pad - k) // stride + 1
+            Wout = (Wv + 2 * pad - k) // stride + 1
+        b = bias_override if bias_override is not None else (self.b if bias else None)
+        return hip.conv_gemm(self.ctx.dt, x0, self.w, self.cout, self.K, x1=x1, F=F, Hin=H, Win=W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout,
+                             ksize=k, stride=stride, pad_t=pad, pad_l=pad, bias=b, rowvec=rowvec, res0=res0, res1=res1, out=out,
+                             out_dtype=out_dtype, epilogue=hip.EPI_GEGLU if self.geglu else hip.EPI_NONE, out_scale=scale), Hout, Wout
+
+
+class Linear:
+    """y = x W^T + b on a [M, K] matrix (fp32 or h16 input)."""
+
+    def __init__(self, ctx, name=None, cin=None, cout=None, bias=True, gain=1.0, weight=None, bias_t=None, geglu=False):
+        self.ctx = ctx
+        if weight is None:
+            weight, bias_t = ctx.src.linear(name, cin, cout, gain, bias)
+        self.cout = weight.shape[0]
+        self.geglu = geglu
+        if geglu:
+            weight, bias_t = packing.geglu_interleave(weight, bias_t)
+        self.K = weight.shape[1]
+        self.w = ctx.dev(packing.pack_matrix(weight, ctx.h16, geglu=geglu))
+        self.b = ctx.dev(bias_t.float()) if bias_t is not None else None
+
+    def __call__(self, x, res0=None, res1=None, out_dtype=torch.float32, rows_per_frame=None, out=None):
+        M = x.shape[0]
+        return hip.conv_gemm(self.ctx.dt, x, self.w, self.cout, self.K, F=1, Hin=M, Win=1, bias=self.b, res0=res0, res1=res1,
+                             out_dtype=out_dtype, out=out, epilogue=hip.EPI_GEGLU if self.geglu else hip.EPI_NONE)
+
+
+class GroupNorm:
+    def __init__(self, ctx, name, C, groups, eps):
+        self.ctx, self.groups, self.eps = ctx, groups, eps
+        g, b = ctx.src.norm(name, C)
+        self.g, self.b = ctx.dev(g), ctx.dev(b)
+
+    def __call__(self, x0, F, HW, x1=None, silu=False, pool_frames=False):
+        return hip.groupnorm(self.ctx.dt, x0, self.g, self.b, self.groups, self.eps, x1=x1, F=F, HW=HW, silu=silu, pool_frames=pool_frames)
+
+
+class LayerNorm:
+    def __init__(self, ctx, name, C):
+        self.ctx = ctx
+        g, b = ctx.src.norm(name, C)
+        self.g, self.b = ctx.dev(g), ctx.dev(b)
+
+    def __call__(self, x, pe=None, rows_per_frame=1):
+        return hip.layernorm(self.ctx.dt, x, self.g, self.b, pe=pe, rows_per_frame=rows_per_frame)
+
+
+class ResBlock:
+    """ResnetBlock2D: GN+SiLU -> conv3 (+temb) -> GN+SiLU -> conv3 -> + shortcut(x)."""
+
+    def __init__(self, ctx, name, cin, cout, groups, eps, temb_dim=None):
+        self.ctx, self.cin, self.cout = ctx, cin, cout
+        self.norm1 = GroupNorm(ctx, name + ".norm1", cin, groups, eps)
+        self.conv1 = Conv(ctx, name + ".conv1", cin, cout)
+        self.temb = Linear(ctx, name + ".time_emb_proj", temb_dim, cout) if temb_dim else None
+        self.norm2 = GroupNorm(ctx, name + ".norm2", cout, groups, eps)
+        self.conv2 = Conv(ctx, name + ".conv2", cout, cout)
+        self.short = Conv(ctx, name + ".conv_shortcut", cin, cout, k=1) if cin != cout else None
+
+    def __call__(self, x0, F, H, W, x1=None, silu_temb=None, res1=None):
+        HW = H * W
+        h = self.norm1(x0, F, HW, x1=x1, silu=True)
+        b1 = None
+        if self.temb is not None:
+            # conv1 bias + time_emb_proj(silu(temb)) is the same vector for every frame -> fold into the bias
+            b1 = self.temb(silu_temb, res0=self.conv1.b.view(1, -1)).view(-1)
+        h, _, _ = self.conv1(h, F, H, W, bias_override=b1)
+        h = self.norm2(h, F, HW, silu=True)
+        if self.short is not None:
+            xs, _, _ = self.short(x0, F, H, W, x1=x1)
+        else:
+            xs = x0
+        out, _, _ = self.conv2(h, F, H, W, res0=xs, res1=res1)
+        return out
+
+
+class SelfAttention:
+    """attn with fused QKV projection (no bias) + output projection (bias) + residual."""
+
+    def __init__(self, ctx, name, C, heads, qkv_bias=False):
+        self.ctx, self.C, self.heads = ctx, C, heads
+        ws, bs = [], []
+        for n in ("to_q", "to_k", "to_v"):
+            w, b = ctx.src.linear(f"{name}.{n}", C, C, 1.0, qkv_bias)
+            ws.append(w); bs.append(b)
+        self.qkv = Linear(ctx, weight=torch.cat(ws, 0), bias_t=torch.cat(bs, 0) if qkv_bias else None)
+        self.out = Linear(ctx, name + ".to_out.0", C, C)
+
+    def spatial(self, n, res, B, N):
+        C, dt = self.C, self.ctx.dt
+        qkv = self.qkv(n, out_dtype=self.ctx.h16)
+        o = torch.empty((B * N, C), dtype=self.ctx.h16, device=n.device)
+        hip.attention(dt, qkv, qkv, qkv, o, B=B, heads=self.heads, Nq=N, Nkv=N, D=C // self.heads, q_bs=N * 3 * C, k_bs=N * 3 * C,
+                      v_bs=N * 3 * C, o_bs=N * C, q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C, k_off=C, v_off=2 * C)
+        return self.out(o, res0=res)
+
+    def temporal(self, n, res, Fr, HW, res1=None):
+        """sequence = frames; rows of the [F*HW, 3C] QKV matrix gathered with stride HW*3C inside the kernel."""
+        C, dt = self.C, self.ctx.dt
+        qkv = self.qkv(n, out_dtype=self.ctx.h16)
+        o = torch.empty((Fr * HW, C), dtype=self.ctx.h16, device=n.device)
+        hip.attention(dt, qkv, qkv, qkv, o, B=HW, heads=self.heads, Nq=Fr, Nkv=Fr, D=C // self.heads, q_bs=3 * C, k_bs=3 * C, v_bs=3 * C,
+                      o_bs=C, q_rs=HW * 3 * C, k_rs=HW * 3 * C, v_rs=HW * 3 * C, o_rs=HW * C, k_off=C, v_off=2 * C)
+        return self.out(o, res0=res, res1=res1)
+
+
+class CrossAttention:
+    """attn2: queries from the image tokens, K/V from the constant text states (projected ONCE at build time)."""
+
+    def __init__(self, ctx, name, C, heads, text_h16):
+        self.ctx, self.C, self.heads = ctx, C, heads
+        cross = text_h16.shape[-1]
+        self.q = Linear(ctx, name + ".to_q", C, C, bias=False)
+        wk, _ = ctx.src.linear(name + ".to_k", cross, C, 1.0, False)
+        wv, _ = ctx.src.linear(name + ".to_v", cross, C, 1.0, False)
+        kvp = Linear(ctx, weight=torch.cat([wk, wv], 0), bias_t=None)
+        self.kv = kvp(text_h16, out_dtype=ctx.h16)            # [77, 2C], hoisted out of the denoise loop
+        self.nkv = text_h16.shape[0]
+        self.out = Linear(ctx, name + ".to_out.0", C, C)
+
+    def __call__(self, n, res, B, N):
+        C = self.C
+        q = self.q(n, out_dtype=self.ctx.h16)
+        o = torch.empty((B * N, C), dtype=self.ctx.h16, device=n.device)
+        hip.attention(self.ctx.dt, q, self.kv, self.kv, o, B=B, heads=self.heads, Nq=N, Nkv=self.nkv, D=C // self.heads, q_bs=N * C, k_bs=0,
+                      v_bs=0, o_bs=N * C, q_rs=C, k_rs=2 * C, v_rs=2 * C, o_rs=C, v_off=C)
+        return self.out(o, res0=res)
+
+
+class FeedForward:
+    def __init__(self, ctx, name, C):
+        self.ctx = ctx
+        self.proj = Linear(ctx, name + ".net.0.proj", C, 8 * C, geglu=True)
+        self.out = Linear(ctx, name + ".net.2", 4 * C, C)
+
+    def __call__(self, n, res):
+        return self.out(self.proj(n, out_dtype=self.ctx.h16), res0=res)
+
+
+class SpatialTransformer:
+    def __init__(self, ctx, name, C, cfg, text_h16):
+        self.ctx = ctx
+        self.norm = GroupNorm(ctx, name + ".norm", C, cfg.groups, 1e-6)
+        self.proj_in = Conv(ctx, name + ".proj_in", C, C, k=1)
+        b = name + ".transformer_blocks.0"
+        self.n1, self.n2, self.n3 = (LayerNorm(ctx, f"{b}.norm{i}", C) for i in (1, 2, 3))
+        self.attn1 = SelfAttention(ctx, b + ".attn1", C, cfg.heads)
+        self.attn2 = CrossAttention(ctx, b + ".attn2", C, cfg.heads, text_h16)
+        self.ff = FeedForward(ctx, b + ".ff", C)
+        self.proj_out = Conv(ctx, name + ".proj_out", C, C, k=1)
+
+    def __call__(self, x, F, H, W):
+        HW = H * W
+        h = self.norm(x, F, HW)
+        t, _, _ = self.proj_in(h, F, H, W)
+        t = self.attn1.spatial(self.n1(t), t, F, HW)
+        t = self.attn2(self.n2(t), t, F, HW)
+        t = self.ff(self.n3(t), t)
+        out, _, _ = self.proj_out(t, F, H, W, res0=x)
+        return out
+
+
+class MotionModule:
+    """AnimateDiff temporal transformer."""
+
+    def __init__(self, ctx, name, C, cfg, pe_table):
+        self.ctx = ctx
+        self.norm = GroupNorm(ctx, name + ".norm", C, cfg.groups, 1e-6)
+        self.proj_in = Linear(ctx, name + ".proj_in", C, C)
+        b = name + ".transformer_blocks.0"
+        self.n1, self.n2, self.n3 = (LayerNorm(ctx, f"{b}.norm{i}", C) for i in (1, 2, 3))
+        self.attn1 = SelfAttention(ctx, b + ".attn1", C, cfg.heads)
+        self.attn2 = SelfAttention(ctx, b + ".attn2", C, cfg.heads)
+        self.ff = FeedForward(ctx, b + ".ff", C)
+        self.proj_out = Linear(ctx, name + ".proj_out", C, C)
+        self.pe = pe_table          # [max_seq, C] fp32 on device
+
+    def __call__(self, x, F, H, W, res1=None):
+        HW = H * W
+        if F > self.pe.shape[0]:
+            raise RuntimeError(f"motion module: clip of {F} frames exceeds the positional table ({self.pe.shape[0]})")
+        h = self.norm(x, F, HW, pool_frames=True)
+        t = self.proj_in(h)
+        t = self.attn1.temporal(self.n1(t, pe=self.pe, rows_per_frame=HW), t, F, HW)
+        t = self.attn2.temporal(self.n2(t, pe=self.pe, rows_per_frame=HW), t, F, HW)
+        t = self.ff(self.n3(t), t)
+        return self.proj_out(t, res0=x, res1=res1)

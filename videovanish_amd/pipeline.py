@@ -1,0 +1,264 @@
+"""DiffuEraser.forward on MI355X: VAE encode -> per-chunk BrushNet + motion-UNet denoise loop -> VAE decode ->
+overlap blend -> soft-mask compose.  Mirrors the third-party call the reference makes at diffuerase.py:62-67
+(argument meaning per SURVEY.md 3.3); chunking/blend semantics are SURVEY.md 8e.
+
+Multi-GPU: one process per GPU (torch.distributed, backend "nccl" = RCCL).  Chunks are assigned to ranks in
+contiguous blocks; every chunk is independent until blend time, when a rank sends the decoded frames of its chunks
+that overlap frames owned by the previous rank (point-to-point over xGMI).  The owner blends in canonical chunk
+order, so the result is bit-identical for every world size.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import hip, imageops
+from .config import RunConfig
+from .nn import Ctx
+from .unet import Denoiser
+from .vae import VAE
+
+
+# ---- plan (pure host logic; covered by CPU tests) ---------------------------------------------------------------
+def model_size(H0, W0, max_img_size):
+    Hs, Ws = H0, W0
+    if max(H0, W0) > max_img_size:
+        s = max_img_size / float(max(H0, W0))
+        Hs, Ws = int(round(H0 * s)), int(round(W0 * s))
+    return max(8, Hs - Hs % 8), max(8, Ws - Ws % 8)
+
+
+def chunk_plan(T, chunk, overlap):
+    if T <= chunk:
+        return [(0, T)]
+    starts, i = [], 0
+    while True:
+        s = min((chunk - overlap) * i, T - chunk)
+        starts.append(s)
+        if s + chunk >= T:
+            break
+        i += 1
+    return [(s, s + chunk) for s in starts]
+
+
+def blend_weights(plan):
+    out, covered = [], 0
+    for (s, e) in plan:
+        w = np.ones(e - s, np.float32)
+        O = max(0, covered - s)
+        for k in range(O):
+            w[k] = np.float32(k + 1) / np.float32(O + 1)
+        out.append(w)
+        covered = max(covered, e)
+    return out
+
+
+def shard_chunks(n_chunks, world):
+    """Contiguous blocks of chunks per rank, sizes differ by at most one (larger blocks first)."""
+    base, rem = divmod(n_chunks, world)
+    out, c = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append(list(range(c, c + n)))
+        c += n
+    return out
+
+
+def frame_owner(plan, shards):
+    """Owner rank of every frame = rank of the FIRST chunk that covers it."""
+    T = max(e for _, e in plan)
+    chunk_rank = {}
+    for r, cs in enumerate(shards):
+        for c in cs:
+            chunk_rank[c] = r
+    owner = np.full(T, -1, np.int64)
+    for ci, (s, e) in enumerate(plan):
+        sel = owner[s:e] < 0
+        owner[s:e][sel] = chunk_rank[ci]
+    return owner, chunk_rank
+
+
+def ddim_timesteps(steps):
+    ratio = 1000 // steps
+    return [int(round(i * ratio)) + 1 for i in range(steps)][::-1]
+
+
+def tcd_timesteps(steps):
+    return [int(round(1000 - i * 1000 / steps)) - 1 for i in range(steps)]
+
+
+def alphas_cumprod():
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float64) ** 2
+    return torch.cumprod(1.0 - betas, 0)
+
+
+def chunk_noise(seed, index, shape):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(int(seed) * 1000003 + int(index))
+    return torch.randn(shape, generator=g, dtype=torch.float32)
+
+
+# ---- the model ---------------------------------------------------------------------------------------------------
+class DiffuEraserHIP:
+    def __init__(self, run: RunConfig = None, device="cuda:0"):
+        self.run = run or RunConfig()
+        self.ctx = Ctx(device, self.run.dtype, self.run.weight_seed)
+        text = self.ctx.src.normal("text_states", (1, self.run.unet.text_len, self.run.unet.cross_dim))
+        self.denoiser = Denoiser(self.ctx, self.run.unet, text)
+        self.vae = VAE(self.ctx, self.run.vae)
+        self.ac = alphas_cumprod()
+        self.taps = imageops.gaussian_taps_21()
+        self.vae_batch = 4
+
+    # -- one clip -------------------------------------------------------------------------------------------------
+    def encode(self, img8, F, H, W):
+        f = self.vae.factor
+        outs = []
+        for a in range(0, F, self.vae_batch):
+            b = min(F, a + self.vae_batch)
+            outs.append(self.vae.encode(img8[a:b].reshape((b - a) * H * W, 8), b - a, H, W))
+        return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+
+    def decode(self, lat, F, h, w):
+        outs = []
+        for a in range(0, F, self.vae_batch):
+            b = min(F, a + self.vae_batch)
+            outs.append(self.vae.decode(lat[a:b].contiguous(), b - a, h, w))
+        return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+
+    def denoise_chunk(self, frames_u8, prior_u8, mask_u8, noise, steps=None, scheduler="ddim", tcd_noise=None, trace=None, progress=None):
+        """frames/prior: u8 [F,H,W,3] device; mask: u8 [F,H,W]; noise: fp32 [F,h,w,4] device.  Returns decoded fp32
+        [F,H,W,3] in [-1,1] (clamp/scale happens in the blend kernel)."""
+        ctx = self.ctx
+        steps = steps or self.run.steps
+        F, H, W, _ = frames_u8.shape
+        f = self.vae.factor
+        h, w = H // f, W // f
+        _, masked8 = hip.preprocess(ctx.dt, frames_u8, mask_u8, want_img=False)
+        prior8, _ = hip.preprocess(ctx.dt, prior_u8, None, want_masked=False)
+        prior_lat = self.encode(prior8, F, H, W)
+        cond_lat = self.encode(masked8, F, H, W)
+        del prior8, masked8
+        if scheduler == "ddim":
+            ts = ddim_timesteps(steps)
+        elif scheduler == "tcd":
+            ts = tcd_timesteps(steps)
+        else:
+            raise ValueError(f"unknown scheduler {scheduler}")
+        a0 = float(self.ac[ts[0]])
+        lat = hip.axpby(prior_lat, noise, a0 ** 0.5, (1 - a0) ** 0.5)
+        if trace is not None:
+            trace.update(prior_lat=prior_lat.clone(), cond_lat=cond_lat.clone(), lat0=lat.clone())
+        for i, t in enumerate(ts):
+            eps = self.denoiser(lat, cond_lat, mask_u8, t, F, h, w, H, W)
+            if trace is not None and i == 0:
+                trace.update(eps0=eps.clone())
+            a_t = float(self.ac[t])
+            if scheduler == "ddim":
+                prev = t - 1000 // steps
+                a_p = float(self.ac[prev]) if prev >= 0 else float(self.ac[0])
+                lat = hip.sched_step(lat, eps, None, a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5)
+            else:
+                last = i + 1 >= len(ts)
+                tp = 0 if last else ts[i + 1]
+                s = int(math.floor((1 - 0.3) * tp))
+                a_s, a_p = float(self.ac[s]), float(self.ac[tp])
+                if last:
+                    lat = hip.sched_step(lat, eps, None, a_t ** 0.5, (1 - a_t) ** 0.5, a_s ** 0.5, (1 - a_s) ** 0.5)
+                else:
+                    r = a_p / a_s
+                    z = tcd_noise[i] if tcd_noise is not None else torch.zeros_like(lat)
+                    lat = hip.sched_step(lat, eps, z, a_t ** 0.5, (1 - a_t) ** 0.5, (r ** 0.5) * a_s ** 0.5, (r ** 0.5) * (1 - a_s) ** 0.5,
+                                         (1 - r) ** 0.5)
+            if progress is not None:
+                progress(i + 1, len(ts))
+        if trace is not None:
+            trace.update(lat_final=lat.clone())
+        return self.decode(lat, F, h, w)
+
+    # -- whole video ----------------------------------------------------------------------------------------------
+    def forward(self, frames, masks2d, priori, max_img_size=960, steps=None, scheduler="ddim", progress=None, return_float=False,
+                dist=None):
+        """frames / priori: list of (H0,W0,3) uint8; masks2d: list of (H0,W0) uint8 (non-zero = masked).
+        Returns list of uint8 RGB frames at the inference size (like the third-party DiffuEraser.forward).
+        dist: None, or (rank, world) with torch.distributed initialised (one process per GPU)."""
+        run, ctx, dev = self.run, self.ctx, self.ctx.device
+        T = len(frames)
+        H0, W0 = frames[0].shape[:2]
+        H, W = model_size(H0, W0, max_img_size)
+        f = self.vae.factor
+        rank, world = dist if dist is not None else (0, 1)
+        plan = chunk_plan(T, run.chunk, run.overlap)
+        wts = blend_weights(plan)
+        shards = shard_chunks(len(plan), world)
+        owner, chunk_rank = frame_owner(plan, shards)
+        mine = shards[rank]
+
+        def prep(lst, a, b, mask=False):
+            arr = np.stack(lst[a:b])
+            t = torch.from_numpy(arr).to(dev)          # masks: every kernel treats any non-zero byte as "masked"
+            if (H, W) != (H0, W0):
+                t = hip.resize_u8(t.contiguous(), H, W, mode="nearest" if mask else "bilinear")
+            return t.contiguous()
+
+        # frames this rank owns (first-covering-chunk rule) + their accumulator
+        own_idx = np.nonzero(owner == rank)[0]
+        acc = {}           # frame index -> fp32 [H,W,3] accumulator (owned frames only)
+        pending = []       # (chunk index, decoded tensor) kept until blended / sent
+        n_my = len(mine)
+        for k, ci in enumerate(mine):
+            s, e = plan[ci]
+            fr, pr, mk = prep(frames, s, e), prep(priori, s, e), prep(masks2d, s, e, mask=True)
+            noise = chunk_noise(run.seed, ci, (e - s, 4, H // f, W // f)).permute(0, 2, 3, 1).contiguous().to(dev)
+            cb = None
+            if progress is not None:
+                cb = lambda i, n, k=k: progress(k * n + i, n_my * n)
+            dec = self.denoise_chunk(fr, pr, mk, noise, steps=steps, scheduler=scheduler, progress=cb)
+            pending.append((ci, dec))
+        # ---- blend time: exchange the decoded overlap frames with the owning rank, then blend in chunk order
+        contrib = {}       # chunk index -> {frame index -> decoded [H,W,3] fp32}   (for frames this rank owns)
+        for ci, dec in pending:
+            s, e = plan[ci]
+            for fi in range(s, e):
+                if owner[fi] == rank:
+                    contrib.setdefault(ci, {})[fi] = dec[fi - s]
+        if world > 1:
+            import torch.distributed as td
+            for ci, (s, e) in enumerate(plan):
+                src = chunk_rank[ci]
+                for dst in sorted(set(int(o) for o in owner[s:e]) - {src}):
+                    idx = [fi for fi in range(s, e) if owner[fi] == dst]
+                    if rank == src:
+                        dec = dict(pending)[ci]
+                        td.send(dec[idx[0] - s: idx[-1] + 1 - s].contiguous(), dst)
+                    elif rank == dst:
+                        buf = torch.empty((len(idx), H, W, 3), dtype=torch.float32, device=dev)
+                        td.recv(buf, src)
+                        for j, fi in enumerate(idx):
+                            contrib.setdefault(ci, {})[fi] = buf[j]
+        out_frames = {}
+        if len(own_idx):
+            lo, hi = int(own_idx[0]), int(own_idx[-1]) + 1
+            accT = torch.zeros((hi - lo, H, W, 3), dtype=torch.float32, device=dev)
+            for ci in sorted(contrib):                       # canonical chunk order
+                s, _ = plan[ci]
+                fis = sorted(contrib[ci])
+                a, b = fis[0], fis[-1] + 1
+                assert fis == list(range(a, b))
+                dec = torch.stack([contrib[ci][fi] for fi in fis])
+                w = torch.from_numpy(wts[ci][a - s: b - s]).to(dev)
+                hip.decode_blend(dec.contiguous(), w, accT[a - lo: b - lo])
+            if return_float:
+                return accT.cpu().numpy(), (lo, hi)
+            fr, mk = prep(frames, lo, hi), prep(masks2d, lo, hi, mask=True)
+            out = hip.blur_compose(accT, fr, mk, self.taps).cpu().numpy()
+            for j in range(hi - lo):
+                out_frames[lo + j] = out[j]
+        if world > 1:
+            import torch.distributed as td
+            gathered = [None] * world
+            td.all_gather_object(gathered, out_frames)
+            out_frames = {}
+            for g in gathered:
+                out_frames.update(g)
+        return [out_frames[i] for i in range(T)]

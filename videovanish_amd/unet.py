@@ -1,0 +1,209 @@
+"""Motion-UNet and BrushNet branch on HIP kernels (architecture: SURVEY App. D.1-D.3; the reference reaches them
+through `DiffuEraser.forward`, call site reference diffuerase.py:62-67)."""
+import math
+
+import torch
+
+from . import hip
+from .nn import Conv, GroupNorm, Linear, MotionModule, ResBlock, SpatialTransformer
+
+
+def timestep_embedding(t, dim):
+    """[cos | sin] sinusoidal embedding (diffusers flip_sin_to_cos=True, freq shift 0); tiny host-side table."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    a = float(t) * freqs
+    return torch.cat([torch.cos(a), torch.sin(a)])[None]
+
+
+def sinusoidal_pos_emb(n, dim):
+    pos = torch.arange(n, dtype=torch.float32)[:, None]
+    div = torch.exp(torch.arange(0, dim, 2, dtype=torch.float32) * (-math.log(10000.0) / dim))
+    pe = torch.zeros(n, dim)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+class _Backbone:
+    """Shared down/mid/up structure of the UNet and of BrushNet."""
+
+    def __init__(self, ctx, pre, cfg, text_h16, motion, in_pad):
+        self.ctx, self.cfg, self.pre, self.motion = ctx, cfg, pre, motion
+        bo, L, lpb = cfg.block_out, len(cfg.block_out), cfg.layers_per_block
+        td = cfg.temb_dim
+        self.t1 = Linear(ctx, pre + ".time_embedding.linear_1", bo[0], td)
+        self.t2 = Linear(ctx, pre + ".time_embedding.linear_2", td, td)
+        cin_real = cfg.in_ch if motion else cfg.brush_in_ch
+        self.conv_in = Conv(ctx, pre + ".conv_in", cin_real, bo[0], cin_pad=in_pad)
+        pes = {}
+
+        def pe(C):
+            if C not in pes:
+                pes[C] = ctx.dev(sinusoidal_pos_emb(cfg.motion_max_seq, C))
+            return pes[C]
+
+        def layer(name_res, name_attn, name_mot, cin, cout, attn):
+            r = ResBlock(ctx, name_res, cin, cout, cfg.groups, 1e-5, td)
+            a = SpatialTransformer(ctx, name_attn, cout, cfg, text_h16) if attn else None
+            m = MotionModule(ctx, name_mot, cout, cfg, pe(cout)) if motion else None
+            return r, a, m
+
+        self.down, self.downs = [], []
+        skip_ch = [bo[0]]
+        cin = bo[0]
+        for i, cout in enumerate(bo):
+            layers = []
+            for j in range(lpb):
+                layers.append(layer(f"{pre}.down_blocks.{i}.resnets.{j}", f"{pre}.down_blocks.{i}.attentions.{j}",
+                                    f"{pre}.down_blocks.{i}.motion_modules.{j}", cin, cout, cfg.attn_levels[i]))
+                cin = cout
+                skip_ch.append(cout)
+            self.down.append(layers)
+            if i < L - 1:
+                self.downs.append(Conv(ctx, f"{pre}.down_blocks.{i}.downsamplers.0.conv", cout, cout))
+                skip_ch.append(cout)
+        self.skip_ch = list(skip_ch)
+        C = bo[-1]
+        self.mid_r0 = ResBlock(ctx, f"{pre}.mid_block.resnets.0", C, C, cfg.groups, 1e-5, td)
+        self.mid_a = SpatialTransformer(ctx, f"{pre}.mid_block.attentions.0", C, cfg, text_h16)
+        self.mid_m = MotionModule(ctx, f"{pre}.mid_block.motion_modules.0", C, cfg, pe(C)) if motion else None
+        self.mid_r1 = ResBlock(ctx, f"{pre}.mid_block.resnets.1", C, C, cfg.groups, 1e-5, td)
+        self.up, self.ups, self.up_ch = [], [], []
+        rev, rev_attn = list(reversed(bo)), list(reversed(cfg.attn_levels))
+        x_ch = C
+        for i, cout in enumerate(rev):
+            layers = []
+            for j in range(lpb + 1):
+                sc = skip_ch.pop()
+                layers.append(layer(f"{pre}.up_blocks.{i}.resnets.{j}", f"{pre}.up_blocks.{i}.attentions.{j}",
+                                    f"{pre}.up_blocks.{i}.motion_modules.{j}", x_ch + sc, cout, rev_attn[i]))
+                x_ch = cout
+                self.up_ch.append(cout)
+            self.up.append(layers)
+            if i < L - 1:
+                self.ups.append(Conv(ctx, f"{pre}.up_blocks.{i}.upsamplers.0.conv", cout, cout))
+                self.up_ch.append(cout)
+
+    def temb(self, t):
+        e = self.ctx.dev(timestep_embedding(t, self.cfg.block_out[0]))
+        e = hip.silu(self.t1(e))
+        return hip.silu(self.t2(e))            # every consumer applies SiLU first (ResnetBlock2D.time_emb_proj)
+
+    def run_down(self, x_in, F, h, w, st):
+        """x_in: h16 [F*h*w, in_pad].  Returns (x, skips=[(tensor,H,W)...], (H,W))."""
+        x, _, _ = self.conv_in(x_in, F, h, w)
+        H, W = h, w
+        skips = [(x, H, W)]
+        L = len(self.cfg.block_out)
+        for i, layers in enumerate(self.down):
+            for (r, a, m) in layers:
+                x = r(x, F, H, W, silu_temb=st)
+                if a is not None:
+                    x = a(x, F, H, W)
+                if m is not None:
+                    x = m(x, F, H, W)
+                skips.append((x, H, W))
+            if i < L - 1:
+                x, H, W = self.downs[i](x, F, H, W, stride=2)
+                skips.append((x, H, W))
+        return x, skips, (H, W)
+
+    def run_mid(self, x, F, H, W, st):
+        x = self.mid_r0(x, F, H, W, silu_temb=st)
+        x = self.mid_a(x, F, H, W)
+        if self.mid_m is not None:
+            x = self.mid_m(x, F, H, W)
+        return self.mid_r1(x, F, H, W, silu_temb=st)
+
+    def run_up(self, x, F, H, W, skips, st, add_up=None, collect=False):
+        """skips: list of (tensor,H,W) consumed from the end.  add_up: per-layer residual tensors fused into the last
+        GEMM of each layer (res1).  collect: return the per-layer outputs (BrushNet)."""
+        outs = []
+        add_up = list(add_up) if add_up is not None else None
+        L = len(self.cfg.block_out)
+        for i, layers in enumerate(self.up):
+            for (r, a, m) in layers:
+                s, sh, sw = skips.pop()
+                au = add_up.pop(0) if add_up is not None else None
+                last = "m" if m is not None else ("a" if a is not None else "r")
+                x = r(x, F, H, W, x1=s, silu_temb=st, res1=au if last == "r" else None)
+                if a is not None:
+                    x = a(x, F, H, W)
+                    if last == "a" and au is not None:
+                        hip.add_inplace(self.ctx.dt, x, au)
+                if m is not None:
+                    x = m(x, F, H, W, res1=au)
+                if collect:
+                    outs.append((x, H, W))
+            if i < L - 1:
+                _, Hn, Wn = skips[-1]
+                au = add_up.pop(0) if add_up is not None else None
+                x, H, W = self.ups[i](x, F, H, W, Hv=Hn, Wv=Wn, res1=au)
+                if collect:
+                    outs.append((x, H, W))
+        return x, outs, (H, W)
+
+
+class BrushNet(_Backbone):
+    def __init__(self, ctx, cfg, text_h16):
+        super().__init__(ctx, "brushnet", cfg, text_h16, motion=False, in_pad=16)
+        zg = cfg.zero_conv_gain
+        self.zd = [Conv(ctx, f"brushnet.brushnet_down_blocks.{i}", c, c, k=1, gain=zg) for i, c in enumerate(self.skip_ch)]
+        self.zm = Conv(ctx, "brushnet.brushnet_mid_block", cfg.block_out[-1], cfg.block_out[-1], k=1, gain=zg)
+        self.zu = [Conv(ctx, f"brushnet.brushnet_up_blocks.{i}", c, c, k=1, gain=zg) for i, c in enumerate(self.up_ch)]
+
+    def __call__(self, x16, t, F, h, w, unet_skips, unet_mid, scale=1.0):
+        """x16: h16 [F*h*w,16] BrushNet input.  unet_skips / unet_mid: the UNet's own down skips and mid output;
+        the zero-conv GEMMs add them in their epilogue, so the returned tensors are already (skip + residual)."""
+        st = self.temb(t)
+        x, skips, (H, W) = self.run_down(x16, F, h, w, st)
+        down_raw = list(skips)
+        mid = self.run_mid(x, F, H, W, st)
+        _, ups, _ = self.run_up(mid, F, H, W, skips, st, collect=True)
+        new_skips = []
+        for z, (s, sh, sw), (us, _, _) in zip(self.zd, down_raw, unet_skips):
+            o, _, _ = z(s, F, sh, sw, res0=us, scale=scale)
+            new_skips.append((o, sh, sw))
+        new_mid, _, _ = self.zm(mid, F, H, W, res0=unet_mid, scale=scale)
+        add_up = [z(s, F, sh, sw, scale=scale)[0] for z, (s, sh, sw) in zip(self.zu, ups)]
+        return new_skips, new_mid, add_up
+
+
+class UNetMotion(_Backbone):
+    def __init__(self, ctx, cfg, text_h16):
+        super().__init__(ctx, "unet", cfg, text_h16, motion=True, in_pad=8)
+        self.norm_out = GroupNorm(ctx, "unet.conv_norm_out", cfg.block_out[0], cfg.groups, 1e-5)
+        self.conv_out = Conv(ctx, "unet.conv_out", cfg.block_out[0], cfg.out_ch)
+
+    def down_mid(self, lat8, t, F, h, w):
+        st = self.temb(t)
+        x, skips, (H, W) = self.run_down(lat8, F, h, w, st)
+        mid = self.run_mid(x, F, H, W, st)
+        return st, skips, mid, (H, W)
+
+    def up_out(self, st, skips, mid, F, H, W, add_up):
+        x, _, (H, W) = self.run_up(mid, F, H, W, skips, st, add_up=add_up)
+        h = self.norm_out(x, F, H * W, silu=True)
+        eps, _, _ = self.conv_out(h, F, H, W)
+        return eps            # fp32 [F*h*w, 4]
+
+
+class Denoiser:
+    """eps = UNet(latents, t | BrushNet(cat[latents, cond, mask], t)) for one clip."""
+
+    def __init__(self, ctx, cfg, text_states):
+        self.ctx, self.cfg = ctx, cfg
+        text_h16 = ctx.dev(text_states[0], ctx.h16)
+        self.unet = UNetMotion(ctx, cfg, text_h16)
+        self.brush = BrushNet(ctx, cfg, text_h16)
+
+    def __call__(self, lat, cond, mask2d, t, F, h, w, H, W):
+        """lat, cond: fp32 [F,h,w,4] device; mask2d: u8 [F,H,W]."""
+        ctx = self.ctx
+        lat8 = hip.pad_channels(ctx.dt, lat, 8).view(F * h * w, 8)
+        st, skips, mid, (Hm, Wm) = self.unet.down_mid(lat8, t, F, h, w)
+        x16 = hip.brushnet_input(ctx.dt, lat, cond, mask2d, H, W).view(F * h * w, 16)
+        new_skips, new_mid, add_up = self.brush(x16, t, F, h, w, skips, mid)
+        eps = self.unet.up_out(st, new_skips, new_mid, F, Hm, Wm, add_up)
+        return eps.view(F, h, w, 4)
