@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- inpainted frames/sec of the DiffuEraser hot path at 720p / 50 denoise steps on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch = ONE 32-frame 1280x720 chunk: VAE encode (prior + masked
+image) -> 50 DDIM steps of BrushNet + motion-UNet -> VAE decode -> overlap blend -> soft-mask compose, inputs
+(uint8 frames / prior / masks, noise) already resident in HBM.  Every rank runs K chunks of one long synthetic video
+(weak scaling; contiguous chunk blocks per rank; the 8-frame overlaps at rank boundaries are exchanged over RCCL at
+blend time).  Credited output = DISTINCT frames (24 new frames per chunk; overlap recompute is not credited).
+
+Prints ONE JSON line (rank 0) with the driver's contract fields + `roofline` (dominant kernel, HIP-event timed inside
+the timed region) + `cpu_baseline` (the fp32 oracle on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_clip(T, H, W, seed=1234, t0=0):
+    """SURVEY 8d synthetic inputs: uniform random frames, one 25% x 25% rectangle drifting +2 px/frame, prior = frame with
+    the masked pixels replaced by the per-frame mean colour (bypasses ProPainter exactly as diffuerase.py:47 allows)."""
+    rng = np.random.default_rng(seed)
+    frames = rng.integers(0, 256, (T, H, W, 3), dtype=np.uint8)
+    masks = np.zeros((T, H, W), np.uint8)
+    rh, rw = H // 4, W // 4
+    for t in range(T):
+        x0 = (W // 8 + 2 * (t0 + t)) % (W - rw)
+        masks[t, H // 3: H // 3 + rh, x0: x0 + rw] = 255
+    prior = frames.copy()
+    for t in range(T):
+        prior[t][masks[t] > 0] = frames[t].reshape(-1, 3).mean(0).astype(np.uint8)
+    return frames, masks, prior
+
+
+def cpu_baseline(H, W, steps, chunk, overlap):
+    """The oracle (kind "port": fp32 torch restatement) timed on the host cores on a bounded sample of the same workload:
+    one BrushNet+UNet denoise step on ONE 720p frame, plus one VAE encode + decode of one frame at quarter area (x4),
+    extrapolated linearly to 50 steps / 2 encodes / 1 decode per frame."""
+    from oracle import model_ref as M
+    from videovanish_amd.config import UNetConfig, VAEConfig
+    ucfg, vcfg = UNetConfig(), VAEConfig()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = M.Params(0)
+    h, w = H // 8, W // 8
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(1, 4, h, w, generator=g)
+    x9 = torch.cat([lat, lat, torch.ones(1, 1, h, w)], 1)
+    text = M.text_states(P, ucfg)
+    hs, ws = (H // 2) // 8 * 8, (W // 2) // 8 * 8
+    img = torch.rand(1, 3, hs, ws, generator=g) * 2 - 1
+    with torch.no_grad():
+        # materialise weights outside the timed sample (tiny input touches every layer)
+        small = torch.randn(1, 4, 8, 8, generator=g)
+        M.unet_forward(P, small, 500, text, ucfg, M.brushnet_forward(P, torch.cat([small, small, torch.ones(1, 1, 8, 8)], 1), 500, text, ucfg))
+        z0 = M.vae_encode(P, torch.zeros(1, 3, 16, 16), vcfg); M.vae_decode(P, z0, vcfg)
+        t0 = time.time()
+        M.unet_forward(P, lat, 500, text, ucfg, M.brushnet_forward(P, x9, 500, text, ucfg))
+        t_step = time.time() - t0
+        t0 = time.time()
+        z = M.vae_encode(P, img, vcfg)
+        t_enc = (time.time() - t0) * (H * W) / float(hs * ws)
+        t0 = time.time()
+        M.vae_decode(P, z, vcfg)
+        t_dec = (time.time() - t0) * (H * W) / float(hs * ws)
+    per_frame = steps * t_step + 2 * t_enc + t_dec
+    inflation = chunk / float(chunk - overlap)
+    return {"value": 1.0 / (per_frame * inflation), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 frame x 1 denoise step at {W}x{H} ({t_step:.1f}s) + VAE enc/dec of 1 frame at {ws}x{hs} scaled x{H * W / float(hs * ws):.1f} "
+                      f"({t_enc:.1f}s/{t_dec:.1f}s); extrapolated to {steps} steps, 2 enc + 1 dec per frame, x{inflation:.2f} chunk overlap"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--chunk", type=int, default=32)
+    ap.add_argument("--overlap", type=int, default=8)
+    ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--arch", default="full", choices=["full", "small", "tiny"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = (rank, world)
+
+    from videovanish_amd import hip
+    from videovanish_amd.config import SMALL_UNET, SMALL_VAE, TINY_UNET, TINY_VAE, RunConfig, UNetConfig, VAEConfig
+    from videovanish_amd.pipeline import DiffuEraserHIP, chunk_plan, shard_chunks
+    ucfg, vcfg = {"full": (UNetConfig(), VAEConfig()), "small": (SMALL_UNET, SMALL_VAE), "tiny": (TINY_UNET, TINY_VAE)}[args.arch]
+    run = RunConfig(steps=args.denoise_steps, chunk=args.chunk, overlap=args.overlap, seed=42, weight_seed=0, dtype=args.dtype, unet=ucfg, vae=vcfg)
+    t_build = time.time()
+    model = DiffuEraserHIP(run, f"cuda:{local_rank}")
+    torch.cuda.synchronize()
+    t_build = time.time() - t_build
+    H, W = args.height, args.width
+    stride = args.chunk - args.overlap
+    dev = model.ctx.device
+
+    def resident_inputs(n_chunks_per_rank):
+        """This rank's slice of a (world * n) -chunk synthetic video, uploaded BEFORE the timed region."""
+        T = stride * n_chunks_per_rank * world + args.overlap
+        plan = chunk_plan(T, args.chunk, args.overlap)
+        assert len(plan) == n_chunks_per_rank * world
+        mine = shard_chunks(len(plan), world)[rank]
+        base, end = plan[mine[0]][0], plan[mine[-1]][1]
+        fr, mk, pr = synth_clip(end - base, H, W, seed=1234 + rank, t0=base)
+        return T, base, torch.from_numpy(fr).to(dev), torch.from_numpy(pr).to(dev), torch.from_numpy(mk).to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as td
+            td.barrier()
+            torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        T, base, fr, pr, mk = resident_inputs(args.warmup)
+        model.forward_device(fr, pr, mk, T, base, steps=args.denoise_steps, scheduler="ddim", dist=dist)
+        del fr, pr, mk
+    T, base, fr, pr, mk = resident_inputs(args.steps)
+    if not args.no_kernel_events:
+        hip.PROFILE = []
+    barrier()
+    t0 = time.time()
+    out, (lo, hi) = model.forward_device(fr, pr, mk, T, base, steps=args.denoise_steps, scheduler="ddim", dist=dist)
+    barrier()
+    dt = time.time() - t0
+    prof, hip.PROFILE = hip.PROFILE, None
+    if world > 1:
+        import torch.distributed as td
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = float(tt.item())
+    distinct = stride * args.steps * world          # credited frames: every chunk contributes (chunk - overlap) new frames
+    assert out is not None and out.dtype == torch.uint8 and out.shape[1:] == (H, W, 3)
+
+    if rank != 0:
+        if world > 1:
+            import torch.distributed as td
+            td.destroy_process_group()
+        return
+    # ---- roofline of the dominant kernel (HIP events recorded on the launch stream inside the timed region)
+    roof = None
+    kernels = {}
+    if prof:
+        for key, flops, nbytes, e0, e1 in prof:
+            k = kernels.setdefault(key, [0, 0.0, 0.0, 0.0])
+            k[0] += 1; k[1] += e0.elapsed_time(e1) * 1e-3; k[2] += flops; k[3] += nbytes
+        dom = max(kernels, key=lambda k: kernels[k][1])
+        n, tsec, fl, by = kernels[dom]
+        mfma = fl > 0
+        ach = (fl / tsec / 1e12) if mfma else (by / tsec / 1e9)
+        peak = MFMA_PEAK_TFLOPS if mfma else HBM_PEAK_GBS
+        roof = {"kernel": dom, "bound": "mfma" if mfma else "hbm", "achieved": round(ach, 2), "peak": peak,
+                "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "traffic": None, "launches": n,
+                "avg_launch_ms": round(tsec / n * 1e3, 4), "algorithmic_per_launch": (fl if mfma else by) / n,
+                "share_of_step_time": round(tsec / dt, 3)}
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline(H, W, args.denoise_steps, args.chunk, args.overlap)
+    res = {
+        "metric": "inpainted frames/sec at 720p, 50 denoise steps", "value": round(distinct / dt, 5), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"c3 chunk: {args.chunk}-frame {W}x{H} chunk, {args.denoise_steps} DDIM steps, {args.chunk}/{args.overlap} chunk/overlap, "
+                               f"{args.arch} SD-1.5 UNet+BrushNet+motion / SD-VAE, random-init weights",
+                   "frames_per_step": args.chunk, "credited_frames_per_step": stride, "chunks_per_rank": args.steps,
+                   "parallelism": f"chunk-dp{world}", "model_build_s": round(t_build, 1)},
+        "roofline": roof, "cpu_baseline": cpu,
+        "kernel_times_s": {k: [v[0], round(v[1], 3), round(v[2] / v[1] / 1e12, 1) if v[2] else round(v[3] / v[1] / 1e9, 1)] for k, v in
+                           sorted(kernels.items(), key=lambda kv: -kv[1][1])},
+    }
+    print(json.dumps(res))
+    if world > 1:
+        import torch.distributed as td
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

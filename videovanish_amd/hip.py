@@ -13,6 +13,29 @@ EPI_NONE, EPI_GEGLU = 0, 1
 _DT = {"bf16": BF16, "fp16": F16}
 _TORCH_H16 = {BF16: torch.bfloat16, F16: torch.float16}
 
+PROFILE = None   # bench.py sets this to a list: every MFMA-kernel launch is then bracketed by HIP events on the launch stream
+
+
+class _Prof:
+    """Bracket one launch with events on torch's current stream (the stream the kernel is launched on)."""
+
+    def __init__(self, key, flops, nbytes):
+        self.rec = None
+        if PROFILE is not None:
+            self.rec = [key, flops, nbytes, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.rec[3].record()
+        return self
+
+    def __exit__(self, *a):
+        if self.rec is not None:
+            self.rec[4].record()
+            PROFILE.append(self.rec)
+        return False
+
+
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libvvhip.so")
 _lib = None
 
@@ -125,6 +148,16 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
                    res0=res0.data_ptr() if res0 is not None else 0, res1=res1.data_ptr() if res1 is not None else 0,
                    res_dtype=dt_of(res0) if res0 is not None else F32, out=out.data_ptr(), out_dtype=dt_of(out), ldo=out.shape[-1],
                    epilogue=epilogue, out_scale=out_scale)
+    if PROFILE is not None:
+        Npad = weight.shape[0]
+        tile = "128x128" if epilogue == EPI_GEGLU else ("128x160" if Npad % 160 == 0 else ("128x128" if Npad % 128 == 0 else "128x16"))
+        key = f"conv_gemm[{tile},{'f32in' if x0.dtype == torch.float32 else 'h16in'},k{ksize}]"
+        es = x0.element_size()
+        nbytes = F * Hin * Win * (C0 + C1) * es + N * K * 2 + M * nout * out.element_size() + sum(
+            M * N * r.element_size() for r in (res0, res1) if r is not None)
+        with _Prof(key, 2.0 * M * N * K, nbytes):
+            _check(lib().vv_conv_gemm(C.byref(p), dtype, _stream()), "vv_conv_gemm")
+        return out
     _check(lib().vv_conv_gemm(C.byref(p), dtype, _stream()), "vv_conv_gemm")
     return out
 
@@ -140,7 +173,8 @@ def groupnorm(dtype, x0, gamma, beta, groups, eps, *, x1=None, F, HW, silu=False
     p = GroupNormParams(in0=x0.data_ptr(), in1=x1.data_ptr() if x1 is not None else 0, in_dtype=dt_of(x0), C0=C0, C1=C1, F=F, HW=HW,
                         groups=groups, pool_frames=int(pool_frames), eps=eps, gamma=gamma.data_ptr(), beta=beta.data_ptr(),
                         silu=int(silu), stats_ws=ws.data_ptr(), out=out.data_ptr(), out_dtype=dt_of(out))
-    _check(lib().vv_groupnorm(C.byref(p), dtype, _stream()), "vv_groupnorm")
+    with _Prof("groupnorm", 0.0, F * HW * Ctot * (2 * x0.element_size() + out.element_size())):
+        _check(lib().vv_groupnorm(C.byref(p), dtype, _stream()), "vv_groupnorm")
     return out
 
 
@@ -148,7 +182,8 @@ def layernorm(dtype, x, gamma, beta, pe=None, rows_per_frame=1):
     _need_cuda(x, gamma, beta, pe)
     M, Cc = x.shape
     out = torch.empty((M, Cc), dtype=h16(dtype), device=x.device)
-    _check(lib().vv_layernorm(_p(x), M, Cc, _p(gamma), _p(beta), _p(pe), rows_per_frame, _p(out), dtype, _stream()), "vv_layernorm")
+    with _Prof("layernorm", 0.0, M * Cc * 6):
+        _check(lib().vv_layernorm(_p(x), M, Cc, _p(gamma), _p(beta), _p(pe), rows_per_frame, _p(out), dtype, _stream()), "vv_layernorm")
     return out
 
 
@@ -159,7 +194,9 @@ def attention(dtype, q, k, v, out, *, B, heads, Nq, Nkv, D, q_bs, k_bs, v_bs, o_
     p = AttnParams(q=q.data_ptr() + q_off * es, k=k.data_ptr() + k_off * es, v=v.data_ptr() + v_off * es, o=out.data_ptr(),
                    q_bs=q_bs, k_bs=k_bs, v_bs=v_bs, o_bs=o_bs, q_rs=q_rs, k_rs=k_rs, v_rs=v_rs, o_rs=o_rs, B=B, heads=heads, Nq=Nq,
                    Nkv=Nkv, D=D, scale=float(D) ** -0.5)
-    _check(lib().vv_attention(C.byref(p), dtype, _stream()), "vv_attention")
+    kind = "temporal" if (Nq <= 32 and Nkv <= 32) else ("cross" if Nkv < 128 and Nq != Nkv else "spatial")
+    with _Prof(f"attention[{kind},d{D}]", 4.0 * B * heads * Nq * Nkv * D, 2 * B * heads * D * (2 * Nq + 2 * Nkv)):
+        _check(lib().vv_attention(C.byref(p), dtype, _stream()), "vv_attention")
     return out
 
 

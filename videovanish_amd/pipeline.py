@@ -182,78 +182,35 @@ class DiffuEraserHIP:
         """frames / priori: list of (H0,W0,3) uint8; masks2d: list of (H0,W0) uint8 (non-zero = masked).
         Returns list of uint8 RGB frames at the inference size (like the third-party DiffuEraser.forward).
         dist: None, or (rank, world) with torch.distributed initialised (one process per GPU)."""
-        run, ctx, dev = self.run, self.ctx, self.ctx.device
+        run, dev = self.run, self.ctx.device
         T = len(frames)
         H0, W0 = frames[0].shape[:2]
         H, W = model_size(H0, W0, max_img_size)
-        f = self.vae.factor
         rank, world = dist if dist is not None else (0, 1)
         plan = chunk_plan(T, run.chunk, run.overlap)
-        wts = blend_weights(plan)
-        shards = shard_chunks(len(plan), world)
-        owner, chunk_rank = frame_owner(plan, shards)
-        mine = shards[rank]
+        mine = shard_chunks(len(plan), world)[rank]
 
         def prep(lst, a, b, mask=False):
-            arr = np.stack(lst[a:b])
-            t = torch.from_numpy(arr).to(dev)          # masks: every kernel treats any non-zero byte as "masked"
+            t = torch.from_numpy(np.stack(lst[a:b])).to(dev)      # masks: every kernel treats any non-zero byte as "masked"
             if (H, W) != (H0, W0):
                 t = hip.resize_u8(t.contiguous(), H, W, mode="nearest" if mask else "bilinear")
             return t.contiguous()
 
-        # frames this rank owns (first-covering-chunk rule) + their accumulator
-        own_idx = np.nonzero(owner == rank)[0]
-        acc = {}           # frame index -> fp32 [H,W,3] accumulator (owned frames only)
-        pending = []       # (chunk index, decoded tensor) kept until blended / sent
-        n_my = len(mine)
-        for k, ci in enumerate(mine):
-            s, e = plan[ci]
-            fr, pr, mk = prep(frames, s, e), prep(priori, s, e), prep(masks2d, s, e, mask=True)
-            noise = chunk_noise(run.seed, ci, (e - s, 4, H // f, W // f)).permute(0, 2, 3, 1).contiguous().to(dev)
-            cb = None
-            if progress is not None:
-                cb = lambda i, n, k=k: progress(k * n + i, n_my * n)
-            dec = self.denoise_chunk(fr, pr, mk, noise, steps=steps, scheduler=scheduler, progress=cb)
-            pending.append((ci, dec))
-        # ---- blend time: exchange the decoded overlap frames with the owning rank, then blend in chunk order
-        contrib = {}       # chunk index -> {frame index -> decoded [H,W,3] fp32}   (for frames this rank owns)
-        for ci, dec in pending:
-            s, e = plan[ci]
-            for fi in range(s, e):
-                if owner[fi] == rank:
-                    contrib.setdefault(ci, {})[fi] = dec[fi - s]
-        if world > 1:
-            import torch.distributed as td
-            for ci, (s, e) in enumerate(plan):
-                src = chunk_rank[ci]
-                for dst in sorted(set(int(o) for o in owner[s:e]) - {src}):
-                    idx = [fi for fi in range(s, e) if owner[fi] == dst]
-                    if rank == src:
-                        dec = dict(pending)[ci]
-                        td.send(dec[idx[0] - s: idx[-1] + 1 - s].contiguous(), dst)
-                    elif rank == dst:
-                        buf = torch.empty((len(idx), H, W, 3), dtype=torch.float32, device=dev)
-                        td.recv(buf, src)
-                        for j, fi in enumerate(idx):
-                            contrib.setdefault(ci, {})[fi] = buf[j]
+        if mine:
+            base, end = plan[mine[0]][0], plan[mine[-1]][1]
+            fr, pr, mk = prep(frames, base, end), prep(priori, base, end), prep(masks2d, base, end, mask=True)
+        else:
+            base, fr, pr, mk = 0, None, None, None
+        res = self.forward_device(fr, pr, mk, T, base, steps=steps, scheduler=scheduler, progress=progress, dist=dist, return_float=return_float)
+        if return_float:
+            out, (lo, hi) = res
+            return out.cpu().numpy(), (lo, hi)
+        out, (lo, hi) = res
         out_frames = {}
-        if len(own_idx):
-            lo, hi = int(own_idx[0]), int(own_idx[-1]) + 1
-            accT = torch.zeros((hi - lo, H, W, 3), dtype=torch.float32, device=dev)
-            for ci in sorted(contrib):                       # canonical chunk order
-                s, _ = plan[ci]
-                fis = sorted(contrib[ci])
-                a, b = fis[0], fis[-1] + 1
-                assert fis == list(range(a, b))
-                dec = torch.stack([contrib[ci][fi] for fi in fis])
-                w = torch.from_numpy(wts[ci][a - s: b - s]).to(dev)
-                hip.decode_blend(dec.contiguous(), w, accT[a - lo: b - lo])
-            if return_float:
-                return accT.cpu().numpy(), (lo, hi)
-            fr, mk = prep(frames, lo, hi), prep(masks2d, lo, hi, mask=True)
-            out = hip.blur_compose(accT, fr, mk, self.taps).cpu().numpy()
+        if out is not None:
+            o = out.cpu().numpy()
             for j in range(hi - lo):
-                out_frames[lo + j] = out[j]
+                out_frames[lo + j] = o[j]
         if world > 1:
             import torch.distributed as td
             gathered = [None] * world
@@ -262,3 +219,62 @@ class DiffuEraserHIP:
             for g in gathered:
                 out_frames.update(g)
         return [out_frames[i] for i in range(T)]
+
+    def forward_device(self, fr, pr, mk, T, base, steps=None, scheduler="ddim", progress=None, dist=None, return_float=False):
+        """Device-resident core.  fr/pr: u8 [n,H,W,3], mk: u8 [n,H,W] hold frames [base, base+n) of a T-frame video at
+        the inference size: exactly the frames covered by this rank's chunks.  Returns (u8 [hi-lo,H,W,3] device tensor of
+        the frames this rank OWNS, (lo, hi)); with return_float the blended fp32 pixels instead of the composed u8."""
+        run, dev = self.run, self.ctx.device
+        rank, world = dist if dist is not None else (0, 1)
+        f = self.vae.factor
+        plan = chunk_plan(T, run.chunk, run.overlap)
+        wts = blend_weights(plan)
+        shards = shard_chunks(len(plan), world)
+        owner, chunk_rank = frame_owner(plan, shards)
+        mine = shards[rank]
+        H, W = (fr.shape[1], fr.shape[2]) if fr is not None else (0, 0)
+        pending = {}       # chunk index -> decoded fp32 [F,H,W,3], kept until blended / sent
+        n_my = len(mine)
+        for k, ci in enumerate(mine):
+            s, e = plan[ci]
+            noise = chunk_noise(run.seed, ci, (e - s, 4, H // f, W // f)).permute(0, 2, 3, 1).contiguous().to(dev)
+            cb = None
+            if progress is not None:
+                cb = lambda i, n, k=k: progress(k * n + i, n_my * n)
+            pending[ci] = self.denoise_chunk(fr[s - base:e - base], pr[s - base:e - base], mk[s - base:e - base], noise, steps=steps,
+                                             scheduler=scheduler, progress=cb)
+        # ---- blend time: hand the decoded overlap frames to the owning rank (RCCL point-to-point), blend in chunk order
+        contrib = {}       # chunk index -> (first frame, decoded [n,H,W,3] fp32) for frames this rank owns
+        for ci, dec in pending.items():
+            s, e = plan[ci]
+            idx = [fi for fi in range(s, e) if owner[fi] == rank]
+            if idx:
+                contrib[ci] = (idx[0], dec[idx[0] - s: idx[-1] + 1 - s])
+        if world > 1:
+            import torch.distributed as td
+            for ci, (s, e) in enumerate(plan):
+                src = chunk_rank[ci]
+                for dst in sorted(set(int(o) for o in owner[s:e]) - {src}):
+                    idx = [fi for fi in range(s, e) if owner[fi] == dst]
+                    if rank == src:
+                        td.send(pending[ci][idx[0] - s: idx[-1] + 1 - s].contiguous(), dst)
+                    elif rank == dst:
+                        Hh, Ww = (H, W)
+                        buf = torch.empty((len(idx), Hh, Ww, 3), dtype=torch.float32, device=dev)
+                        td.recv(buf, src)
+                        contrib[ci] = (idx[0], buf)
+        own_idx = np.nonzero(owner == rank)[0]
+        if not len(own_idx):
+            return None, (0, 0)
+        lo, hi = int(own_idx[0]), int(own_idx[-1]) + 1
+        accT = torch.zeros((hi - lo, H, W, 3), dtype=torch.float32, device=dev)
+        for ci in sorted(contrib):                       # canonical chunk order
+            s, _ = plan[ci]
+            a, dec = contrib[ci]
+            b = a + dec.shape[0]
+            w = torch.from_numpy(wts[ci][a - s: b - s]).to(dev)
+            hip.decode_blend(dec.contiguous(), w, accT[a - lo: b - lo])
+        if return_float:
+            return accT, (lo, hi)
+        out = hip.blur_compose(accT, fr[lo - base: hi - base], mk[lo - base: hi - base], self.taps)
+        return out, (lo, hi)
