@@ -1,24 +1,42 @@
 // K1/K6: implicit-GEMM convolution / linear on MFMA (gfx950).  See include/vvhip.h (vv_conv_gemm).
 //
 // Tile: BM x BN x 64, 256 threads = 4 waves in a WR x WC grid, each wave MT x NT tiles of 16x16 (mfma 16x16x32).
-// A (activations) is gathered im2col-style straight from NHWC global memory into registers (16 B = 8 channels per
-// lane, one k-tile ahead of the MFMAs: issue-early / write-late), then written to an XOR-swizzled LDS image
-// [row][64] so the MFMA operand reads are ds_read_b128.  B (weights, [N][K] K-contiguous) is staged the same way.
+// LDS holds double-buffered XOR-swizzled [row][64] h16 images of the A (activation, im2col-gathered from NHWC) and
+// B (weight, [N][K] K-contiguous) tiles; MFMA operands are read with ds_read_b128.
+//   FAST path (h16 activations, channel counts multiples of 64): both tiles are filled by LDS-DMA
+//     (global_load_lds_dwordx4, per-lane source address = the im2col gather, swizzle applied on the SOURCE address,
+//     out-of-image taps read a zero page), one tile ahead of the MFMAs, no staging VGPRs, no ds_write.  The two
+//     buffers are DISTINCT __shared__ arrays and the k loop is unrolled by two, so the compiler can prove that the
+//     ds_reads of one buffer do not alias the DMA in flight into the other (otherwise it drains vmcnt(0) first).
+//   generic / fp32-activation paths: register staged (issue-early, convert, write-late).
+// The MFMA is issued with swapped operands (D = W_tile * A_tile^T) so every lane owns 4 CONSECUTIVE output channels
+// of one output row: the epilogue (bias, time-embedding vector, residuals, GEGLU, cast) is 16-byte vectorised.
 // The block index is remapped so that the column tiles of one row panel run on the same XCD (shared L2).
 #include "vv_common.h"
 
 namespace {
 
 constexpr int BK = 64;
+enum { MODE_H16 = 0, MODE_F32 = 1, MODE_FAST = 2 };
 
-template <typename T, int WR, int WC, int MT, int NT, bool AF32>
+__device__ __attribute__((aligned(64))) const unsigned int g_zero_page[16] = {0};
+
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+    typedef const void __attribute__((address_space(1))) * gp_t;
+    typedef void __attribute__((address_space(3))) * lp_t;
+    __builtin_amdgcn_global_load_lds((gp_t)gptr, (lp_t)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int WR, int WC, int MT, int NT, int MODE>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const vv_conv_params p, const int M, const int tilesM, const int tilesN) {
     constexpr int BM = WR * MT * 16, BN = WC * NT * 16;
     constexpr int AR = BM / 32;                 // A rows staged per thread
     constexpr int BCH = (BN * 8 + 255) / 256;   // B chunks staged per thread
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA = smem;                          // [2][BM][128 B]
-    unsigned char* sB = smem + 2 * BM * 128;           // [2][BN][128 B]
+    constexpr bool AF32 = MODE == MODE_F32, FAST = MODE == MODE_FAST;
+    __shared__ __attribute__((aligned(16))) unsigned char sA0[BM * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char sA1[BM * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char sB0[BN * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char sB1[BN * 128];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave / WC, wc = wave % WC;
@@ -35,9 +53,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const vv_conv_params p, 
 
     const int Cin = p.C0 + p.C1;
     const int HWo = p.Hout * p.Wout;
-    const int c8 = t & 7;                      // this thread's 16-byte chunk column inside the 64-wide k tile
+    const int c8 = t & 7;                      // this thread's 16-byte slot inside the 64-wide k tile
+    const int rsw = (t >> 3) & 7;              // (row & 7) of every row this thread stages (rows differ by 32)
     // per-row gather state
-    int rf[AR], ryb[AR], rxb[AR];
+    int rpix[AR], ryb[AR], rxb[AR];
     bool rv[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
@@ -46,15 +65,43 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const vv_conv_params p, 
         const int mm = rv[i] ? m : 0;
         const int f = mm / HWo, rem = mm - f * HWo;
         const int y = rem / p.Wout, x = rem - y * p.Wout;
-        rf[i] = f; ryb[i] = y * p.stride - p.pad_t; rxb[i] = x * p.stride - p.pad_l;
+        ryb[i] = y * p.stride - p.pad_t; rxb[i] = x * p.stride - p.pad_l;
+        rpix[i] = FAST ? (f * p.Hin + ryb[i]) * p.Win + rxb[i] : f;     // FAST: pixel index of tap (0,0); else frame
     }
     const bool resize = (p.Hv != p.Hin) || (p.Wv != p.Win);
     const unsigned short* wbase = (const unsigned short*)p.weight;
 
-    uint4 ra[AR];          // staged A chunks (h16)  -- or first half of fp32
+    uint4 ra[FAST ? 1 : AR];
     uint4 ra2[AF32 ? AR : 1];
-    uint4 rb[BCH];
+    uint4 rb[FAST ? 1 : BCH];
 
+    // ---- FAST: LDS-DMA fill of k tile kt (lies inside one tap and one source) into the given buffers
+    auto dma_tile = [&](int kt, unsigned char* bufA, unsigned char* bufB) {
+        const int k0 = kt * BK;
+        const int tap = k0 / Cin;
+        int cc = k0 - tap * Cin;
+        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+        const unsigned char* src = (const unsigned char*)p.in0;
+        int Cs = p.C0;
+        if (cc >= p.C0) { src = (const unsigned char*)p.in1; cc -= p.C0; Cs = p.C1; }
+        const int dpix = ky * p.Win + kx;
+        const int csrc = cc + ((c8 ^ rsw) << 3);              // swizzle on the SOURCE address, LDS image stays lane-linear
+        unsigned char* a = bufA + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int yv = ryb[i] + ky, xv = rxb[i] + kx;
+            const bool ok = rv[i] && yv >= 0 && yv < p.Hin && xv >= 0 && xv < p.Win;
+            const void* g = ok ? (const void*)(src + ((int64_t)(rpix[i] + dpix) * Cs + csrc) * 2) : (const void*)g_zero_page;
+            glds16(g, a + i * 32 * 128);
+        }
+        unsigned char* b = bufB + wave * 1024;
+        const unsigned short* wrow = wbase + (int64_t)(n0 + (t >> 3)) * p.Kpad + k0 + ((c8 ^ rsw) << 3);
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            if (BN * 8 % 256 == 0 || t + 256 * i < BN * 8) glds16(wrow + (int64_t)(32 * i) * p.Kpad, b + i * 32 * 128);
+        }
+    };
+    // ---- generic: register staged
     auto load_tile = [&](int kt) {
         const int k = kt * BK + c8 * 8;
         const bool kvalid = k < p.K;
@@ -67,9 +114,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const vv_conv_params p, 
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             int yv = ryb[i] + ky, xv = rxb[i] + kx;
-            bool ok = kvalid && rv[i] && yv >= 0 && yv < p.Hv && xv >= 0 && xv < p.Wv;
+            const bool ok = kvalid && rv[i] && yv >= 0 && yv < p.Hv && xv >= 0 && xv < p.Wv;
             if (resize) { yv = (yv * p.Hin) / p.Hv; xv = (xv * p.Win) / p.Wv; }
-            const int64_t pix = ((int64_t)rf[i] * p.Hin + yv) * p.Win + xv;
+            const int64_t pix = ((int64_t)rpix[i] * p.Hin + yv) * p.Win + xv;
             const int64_t off = pix * Cs + cc;
             if (AF32) {
                 const float4* g = (const float4*)(src + off * 4);
@@ -88,9 +135,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const vv_conv_params p, 
             }
         }
     };
-    auto store_tile = [&](int buf) {
-        unsigned char* a = sA + buf * BM * 128;
-        unsigned char* b = sB + buf * BN * 128;
+    auto store_tile = [&](unsigned char* a, unsigned char* b) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int row = (t >> 3) + 32 * i;
@@ -119,15 +164,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const vv_conv_params p, 
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.Kpad / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
     const int lr = lane & 15, lq = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const unsigned char* a = sA + cur * BM * 128 + (wr * MT * 16) * 128;
-        const unsigned char* b = sB + cur * BN * 128 + (wc * NT * 16) * 128;
+    // one k tile: prefetch the next tile into (nA,nB), run the MFMAs on (cA,cB), then barrier
+    auto k_step = [&](int kt, const unsigned char* cA, const unsigned char* cB, unsigned char* nA, unsigned char* nB) {
+        const bool more = kt + 1 < nk;
+        if (more) { if (FAST) dma_tile(kt + 1, nA, nB); else load_tile(kt + 1); }
+        const unsigned char* a = cA + (wr * MT * 16) * 128;
+        const unsigned char* b = cB + (wc * NT * 16) * 128;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             uint4 af[MT], bf[NT];
@@ -142,81 +185,116 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const vv_conv_params p, 
                 const int row = j * 16 + lr;
                 bf[j] = *(const uint4*)(b + row * 128 + ((ch ^ (row & 7)) << 4));
             }
+            // swapped operands: D[n-in-tile][m-in-tile] -> lane (lr,lq) owns row m = ..+lr, channels n = ..+4*lq+{0..3}
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = T::mfma(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < NT; ++j) acc[i][j] = T::mfma(bf[j], af[i], acc[i][j]);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
-        __syncthreads();
+        if (!FAST && more) store_tile(nA, nB);
+        __syncthreads();     // with LDS-DMA in flight hipcc drains vmcnt(0) here: the prefetch overlapped the MFMAs
+    };
+
+    if (FAST) dma_tile(0, sA0, sB0);
+    else { load_tile(0); store_tile(sA0, sB0); }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        k_step(kt, sA0, sB0, sA1, sB1);
+        if (kt + 1 < nk) k_step(kt + 1, sA1, sB1, sA0, sB0);
     }
 
-    // ---- epilogue: C/D layout of mfma 16x16: col = lane&15, row = (lane>>4)*4 + reg
+    // ---- epilogue: lane owns out[m][n .. n+3]
     const bool geglu = p.epilogue == VV_EPI_GEGLU;
     const int N = p.N;
+    const bool vec = (N & 3) == 0 && (p.ldo & 3) == 0;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wr * MT * 16 + i * 16 + lr;
+        if (m >= M) continue;
+        const float* rowv = p.rowvec ? p.rowvec + (int64_t)(m / HWo) * N : nullptr;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wr * MT * 16 + i * 16 + lq * 4 + r;
-            if (m >= M) continue;
-            const float* rowv = p.rowvec ? p.rowvec + (int64_t)(m / HWo) * N : nullptr;
+        for (int j = 0; j < NT; ++j) {
+            const int nt0 = n0 + wc * NT * 16 + j * 16;       // first channel of this 16-wide tile
+            const int n = nt0 + 4 * lq;
+            if (geglu) {
+                if (NT % 2 == 0 && (j & 1) == 0 && n < N) {
+                    float o[4];
+                    const f32x4 gacc = acc[i][j + (NT % 2 == 0 ? 1 : 0)];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = n0 + wc * NT * 16 + j * 16 + lr;
-                if (geglu) {
-                    if (NT % 2 == 0 && (j & 1) == 0 && n < N) {
-                        const float val = acc[i][j][r] + (p.bias ? p.bias[n] : 0.f);
-                        const float gate = acc[i][j + (NT % 2 == 0 ? 1 : 0)][r] + (p.bias ? p.bias[n + 16] : 0.f);
-                        const float o = val * gelu_f(gate);
-                        const int64_t oc = (int64_t)m * p.ldo + ((n0 + wc * NT * 16 + j * 16) >> 1) + lr;
-                        if (p.out_dtype == VV_F32) ((float*)p.out)[oc] = o;
-                        else ((unsigned short*)p.out)[oc] = T::from_f32(o);
+                    for (int r = 0; r < 4; ++r) {
+                        const float val = acc[i][j][r] + (p.bias ? p.bias[n + r] : 0.f);
+                        const float gate = gacc[r] + (p.bias ? p.bias[n + 16 + r] : 0.f);
+                        o[r] = val * gelu_f(gate);
                     }
-                    continue;
+                    const int64_t oc = (int64_t)m * p.ldo + (nt0 >> 1) + 4 * lq;
+                    if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + oc) = make_float4(o[0], o[1], o[2], o[3]);
+                    else *(uint2*)((unsigned short*)p.out + oc) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
                 }
-                if (n >= N) continue;
-                float v = acc[i][j][r];
-                if (p.bias) v += p.bias[n];
-                v *= p.out_scale;
-                if (rowv) v += rowv[n];
-                const int64_t ri = (int64_t)m * N + n;
-                if (p.res0) v += (p.res_dtype == VV_F32) ? ((const float*)p.res0)[ri] : T::to_f32(((const unsigned short*)p.res0)[ri]);
-                if (p.res1) v += (p.res_dtype == VV_F32) ? ((const float*)p.res1)[ri] : T::to_f32(((const unsigned short*)p.res1)[ri]);
-                const int64_t oc = (int64_t)m * p.ldo + n;
-                if (p.out_dtype == VV_F32) ((float*)p.out)[oc] = v;
-                else ((unsigned short*)p.out)[oc] = T::from_f32(v);
+                continue;
+            }
+            if (n >= N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            const int64_t ri = (int64_t)m * N + n;
+            const int64_t oc = (int64_t)m * p.ldo + n;
+            if (vec) {
+                if (p.bias) { const float4 b4 = *(const float4*)(p.bias + n); v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= p.out_scale;
+                if (rowv) { const float4 t4 = *(const float4*)(rowv + n); v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w; }
+                if (p.res0) {
+                    if (p.res_dtype == VV_F32) { const float4 r4 = *(const float4*)((const float*)p.res0 + ri); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+                    else { const uint2 r2 = *(const uint2*)((const unsigned short*)p.res0 + ri); v[0] += T::to_f32(r2.x & 0xffff); v[1] += T::to_f32(r2.x >> 16); v[2] += T::to_f32(r2.y & 0xffff); v[3] += T::to_f32(r2.y >> 16); }
+                }
+                if (p.res1) {
+                    if (p.res_dtype == VV_F32) { const float4 r4 = *(const float4*)((const float*)p.res1 + ri); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+                    else { const uint2 r2 = *(const uint2*)((const unsigned short*)p.res1 + ri); v[0] += T::to_f32(r2.x & 0xffff); v[1] += T::to_f32(r2.x >> 16); v[2] += T::to_f32(r2.y & 0xffff); v[3] += T::to_f32(r2.y >> 16); }
+                }
+                if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + oc) = make_float4(v[0], v[1], v[2], v[3]);
+                else *(uint2*)((unsigned short*)p.out + oc) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r >= N) continue;
+                    float x = v[r];
+                    if (p.bias) x += p.bias[n + r];
+                    x *= p.out_scale;
+                    if (rowv) x += rowv[n + r];
+                    if (p.res0) x += (p.res_dtype == VV_F32) ? ((const float*)p.res0)[ri + r] : T::to_f32(((const unsigned short*)p.res0)[ri + r]);
+                    if (p.res1) x += (p.res_dtype == VV_F32) ? ((const float*)p.res1)[ri + r] : T::to_f32(((const unsigned short*)p.res1)[ri + r]);
+                    if (p.out_dtype == VV_F32) ((float*)p.out)[oc + r] = x;
+                    else ((unsigned short*)p.out)[oc + r] = T::from_f32(x);
+                }
             }
         }
     }
 }
 
-template <typename T, int WR, int WC, int MT, int NT, bool AF32>
+template <typename T, int WR, int WC, int MT, int NT, int MODE>
 int launch_cfg(const vv_conv_params& p, int M, hipStream_t st) {
     constexpr int BM = WR * MT * 16, BN = WC * NT * 16;
     if (p.Npad % BN != 0) VV_FAIL(VV_E_ARG, "vv_conv_gemm: Npad %d not a multiple of tile N %d", p.Npad, BN);
     const int tilesM = (M + BM - 1) / BM, tilesN = p.Npad / BN;
-    const size_t lds = 2 * (BM + BN) * 128;
-    auto kern = conv_gemm_kernel<T, WR, WC, MT, NT, AF32>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            VV_FAIL(VV_E_LAUNCH, "vv_conv_gemm: cannot set dynamic LDS size %zu", lds);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(256), lds, st, p, M, tilesM, tilesN);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     VV_CHECK_LAUNCH("vv_conv_gemm");
     return VV_OK;
 }
 
-template <typename T, bool AF32>
+template <typename T, int MODE>
 int launch_t(const vv_conv_params& p, int M, hipStream_t st) {
     // tile choice: GEGLU needs an even number of N tiles per wave; N % 160 == 0 -> 128x160; tiny N -> 128x16
-    if (p.epilogue == VV_EPI_GEGLU) return launch_cfg<T, 2, 2, 4, 4, AF32>(p, M, st);
-    if (p.Npad % 160 == 0) return launch_cfg<T, 2, 2, 4, 5, AF32>(p, M, st);
-    if (p.Npad % 128 == 0) return launch_cfg<T, 2, 2, 4, 4, AF32>(p, M, st);
-    if (p.Npad % 16 == 0 && p.Npad <= 64) return launch_cfg<T, 4, 1, 2, 1, AF32>(p, M, st);
+    if (p.epilogue == VV_EPI_GEGLU) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, M, st);
+    if (p.Npad % 160 == 0) return launch_cfg<T, 2, 2, 4, 5, MODE>(p, M, st);
+    if (p.Npad % 128 == 0) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, M, st);
+    if (p.Npad % 16 == 0 && p.Npad <= 64) return launch_cfg<T, 4, 1, 2, 1, MODE>(p, M, st);
     VV_FAIL(VV_E_ARG, "vv_conv_gemm: unsupported Npad %d (need %%160, %%128 or 16..64 %%16)", p.Npad);
+}
+
+template <typename T>
+int launch_mode(const vv_conv_params& p, int M, hipStream_t st) {
+    if (p.in_dtype == VV_F32) return launch_t<T, MODE_F32>(p, M, st);
+    const bool no_resize = p.Hv == p.Hin && p.Wv == p.Win;
+    const bool fast = no_resize && (p.C0 % 64 == 0) && (p.C1 % 64 == 0) && p.Kpad == p.K && (int64_t)p.F * p.Hin * p.Win < 0x7fffffff;
+    return fast ? launch_t<T, MODE_FAST>(p, M, st) : launch_t<T, MODE_H16>(p, M, st);
 }
 
 }  // namespace
@@ -234,13 +312,11 @@ extern "C" int vv_conv_gemm(const vv_conv_params* pp, int dtype, void* stream) {
     if (p.in_dtype != VV_F32 && p.in_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_conv_gemm: in_dtype mismatch");
     if (p.out_dtype != VV_F32 && p.out_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_conv_gemm: out_dtype mismatch");
     if ((p.res0 || p.res1) && p.res_dtype != VV_F32 && p.res_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_conv_gemm: res_dtype mismatch");
-    if (p.epilogue == VV_EPI_GEGLU && (p.N % 32 || p.rowvec || p.res0 || p.res1)) VV_FAIL(VV_E_ARG, "vv_conv_gemm: GEGLU needs N%%32==0 and no residual/rowvec");
+    if (p.epilogue == VV_EPI_GEGLU && (p.N % 32 || p.rowvec || p.res0 || p.res1 || (p.ldo & 3))) VV_FAIL(VV_E_ARG, "vv_conv_gemm: GEGLU needs N%%32==0, ldo%%4==0 and no residual/rowvec");
     if (p.F <= 0 || p.Hout <= 0 || p.Wout <= 0 || p.Hin <= 0 || p.Win <= 0 || p.Hv <= 0 || p.Wv <= 0) VV_FAIL(VV_E_ARG, "vv_conv_gemm: bad geometry");
     const int64_t M64 = (int64_t)p.F * p.Hout * p.Wout;
     if (M64 > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_conv_gemm: M too large");
     const int M = (int)M64;
     hipStream_t st = (hipStream_t)stream;
-    const bool af32 = p.in_dtype == VV_F32;
-    if (dtype == VV_BF16) return af32 ? launch_t<BF16, true>(p, M, st) : launch_t<BF16, false>(p, M, st);
-    return af32 ? launch_t<F16, true>(p, M, st) : launch_t<F16, false>(p, M, st);
+    return dtype == VV_BF16 ? launch_mode<BF16>(p, M, st) : launch_mode<F16>(p, M, st);
 }
