@@ -45,25 +45,25 @@ def synth_clip(T, H, W, seed=1234, t0=0):
     return frames, masks, prior
 
 
-def cpu_baseline(H, W, steps, chunk, overlap):
-    """The oracle (kind "port": fp32 torch restatement) timed on the host cores on a bounded sample of the same workload:
-    one BrushNet+UNet denoise step on ONE 720p frame, plus one VAE encode + decode of one frame at quarter area (x4),
-    extrapolated linearly to 50 steps / 2 encodes / 1 decode per frame."""
+def cpu_baseline(H, W, steps, chunk, overlap, sample_hw=(192, 256), vae_hw=(96, 128)):
+    """The oracle (kind "port": fp32 torch restatement) timed on the host cores on a BOUNDED sample of the same workload:
+    one BrushNet+UNet denoise step on one frame at 256x192 and one VAE encode+decode at 128x96 (full-width architecture,
+    same weights), converted to CPU TFLOP/s with the algorithmic FLOP model and then to frames/s of the 720p/50-step job."""
     from oracle import model_ref as M
+    from videovanish_amd import flops
     from videovanish_amd.config import UNetConfig, VAEConfig
     ucfg, vcfg = UNetConfig(), VAEConfig()
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    cores = torch.get_num_threads()
     P = M.Params(0)
-    h, w = H // 8, W // 8
+    sh, sw = sample_hw
+    h, w = sh // 8, sw // 8
     g = torch.Generator().manual_seed(0)
     lat = torch.randn(1, 4, h, w, generator=g)
     x9 = torch.cat([lat, lat, torch.ones(1, 1, h, w)], 1)
     text = M.text_states(P, ucfg)
-    hs, ws = (H // 2) // 8 * 8, (W // 2) // 8 * 8
-    img = torch.rand(1, 3, hs, ws, generator=g) * 2 - 1
+    img = torch.rand(1, 3, vae_hw[0], vae_hw[1], generator=g) * 2 - 1
     with torch.no_grad():
-        # materialise weights outside the timed sample (tiny input touches every layer)
+        # materialise the weights outside the timed sample (a tiny input touches every layer)
         small = torch.randn(1, 4, 8, 8, generator=g)
         M.unet_forward(P, small, 500, text, ucfg, M.brushnet_forward(P, torch.cat([small, small, torch.ones(1, 1, 8, 8)], 1), 500, text, ucfg))
         z0 = M.vae_encode(P, torch.zeros(1, 3, 16, 16), vcfg); M.vae_decode(P, z0, vcfg)
@@ -72,15 +72,16 @@ def cpu_baseline(H, W, steps, chunk, overlap):
         t_step = time.time() - t0
         t0 = time.time()
         z = M.vae_encode(P, img, vcfg)
-        t_enc = (time.time() - t0) * (H * W) / float(hs * ws)
-        t0 = time.time()
         M.vae_decode(P, z, vcfg)
-        t_dec = (time.time() - t0) * (H * W) / float(hs * ws)
-    per_frame = steps * t_step + 2 * t_enc + t_dec
-    inflation = chunk / float(chunk - overlap)
-    return {"value": 1.0 / (per_frame * inflation), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 frame x 1 denoise step at {W}x{H} ({t_step:.1f}s) + VAE enc/dec of 1 frame at {ws}x{hs} scaled x{H * W / float(hs * ws):.1f} "
-                      f"({t_enc:.1f}s/{t_dec:.1f}s); extrapolated to {steps} steps, 2 enc + 1 dec per frame, x{inflation:.2f} chunk overlap"}
+        t_vae = time.time() - t0
+    enc, dec = flops.vae_per_frame(vae_hw[0], vae_hw[1], vcfg)
+    fl = flops.denoise_step_per_frame(h, w, 1, ucfg) + enc + dec
+    tfs = fl / (t_step + t_vae) / 1e12
+    per_frame = flops.per_output_frame(H, W, chunk, steps, ucfg, vcfg) * chunk / float(chunk - overlap)
+    return {"value": tfs * 1e12 / per_frame, "unit": "frames/s", "cores": cores, "kind": "port", "cpu_tflops": round(tfs, 4),
+            "sample": f"1 frame: one denoise step at {sw}x{sh} ({t_step:.1f}s) + VAE encode+decode at {vae_hw[1]}x{vae_hw[0]} ({t_vae:.1f}s), "
+                      f"{fl / 1e12:.2f} TFLOP; scaled by the algorithmic FLOP model to {steps} steps + 2 enc + 1 dec per {W}x{H} frame, "
+                      f"x{chunk / float(chunk - overlap):.2f} chunk overlap"}
 
 
 def main():
@@ -196,6 +197,8 @@ def main():
                    "frames_per_step": args.chunk, "credited_frames_per_step": stride, "chunks_per_rank": args.steps,
                    "parallelism": f"chunk-dp{world}", "model_build_s": round(t_build, 1)},
         "roofline": roof, "cpu_baseline": cpu,
+        "job_tflops": round(__import__("videovanish_amd.flops", fromlist=["x"]).per_output_frame(H, W, args.chunk, args.denoise_steps, ucfg, vcfg)
+                            * args.chunk * args.steps * world / dt / 1e12, 1),
         "kernel_times_s": {k: [v[0], round(v[1], 3), round(v[2] / v[1] / 1e12, 1) if v[2] else round(v[3] / v[1] / 1e9, 1)] for k, v in
                            sorted(kernels.items(), key=lambda kv: -kv[1][1])},
     }

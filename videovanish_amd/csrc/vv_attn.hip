@@ -6,7 +6,12 @@
 // exchanges, and the accumulator registers of S^T are -- after exp2 and packing -- directly the B operand of
 // O^T = V^T P^T.  V^T operands come from the row-major V tile through ds_read_b64_tr_b16 (hardware transpose).
 // Head dims that are not MFMA multiples are zero-padded in LDS only (K-dim to 32, V-dim to 16).
+#include <stdlib.h>
+#include <type_traits>
 #include "vv_common.h"
+#ifndef VV_ATTN_PART
+#define VV_ATTN_PART 0
+#endif
 
 namespace {
 
@@ -31,9 +36,18 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const vv_attn_params p, c
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    int bid = blockIdx.x;
-    const int qt = bid % nqt; bid /= nqt;
-    const int h = bid % p.heads; const int b = bid / p.heads;
+    // XCD-aware decode: blocks i and i+8 share an XCD (and its L2).  Give every XCD its own (batch, head) pairs and walk
+    // that pair's query tiles on it, so the pair's K/V (re-read by every query tile) stays resident in ONE 4 MiB L2.
+    int qt, h, b;
+    {
+        const int nbh = p.B * p.heads;
+        const int full = (nbh / 8) * 8;                       // pairs handled in XCD-striped rounds of 8
+        const int bid = blockIdx.x;
+        int bh;
+        if (bid < full * nqt) { const int xcd = bid & 7, idx = bid >> 3; bh = (idx / nqt) * 8 + xcd; qt = idx % nqt; }
+        else { const int r = bid - full * nqt; bh = full + r / nqt; qt = r % nqt; }
+        h = bh % p.heads; b = bh / p.heads;
+    }
 
     const unsigned short* Q = (const unsigned short*)p.q + (int64_t)b * p.q_bs + (int64_t)h * D;
     const unsigned short* Kp = (const unsigned short*)p.k + (int64_t)b * p.k_bs + (int64_t)h * D;
@@ -97,7 +111,9 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const vv_attn_params p, c
     load_kv(0);
     store_kv();
     __syncthreads();
-    for (int it = 0; it < ntiles; ++it) {
+    // one KV tile; MASK is a compile-time flag so that only the LAST (ragged) tile pays for the key mask
+    auto tile_step = [&](const int it, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
         const int kv0 = it * KVT;
         if (PREFETCH && it + 1 < ntiles) load_kv(kv0 + KVT);
 
@@ -116,8 +132,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const vv_attn_params p, c
                 for (int j = 0; j < QT; ++j) sacc[kt][j] = T::mfma(kf, qf[j][s], sacc[kt][j]);
             }
         }
-        // ---- mask keys beyond Nkv (last tile only)
-        if (kv0 + KVT > p.Nkv) {
+        if (MASK) {
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -136,10 +151,10 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const vv_attn_params p, c
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kt][j][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), (16 << 10) | 0x1f)));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mnew = fmaxf(mrun[j], mx);
-            const float alpha = exp2f((mrun[j] - mnew) * c);
+            const float alpha = __builtin_amdgcn_exp2f((mrun[j] - mnew) * c);
             mrun[j] = mnew;
             const float mc = mnew * c;
             float ps = 0.f;
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const vv_attn_params p, c
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f(sacc[kt][j][r] * c - mc);
+                    const float e = __builtin_amdgcn_exp2f(sacc[kt][j][r] * c - mc);
                     sacc[kt][j][r] = e;
                     ps += e;
                 }
@@ -178,7 +193,11 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const vv_attn_params p, c
             store_kv();
             __syncthreads();
         }
-    }
+    };
+    const bool ragged = (p.Nkv % KVT) != 0;
+    const int nfull = ragged ? ntiles - 1 : ntiles;
+    for (int it = 0; it < nfull; ++it) tile_step(it, std::false_type{});
+    if (ragged) tile_step(ntiles - 1, std::true_type{});
     // ---- finalize: O[q][d] = O^T[d][q] / l
 #pragma unroll
     for (int j = 0; j < QT; ++j) {
@@ -228,6 +247,11 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
     } else {
         // short sequences (temporal attention over <=32 frames, tiny test shapes): one wave per block, 32-key tiles
         if (p.Nq <= 32 && p.Nkv <= 32) return attn_launch<T, D, 2, 32, 1, true>(p, st);
+        if constexpr (D <= 80) {
+            static int qt4 = -1;
+            if (qt4 < 0) { const char* e = getenv("VV_ATTN_QT4"); qt4 = e ? atoi(e) : 0; }
+            if (qt4 && p.Nq >= 1024) return attn_launch<T, D, 4, 64, 4, true>(p, st);
+        }
         return attn_launch<T, D, 2, 64, 4, true>(p, st);
     }
 }
@@ -235,17 +259,23 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
 template <typename T>
 int attn_by_d(const vv_attn_params& p, hipStream_t st) {
     switch (p.D) {
+#if VV_ATTN_PART == 0      // small head dims: built with -mllvm -amdgpu-mfma-vgpr-form (accumulators in arch VGPRs)
         case 32: return attn_dispatch<T, 32>(p, st);
         case 40: return attn_dispatch<T, 40>(p, st);
         case 64: return attn_dispatch<T, 64>(p, st);
         case 80: return attn_dispatch<T, 80>(p, st);
+#else                      // large head dims need the AGPR half of the register file for O^T
         case 160: return attn_dispatch<T, 160>(p, st);
         case 512: return attn_dispatch<T, 512>(p, st);
+#endif
         default: VV_FAIL(VV_E_UNSUPPORTED, "vv_attention: head dim %d not built (32,40,64,80,160,512)", p.D);
     }
 }
 
 }  // namespace
+
+#if VV_ATTN_PART == 0
+extern "C" int vv_attention_large_d(const vv_attn_params* pp, int dtype, void* stream);
 
 extern "C" int vv_attention(const vv_attn_params* pp, int dtype, void* stream) {
     if (!pp) VV_FAIL(VV_E_ARG, "vv_attention: null params");
@@ -254,7 +284,13 @@ extern "C" int vv_attention(const vv_attn_params* pp, int dtype, void* stream) {
     if (p.B <= 0 || p.heads <= 0 || p.Nq <= 0 || p.Nkv <= 0) VV_FAIL(VV_E_ARG, "vv_attention: empty problem");
     if ((p.q_rs | p.k_rs | p.v_rs | p.o_rs | p.q_bs | p.k_bs | p.v_bs | p.o_bs) & 3) VV_FAIL(VV_E_ARG, "vv_attention: strides must be multiples of 4 elements (q/k/v: 8)");
     if ((p.q_rs | p.k_rs | p.v_rs | p.q_bs | p.k_bs | p.v_bs) & 7) VV_FAIL(VV_E_ARG, "vv_attention: q/k/v strides must be multiples of 8 elements");
-    if (dtype == VV_BF16) return attn_by_d<BF16>(p, (hipStream_t)stream);
-    if (dtype == VV_F16) return attn_by_d<F16>(p, (hipStream_t)stream);
-    VV_FAIL(VV_E_ARG, "vv_attention: bad dtype");
+    if (dtype != VV_BF16 && dtype != VV_F16) VV_FAIL(VV_E_ARG, "vv_attention: bad dtype");
+    if (p.D > 80) return vv_attention_large_d(pp, dtype, stream);
+    return dtype == VV_BF16 ? attn_by_d<BF16>(p, (hipStream_t)stream) : attn_by_d<F16>(p, (hipStream_t)stream);
 }
+#else
+extern "C" int vv_attention_large_d(const vv_attn_params* pp, int dtype, void* stream) {
+    const vv_attn_params& p = *pp;
+    return dtype == VV_BF16 ? attn_by_d<BF16>(p, (hipStream_t)stream) : attn_by_d<F16>(p, (hipStream_t)stream);
+}
+#endif

@@ -27,8 +27,18 @@ struct F16 {
     }
 };
 
-template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi) {
-    return (unsigned)T::from_f32(lo) | ((unsigned)T::from_f32(hi) << 16);
+// two fp32 -> one dword of two h16 (round to nearest even).  A vector fptrunc lowers to ONE v_cvt_pk_{bf16,f16}_f32 on
+// gfx950 and -- unlike inline asm -- stays visible to the compiler's hazard recognizer (an asm-written VGPR consumed by
+// the next MFMA missed its wait states: NaNs in one fp16 instantiation).
+typedef float vv_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 vv_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 vv_f16x2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi);
+template <> __device__ __forceinline__ unsigned pack2<BF16>(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((vv_f32x2){lo, hi}, vv_bf16x2));
+}
+template <> __device__ __forceinline__ unsigned pack2<F16>(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((vv_f32x2){lo, hi}, vv_f16x2));
 }
 template <typename T> __device__ __forceinline__ uint4 pack8(const float* v) {
     return make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));

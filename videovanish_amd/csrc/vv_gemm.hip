@@ -5,13 +5,16 @@
 // B (weight, [N][K] K-contiguous) tiles; MFMA operands are read with ds_read_b128.
 //   FAST path (h16 activations, channel counts multiples of 64): both tiles are filled by LDS-DMA
 //     (global_load_lds_dwordx4, per-lane source address = the im2col gather, swizzle applied on the SOURCE address,
-//     out-of-image taps read a zero page), one tile ahead of the MFMAs, no staging VGPRs, no ds_write.  The two
-//     buffers are DISTINCT __shared__ arrays and the k loop is unrolled by two, so the compiler can prove that the
-//     ds_reads of one buffer do not alias the DMA in flight into the other (otherwise it drains vmcnt(0) first).
+//     out-of-image taps read a zero page), no staging VGPRs, no ds_write.  Two variants were measured A/B in one
+//     process (VV_GEMM_SPLIT): SPLIT=1 keeps the two buffers in DISTINCT __shared__ arrays with the k loop unrolled by
+//     two, so hipcc lets the DMA of tile k+1 fly during the MFMAs of tile k; SPLIT=0 (one array, hipcc drains vmcnt(0)
+//     before the ds_reads, two co-resident blocks per CU alternate load/compute) is 1.3-1.4x FASTER on the 128x160 tile
+//     (profiles/r1_gemm_ab.txt) and is the default.
 //   generic / fp32-activation paths: register staged (issue-early, convert, write-late).
 // The MFMA is issued with swapped operands (D = W_tile * A_tile^T) so every lane owns 4 CONSECUTIVE output channels
 // of one output row: the epilogue (bias, time-embedding vector, residuals, GEGLU, cast) is 16-byte vectorised.
 // The block index is remapped so that the column tiles of one row panel run on the same XCD (shared L2).
+#include <stdlib.h>
 #include "vv_common.h"
 
 namespace {
@@ -27,16 +30,17 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gp_t)gptr, (lp_t)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int WR, int WC, int MT, int NT, int MODE>
+template <typename T, int WR, int WC, int MT, int NT, int MODE, bool SPLIT>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const vv_conv_params p, const int M, const int tilesM, const int tilesN) {
     constexpr int BM = WR * MT * 16, BN = WC * NT * 16;
     constexpr int AR = BM / 32;                 // A rows staged per thread
     constexpr int BCH = (BN * 8 + 255) / 256;   // B chunks staged per thread
     constexpr bool AF32 = MODE == MODE_F32, FAST = MODE == MODE_FAST;
     __shared__ __attribute__((aligned(16))) unsigned char sA0[BM * 128];
-    __shared__ __attribute__((aligned(16))) unsigned char sA1[BM * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char sA1[SPLIT ? BM * 128 : 16];
     __shared__ __attribute__((aligned(16))) unsigned char sB0[BN * 128];
-    __shared__ __attribute__((aligned(16))) unsigned char sB1[BN * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char sB1[SPLIT ? BN * 128 : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char sAB[SPLIT ? 16 : 2 * (BM + BN) * 128];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave / WC, wc = wave % WC;
@@ -195,12 +199,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const vv_conv_params p, 
         __syncthreads();     // with LDS-DMA in flight hipcc drains vmcnt(0) here: the prefetch overlapped the MFMAs
     };
 
-    if (FAST) dma_tile(0, sA0, sB0);
-    else { load_tile(0); store_tile(sA0, sB0); }
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        k_step(kt, sA0, sB0, sA1, sB1);
-        if (kt + 1 < nk) k_step(kt + 1, sA1, sB1, sA0, sB0);
+    if (SPLIT) {
+        if (FAST) dma_tile(0, sA0, sB0);
+        else { load_tile(0); store_tile(sA0, sB0); }
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            k_step(kt, sA0, sB0, sA1, sB1);
+            if (kt + 1 < nk) k_step(kt + 1, sA1, sB1, sA0, sB0);
+        }
+    } else {
+        unsigned char* a2 = sAB; unsigned char* b2 = sAB + 2 * BM * 128;
+        if (FAST) dma_tile(0, a2, b2);
+        else { load_tile(0); store_tile(a2, b2); }
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            k_step(kt, a2 + cur * BM * 128, b2 + cur * BN * 128, a2 + (cur ^ 1) * BM * 128, b2 + (cur ^ 1) * BN * 128);
+        }
     }
 
     // ---- epilogue: lane owns out[m][n .. n+3]
@@ -274,7 +289,10 @@ int launch_cfg(const vv_conv_params& p, int M, hipStream_t st) {
     constexpr int BM = WR * MT * 16, BN = WC * NT * 16;
     if (p.Npad % BN != 0) VV_FAIL(VV_E_ARG, "vv_conv_gemm: Npad %d not a multiple of tile N %d", p.Npad, BN);
     const int tilesM = (M + BM - 1) / BM, tilesN = p.Npad / BN;
-    hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
+    static int split = -1;
+    if (split < 0) { const char* e = getenv("VV_GEMM_SPLIT"); split = e ? atoi(e) : 0; }
+    if (split) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, true>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, false>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     VV_CHECK_LAUNCH("vv_conv_gemm");
     return VV_OK;
 }

@@ -77,28 +77,32 @@ __global__ void gn_stats_kernel(const vv_groupnorm_params p, const GNGeom g) {
     for (int i = t; i < 2 * p.groups; i += blockDim.x) ws[i] = sh[i];
 }
 
-// one block per frame (or one block when statistics pool over the clip): partials -> mean / rstd
-__global__ void gn_finalize_kernel(const vv_groupnorm_params p, const GNGeom g) {
-    const int grp = threadIdx.x;
-    if (grp >= p.groups) return;
+// one block per frame (or one block when statistics pool over the clip): partials -> mean / rstd.
+// 256 threads: thread (grp, lane8) sums a strided share of the partials in double, then an 8-lane shuffle reduce.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const vv_groupnorm_params p, const GNGeom g) {
     const int C = p.C0 + p.C1, cpg = C / p.groups;
     const int f0 = p.pool_frames ? 0 : blockIdx.x, f1 = p.pool_frames ? p.F : blockIdx.x + 1;
-    double s = 0.0, q = 0.0;
-    for (int f = f0; f < f1; ++f)
-        for (int sp = 0; sp < g.nsplit; ++sp) {
-            const float* ws = p.stats_ws + (((int64_t)f * g.nsplit + sp) * p.groups + grp) * 2;
+    const int sub = threadIdx.x & 7;
+    float* fin = p.stats_ws + (int64_t)p.F * g.nsplit * p.groups * 2;
+    for (int grp = threadIdx.x >> 3; grp < p.groups; grp += 32) {
+        double s = 0.0, q = 0.0;
+        const int nparts = (f1 - f0) * g.nsplit;
+        for (int i = sub; i < nparts; i += 8) {
+            const float* ws = p.stats_ws + (((int64_t)f0 * g.nsplit + i) * p.groups + grp) * 2;
             s += ws[0]; q += ws[1];
         }
-    const double n = (double)(f1 - f0) * p.HW * cpg;
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    float* fin = p.stats_ws + (int64_t)p.F * g.nsplit * p.groups * 2;
-    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-    if (p.pool_frames) {
-        for (int f = 0; f < p.F; ++f) { fin[((int64_t)f * p.groups + grp) * 2] = (float)mean; fin[((int64_t)f * p.groups + grp) * 2 + 1] = rstd; }
-    } else {
-        fin[((int64_t)blockIdx.x * p.groups + grp) * 2] = (float)mean; fin[((int64_t)blockIdx.x * p.groups + grp) * 2 + 1] = rstd;
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+        const double n = (double)(f1 - f0) * p.HW * cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        if (p.pool_frames) {
+            for (int f = sub; f < p.F; f += 8) { fin[((int64_t)f * p.groups + grp) * 2] = (float)mean; fin[((int64_t)f * p.groups + grp) * 2 + 1] = rstd; }
+        } else if (sub == 0) {
+            fin[((int64_t)blockIdx.x * p.groups + grp) * 2] = (float)mean; fin[((int64_t)blockIdx.x * p.groups + grp) * 2 + 1] = rstd;
+        }
     }
 }
 
@@ -189,7 +193,7 @@ int gn_launch(const vv_groupnorm_params& p, hipStream_t st) {
     const GNGeom g = gn_geom(p.HW, C);
     const int threads = (g.threads + 63) / 64 * 64;
     hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.pool_frames ? 1 : p.F), dim3(64), 0, st, p, g);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.pool_frames ? 1 : p.F), dim3(256), 0, st, p, g);
     hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
     VV_CHECK_LAUNCH("vv_groupnorm");
     return VV_OK;

@@ -190,7 +190,8 @@ class FeedForward:
         self.out = Linear(ctx, name + ".net.2", 4 * C, C)
 
     def __call__(self, n, res):
-        return self.out(self.proj(n, out_dtype=self.ctx.h16), res0=res)
+        # the FF result is consumed only as the A operand of proj_out (which rounds it to h16 anyway): store it as h16
+        return self.out(self.proj(n, out_dtype=self.ctx.h16), res0=res, out_dtype=self.ctx.h16)
 
 
 class SpatialTransformer:
