@@ -181,8 +181,13 @@ def main():
         mfma = fl > 0
         ach = (fl / tsec / 1e12) if mfma else (by / tsec / 1e9)
         peak = MFMA_PEAK_TFLOPS if mfma else HBM_PEAK_GBS
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (profiles/traffic_table.json; rocprofv3 --pmc)
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic_table.json"))).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
         roof = {"kernel": dom, "bound": "mfma" if mfma else "hbm", "achieved": round(ach, 2), "peak": peak,
-                "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "traffic": None, "launches": n,
+                "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "traffic": traffic, "launches": n,
                 "avg_launch_ms": round(tsec / n * 1e3, 4), "algorithmic_per_launch": (fl if mfma else by) / n,
                 "share_of_step_time": round(tsec / dt, 3)}
     cpu = None

@@ -98,6 +98,45 @@ def chunk_noise(seed, index, shape):
     return torch.randn(shape, generator=g, dtype=torch.float32)
 
 
+def exchange_and_blend(plan, wts, owner, chunk_rank, rank, world, pending, hw, dev, blend_fn=None):
+    """Blend-time step.  pending: {chunk index: decoded fp32 [F,H,W,3]} for THIS rank's chunks.  Every rank hands the
+    decoded frames that another rank owns to that rank (torch.distributed send/recv: RCCL over xGMI on GPUs, gloo in the
+    CPU tests), then each owner blends its frames in canonical chunk order.  Returns (acc [hi-lo,H,W,3] fp32, (lo, hi))
+    for the frames this rank owns.  blend_fn(dec, w, acc_view) defaults to the HIP kernel vv_decode_blend."""
+    H, W = hw
+    blend_fn = blend_fn or hip.decode_blend
+    contrib = {}       # chunk index -> (first frame, decoded [n,H,W,3] fp32) for frames this rank owns
+    for ci, dec in pending.items():
+        s, e = plan[ci]
+        idx = [fi for fi in range(s, e) if owner[fi] == rank]
+        if idx:
+            contrib[ci] = (idx[0], dec[idx[0] - s: idx[-1] + 1 - s])
+    if world > 1:
+        import torch.distributed as td
+        for ci, (s, e) in enumerate(plan):
+            src = chunk_rank[ci]
+            for dst in sorted(set(int(o) for o in owner[s:e]) - {src}):
+                idx = [fi for fi in range(s, e) if owner[fi] == dst]
+                if rank == src:
+                    td.send(pending[ci][idx[0] - s: idx[-1] + 1 - s].contiguous(), dst)
+                elif rank == dst:
+                    buf = torch.empty((len(idx), H, W, 3), dtype=torch.float32, device=dev)
+                    td.recv(buf, src)
+                    contrib[ci] = (idx[0], buf)
+    own_idx = np.nonzero(owner == rank)[0]
+    if not len(own_idx):
+        return None, (0, 0)
+    lo, hi = int(own_idx[0]), int(own_idx[-1]) + 1
+    accT = torch.zeros((hi - lo, H, W, 3), dtype=torch.float32, device=dev)
+    for ci in sorted(contrib):                       # canonical chunk order
+        s, _ = plan[ci]
+        a, dec = contrib[ci]
+        b = a + dec.shape[0]
+        w = torch.from_numpy(wts[ci][a - s: b - s]).to(dev)
+        blend_fn(dec.contiguous(), w, accT[a - lo: b - lo])
+    return accT, (lo, hi)
+
+
 # ---- the model ---------------------------------------------------------------------------------------------------
 class DiffuEraserHIP:
     def __init__(self, run: RunConfig = None, device="cuda:0"):
@@ -243,37 +282,9 @@ class DiffuEraserHIP:
                 cb = lambda i, n, k=k: progress(k * n + i, n_my * n)
             pending[ci] = self.denoise_chunk(fr[s - base:e - base], pr[s - base:e - base], mk[s - base:e - base], noise, steps=steps,
                                              scheduler=scheduler, progress=cb)
-        # ---- blend time: hand the decoded overlap frames to the owning rank (RCCL point-to-point), blend in chunk order
-        contrib = {}       # chunk index -> (first frame, decoded [n,H,W,3] fp32) for frames this rank owns
-        for ci, dec in pending.items():
-            s, e = plan[ci]
-            idx = [fi for fi in range(s, e) if owner[fi] == rank]
-            if idx:
-                contrib[ci] = (idx[0], dec[idx[0] - s: idx[-1] + 1 - s])
-        if world > 1:
-            import torch.distributed as td
-            for ci, (s, e) in enumerate(plan):
-                src = chunk_rank[ci]
-                for dst in sorted(set(int(o) for o in owner[s:e]) - {src}):
-                    idx = [fi for fi in range(s, e) if owner[fi] == dst]
-                    if rank == src:
-                        td.send(pending[ci][idx[0] - s: idx[-1] + 1 - s].contiguous(), dst)
-                    elif rank == dst:
-                        Hh, Ww = (H, W)
-                        buf = torch.empty((len(idx), Hh, Ww, 3), dtype=torch.float32, device=dev)
-                        td.recv(buf, src)
-                        contrib[ci] = (idx[0], buf)
-        own_idx = np.nonzero(owner == rank)[0]
-        if not len(own_idx):
+        accT, (lo, hi) = exchange_and_blend(plan, wts, owner, chunk_rank, rank, world, pending, (H, W), dev)
+        if accT is None:
             return None, (0, 0)
-        lo, hi = int(own_idx[0]), int(own_idx[-1]) + 1
-        accT = torch.zeros((hi - lo, H, W, 3), dtype=torch.float32, device=dev)
-        for ci in sorted(contrib):                       # canonical chunk order
-            s, _ = plan[ci]
-            a, dec = contrib[ci]
-            b = a + dec.shape[0]
-            w = torch.from_numpy(wts[ci][a - s: b - s]).to(dev)
-            hip.decode_blend(dec.contiguous(), w, accT[a - lo: b - lo])
         if return_float:
             return accT, (lo, hi)
         out = hip.blur_compose(accT, fr[lo - base: hi - base], mk[lo - base: hi - base], self.taps)
