@@ -5,11 +5,11 @@
 // B (weight, [N][K] K-contiguous) tiles; MFMA operands are read with ds_read_b128.
 //   FAST path (h16 activations, channel counts multiples of 64): both tiles are filled by LDS-DMA
 //     (global_load_lds_dwordx4, per-lane source address = the im2col gather, swizzle applied on the SOURCE address,
-//     out-of-image taps read a zero page), no staging VGPRs, no ds_write.  Two variants were measured A/B in one
-//     process (VV_GEMM_SPLIT): SPLIT=1 keeps the two buffers in DISTINCT __shared__ arrays with the k loop unrolled by
-//     two, so hipcc lets the DMA of tile k+1 fly during the MFMAs of tile k; SPLIT=0 (one array, hipcc drains vmcnt(0)
-//     before the ds_reads, two co-resident blocks per CU alternate load/compute) is 1.3-1.4x FASTER on the 128x160 tile
-//     (profiles/r1_gemm_ab.txt) and is the default.
+//     out-of-image taps read a zero page), no staging VGPRs, no ds_write.  Three buffering variants were measured A/B in
+//     one process (VV_GEMM_SPLIT, profiles/r1_gemm_ab.txt): 2 = SINGLE buffer (fill -> barrier -> MFMAs -> barrier; 36 KB
+//     of LDS, so 3-4 co-resident blocks per CU hide each other's fills) is the fastest and the default; 0 = one array
+//     double buffered (hipcc drains vmcnt(0) before the ds_reads); 1 = double buffered in DISTINCT __shared__ arrays with
+//     the k loop unrolled by two (the DMA of tile k+1 really flies during the MFMAs of tile k) -- the slowest of the three.
 //   generic / fp32-activation paths: register staged (issue-early, convert, write-late).
 // The MFMA is issued with swapped operands (D = W_tile * A_tile^T) so every lane owns 4 CONSECUTIVE output channels
 // of one output row: the epilogue (bias, time-embedding vector, residuals, GEGLU, cast) is 16-byte vectorised.
@@ -30,17 +30,17 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gp_t)gptr, (lp_t)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int WR, int WC, int MT, int NT, int MODE, bool SPLIT>
+template <typename T, int WR, int WC, int MT, int NT, int MODE, int SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params p, const int M, const int tilesM, const int tilesN) {
     constexpr int BM = WR * MT * 16, BN = WC * NT * 16;
     constexpr int AR = BM / 32;                 // A rows staged per thread
     constexpr int BCH = (BN * 8 + 255) / 256;   // B chunks staged per thread
     constexpr bool AF32 = MODE == MODE_F32, FAST = MODE == MODE_FAST;
-    __shared__ __attribute__((aligned(16))) unsigned char sA0[BM * 128];
-    __shared__ __attribute__((aligned(16))) unsigned char sA1[SPLIT ? BM * 128 : 16];
-    __shared__ __attribute__((aligned(16))) unsigned char sB0[BN * 128];
-    __shared__ __attribute__((aligned(16))) unsigned char sB1[SPLIT ? BN * 128 : 16];
-    __shared__ __attribute__((aligned(16))) unsigned char sAB[SPLIT ? 16 : 2 * (BM + BN) * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char sA0[SPLIT == 0 ? 16 : BM * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char sA1[SPLIT == 1 ? BM * 128 : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char sB0[SPLIT == 0 ? 16 : BN * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char sB1[SPLIT == 1 ? BN * 128 : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char sAB[SPLIT == 0 ? 2 * (BM + BN) * 128 : 16];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave / WC, wc = wave % WC;
@@ -199,7 +199,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
         __syncthreads();     // with LDS-DMA in flight hipcc drains vmcnt(0) here: the prefetch overlapped the MFMAs
     };
 
-    if (SPLIT) {
+    if (SPLIT == 2) {
+        // single buffer: fill -> barrier -> MFMAs -> barrier; half the LDS, so twice the co-resident blocks hide the fill
+        for (int kt = 0; kt < nk; ++kt) {
+            if (FAST) dma_tile(kt, sA0, sB0);
+            else { load_tile(kt); store_tile(sA0, sB0); }
+            __syncthreads();
+            k_step(nk, sA0, sB0, sA0, sB0);      // kt argument = nk: no prefetch inside, ends with a barrier
+        }
+    } else if (SPLIT == 1) {
         if (FAST) dma_tile(0, sA0, sB0);
         else { load_tile(0); store_tile(sA0, sB0); }
         __syncthreads();
@@ -332,9 +340,10 @@ int launch_cfg(const vv_conv_params& p, int M, hipStream_t st) {
     if (p.Npad % BN != 0) VV_FAIL(VV_E_ARG, "vv_conv_gemm: Npad %d not a multiple of tile N %d", p.Npad, BN);
     const int tilesM = (M + BM - 1) / BM, tilesN = p.Npad / BN;
     static int split = -1;
-    if (split < 0) { const char* e = getenv("VV_GEMM_SPLIT"); split = e ? atoi(e) : 0; }
-    if (split) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, true>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
-    else hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, false>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
+    if (split < 0) { const char* e = getenv("VV_GEMM_SPLIT"); split = e ? atoi(e) : 2; }
+    if (split == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 1>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
+    else if (split == 2) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 0>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     VV_CHECK_LAUNCH("vv_conv_gemm");
     return VV_OK;
 }
