@@ -21,8 +21,8 @@ __device__ __forceinline__ uint2 ds_read_tr16(const unsigned char* lds_ptr) {
     return __builtin_bit_cast(uint2, v);
 }
 
-template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH>
-__global__ __launch_bounds__(NW * 64) void attn_kernel(const vv_attn_params p, const int nqt) {
+template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1>
+__global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params p, const int nqt) {
     constexpr int DK = (D + 31) / 32 * 32, DKC = DK / 8, KS = DK / 32;
     constexpr int DV = (D + 15) / 16 * 16, DVC = DV / 8, NDT = DV / 16;
     constexpr int KT = KVT / 16, US = KVT / 32;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const vv_attn_params p, c
     }
 }
 
-template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH>
+template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1>
 int attn_launch(const vv_attn_params& p, hipStream_t st) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
     constexpr int PK = DK * 2 + 16, PV = DV * 2 + 16;
@@ -228,7 +228,7 @@ int attn_launch(const vv_attn_params& p, hipStream_t st) {
     const int nqt = (p.Nq + BQ - 1) / BQ;
     const int64_t nblk = (int64_t)p.B * p.heads * nqt;
     if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_attention: grid too large");
-    auto kern = attn_kernel<T, D, QT, KVT, NW, PREFETCH>;
+    auto kern = attn_kernel<T, D, QT, KVT, NW, PREFETCH, OCC>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -248,9 +248,12 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
         // short sequences (temporal attention over <=32 frames, tiny test shapes): one wave per block, 32-key tiles
         if (p.Nq <= 32 && p.Nkv <= 32) return attn_launch<T, D, 2, 32, 1, true>(p, st);
         if constexpr (D <= 80) {
-            static int qt4 = -1;
-            if (qt4 < 0) { const char* e = getenv("VV_ATTN_QT4"); qt4 = e ? atoi(e) : 0; }
-            if (qt4 && p.Nq >= 1024) return attn_launch<T, D, 4, 64, 4, true>(p, st);
+            static int var = -1;
+            if (var < 0) { const char* e = getenv("VV_ATTN_VARIANT"); var = e ? atoi(e) : 0; }
+            if (var == 1) return attn_launch<T, D, 2, 64, 4, false, 1>(p, st);     // no register prefetch
+            if (var == 2) return attn_launch<T, D, 2, 64, 4, true, 4>(p, st);      // capped at 128 VGPRs (4 waves/SIMD)
+            if (var == 3) return attn_launch<T, D, 2, 64, 4, false, 4>(p, st);     // both
+            if (var == 4) return attn_launch<T, D, 2, 32, 4, true, 4>(p, st);      // 32-key tiles, capped
         }
         return attn_launch<T, D, 2, 64, 4, true>(p, st);
     }
