@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
     const int c8 = t & 7;                      // this thread's 16-byte slot inside the 64-wide k tile
     const int rsw = (t >> 3) & 7;              // (row & 7) of every row this thread stages (rows differ by 32)
     // per-row gather state
-    int rpix[AR], ryb[AR], rxb[AR];
+    int rpix[AR], ryb[AR], rxb[AR], rfr[FAST ? AR : 1];
     bool rv[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
         const int y = rem / p.Wout, x = rem - y * p.Wout;
         ryb[i] = y * p.stride - p.pad_t; rxb[i] = x * p.stride - p.pad_l;
         rpix[i] = FAST ? (f * p.Hin + ryb[i]) * p.Win + rxb[i] : f;     // FAST: pixel index of tap (0,0); else frame
+        if (FAST) rfr[i] = f;
     }
     const bool resize = (p.Hv != p.Hin) || (p.Wv != p.Win);
     const unsigned short* wbase = (const unsigned short*)p.weight;
@@ -94,8 +95,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int yv = ryb[i] + ky, xv = rxb[i] + kx;
-            const bool ok = rv[i] && yv >= 0 && yv < p.Hin && xv >= 0 && xv < p.Win;
-            const void* g = ok ? (const void*)(src + ((int64_t)(rpix[i] + dpix) * Cs + csrc) * 2) : (const void*)g_zero_page;
+            const bool ok = rv[i] && yv >= 0 && yv < p.Hv && xv >= 0 && xv < p.Wv;
+            int pix = rpix[i] + dpix;
+            if (resize) pix = (rfr[i] * p.Hin + (yv * p.Hin) / p.Hv) * p.Win + (xv * p.Win) / p.Wv;   // fused nearest upsample
+            const void* g = ok ? (const void*)(src + ((int64_t)pix * Cs + csrc) * 2) : (const void*)g_zero_page;
             glds16(g, a + i * 32 * 128);
         }
         unsigned char* b = bufB + wave * 1024;
@@ -361,8 +364,7 @@ int launch_t(const vv_conv_params& p, int M, hipStream_t st) {
 template <typename T>
 int launch_mode(const vv_conv_params& p, int M, hipStream_t st) {
     if (p.in_dtype == VV_F32) return launch_t<T, MODE_F32>(p, M, st);
-    const bool no_resize = p.Hv == p.Hin && p.Wv == p.Win;
-    const bool fast = no_resize && (p.C0 % 64 == 0) && (p.C1 % 64 == 0) && p.Kpad == p.K && (int64_t)p.F * p.Hin * p.Win < 0x7fffffff;
+    const bool fast = (p.C0 % 64 == 0) && (p.C1 % 64 == 0) && p.Kpad == p.K && (int64_t)p.F * p.Hin * p.Win < 0x7fffffff;
     return fast ? launch_t<T, MODE_FAST>(p, M, st) : launch_t<T, MODE_H16>(p, M, st);
 }
 

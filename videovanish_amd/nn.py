@@ -113,7 +113,7 @@ class ResBlock:
         self.conv2 = Conv(ctx, name + ".conv2", cout, cout)
         self.short = Conv(ctx, name + ".conv_shortcut", cin, cout, k=1) if cin != cout else None
 
-    def __call__(self, x0, F, H, W, x1=None, silu_temb=None, res1=None):
+    def __call__(self, x0, F, H, W, x1=None, silu_temb=None, res1=None, out_dtype=torch.float32):
         HW = H * W
         h = self.norm1(x0, F, HW, x1=x1, silu=True)
         b1 = None
@@ -126,7 +126,7 @@ class ResBlock:
             xs, _, _ = self.short(x0, F, H, W, x1=x1)
         else:
             xs = x0
-        out, _, _ = self.conv2(h, F, H, W, res0=xs, res1=res1)
+        out, _, _ = self.conv2(h, F, H, W, res0=xs, res1=res1, out_dtype=out_dtype)
         return out
 
 
@@ -206,14 +206,14 @@ class SpatialTransformer:
         self.ff = FeedForward(ctx, b + ".ff", C)
         self.proj_out = Conv(ctx, name + ".proj_out", C, C, k=1)
 
-    def __call__(self, x, F, H, W):
+    def __call__(self, x, F, H, W, out_dtype=torch.float32):
         HW = H * W
         h = self.norm(x, F, HW)
         t, _, _ = self.proj_in(h, F, H, W)
         t = self.attn1.spatial(self.n1(t), t, F, HW)
         t = self.attn2(self.n2(t), t, F, HW)
         t = self.ff(self.n3(t), t)
-        out, _, _ = self.proj_out(t, F, H, W, res0=x)
+        out, _, _ = self.proj_out(t, F, H, W, res0=x, out_dtype=out_dtype)
         return out
 
 
@@ -232,7 +232,7 @@ class MotionModule:
         self.proj_out = Linear(ctx, name + ".proj_out", C, C)
         self.pe = pe_table          # [max_seq, C] fp32 on device
 
-    def __call__(self, x, F, H, W, res1=None):
+    def __call__(self, x, F, H, W, res1=None, out_dtype=torch.float32):
         HW = H * W
         if F > self.pe.shape[0]:
             raise RuntimeError(f"motion module: clip of {F} frames exceeds the positional table ({self.pe.shape[0]})")
@@ -241,4 +241,4 @@ class MotionModule:
         t = self.attn1.temporal(self.n1(t, pe=self.pe, rows_per_frame=HW), t, F, HW)
         t = self.attn2.temporal(self.n2(t, pe=self.pe, rows_per_frame=HW), t, F, HW)
         t = self.ff(self.n3(t), t)
-        return self.proj_out(t, res0=x, res1=res1)
+        return self.proj_out(t, res0=x, res1=res1, out_dtype=out_dtype)

@@ -122,18 +122,22 @@ class _Backbone:
         outs = []
         add_up = list(add_up) if add_up is not None else None
         L = len(self.cfg.block_out)
+        f32 = torch.float32
         for i, layers in enumerate(self.up):
-            for (r, a, m) in layers:
+            for li, (r, a, m) in enumerate(layers):
                 s, sh, sw = skips.pop()
                 au = add_up.pop(0) if add_up is not None else None
                 last = "m" if m is not None else ("a" if a is not None else "r")
-                x = r(x, F, H, W, x1=s, silu_temb=st, res1=au if last == "r" else None)
+                # the output of a block's last layer feeds only MFMA A operands (upsampler conv, BrushNet zero conv):
+                # store it as h16 (same operand values, half the bytes, LDS-DMA fast path downstream)
+                od = self.ctx.h16 if (li == len(layers) - 1 and i < L - 1 and not (last == "a" and au is not None)) else f32
+                x = r(x, F, H, W, x1=s, silu_temb=st, res1=au if last == "r" else None, out_dtype=od if last == "r" else f32)
                 if a is not None:
-                    x = a(x, F, H, W)
+                    x = a(x, F, H, W, out_dtype=od if last == "a" else f32)
                     if last == "a" and au is not None:
                         hip.add_inplace(self.ctx.dt, x, au)
                 if m is not None:
-                    x = m(x, F, H, W, res1=au)
+                    x = m(x, F, H, W, res1=au, out_dtype=od)
                 if collect:
                     outs.append((x, H, W))
             if i < L - 1:
