@@ -27,11 +27,12 @@
 extern "C" {
 #endif
 
-#define VV_ABI_VERSION 1
+#define VV_ABI_VERSION 2
 
 enum { VV_BF16 = 0, VV_F16 = 1, VV_F32 = 2, VV_U8 = 3 };
 enum { VV_OK = 0, VV_E_ARG = -1, VV_E_UNSUPPORTED = -2, VV_E_LAUNCH = -3 };
 enum { VV_EPI_NONE = 0, VV_EPI_GEGLU = 1 };
+enum { VV_ACT_NONE = 0, VV_ACT_SILU = 1, VV_ACT_RELU = 2 };
 
 int vv_abi_version(void);
 const char* vv_last_error(void);
@@ -56,7 +57,7 @@ typedef struct {
     int32_t Hin, Win;     /* stored spatial size of the sources */
     int32_t Hv, Wv;       /* virtual size after nearest resize (== Hin,Win when no resize) */
     int32_t Hout, Wout;   /* output spatial size; M = F*Hout*Wout */
-    int32_t ksize;        /* 1 or 3 */
+    int32_t ksize;        /* kernel height: 1, 3, 5 or 7 */
     int32_t stride;       /* 1 or 2 */
     int32_t pad_t, pad_l; /* top/left zero padding (bottom/right implied by bounds) */
     const void* weight;   /* h16 [Npad][Kpad], Kpad % 64 == 0, rows >= N are zero, Npad % tileN == 0 */
@@ -74,6 +75,8 @@ typedef struct {
     int32_t ldo;
     int32_t epilogue;     /* VV_EPI_* ; GEGLU expects weight rows interleaved in blocks of 16: [v0..15 g0..15 v16..] */
     float out_scale;      /* multiplies the accumulated product+bias before residuals (1.0f = none) */
+    int32_t ksize_w;      /* kernel width (0 = same as ksize); k = (ky*ksize_w + kx)*Cin + c */
+    int32_t act;          /* VV_ACT_NONE or VV_ACT_RELU applied last (after residuals) */
 } vv_conv_params;
 int vv_conv_gemm(const vv_conv_params* host_p, int dtype, void* stream);
 
@@ -90,7 +93,7 @@ typedef struct {
     int32_t pool_frames;                /* 1: statistics pooled over all F frames (motion module norm) */
     float eps;
     const float* gamma; const float* beta;   /* [C] */
-    int32_t silu;
+    int32_t silu;                       /* activation after the affine: VV_ACT_NONE / VV_ACT_SILU / VV_ACT_RELU */
     float* stats_ws;                    /* workspace: F * (nsplit + 1) * groups * 2 floats, nsplit = vv_groupnorm_nsplit() */
     void* out; int32_t out_dtype;       /* [F*HW][C] h16 (or fp32) */
 } vv_groupnorm_params;
@@ -151,6 +154,35 @@ int vv_feather_composite(const uint8_t* inpainted, const uint8_t* orig, const ui
 /* windowed 5x5 chamfer distance transform: distance to the nearest ZERO pixel where it is <= R, else a large
  * constant ((INT_MAX>>2)/65536); fp32 */
 int vv_chamfer_dt(const uint8_t* bin, int T, int H, int W, int R, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K9/K10  RAFT correlation lookup + recurrent-update pieces + convex upsampling, bilinear warp, forward/backward
+ * consistency and flow-guided fill (reference diffuerase.py:52-57 -> Propainter.forward).
+ * The dense parts of RAFT (encoders, the all-pairs correlation f1^T f2 / 16, update-block convs) run on vv_conv_gemm.
+ * Layouts: feature maps / flows are NHWC ([h][w][C]); coords are absolute (x, y) pixel positions.
+ * ------------------------------------------------------------------------------------------------------------ */
+int vv_avgpool2_f32(const float* in, int64_t N, int h, int w, float* out, void* stream);          /* [N][h][w] -> [N][h/2][w/2] */
+/* out[n][l*81 + i*9 + j] = bilinear(corr_l[n], x/2^l + i-4, y/2^l + j-4), zeros outside; channels 324..cpad-1 = 0 (h16) */
+int vv_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3, int h, int w, const float* coords,
+                   int64_t N, int cpad, void* out, int dtype, void* stream);
+/* context encoder output cn [M][256] -> net = tanh(cn[:, :128]) (fp32 + h16), relu(cn[:, 128:]) -> xbuf[:, 0:128] (h16, ld 256) */
+int vv_raft_ctx_split(const float* cn, int64_t M, float* net, void* net16, void* xbuf, int dtype, void* stream);
+/* flow = coords1 - grid -> flow8 (h16 [M][8]) and xbuf[:, 254:256] */
+int vv_raft_flow_prep(const float* coords1, int64_t M, int w, void* flow8, void* xbuf, int dtype, void* stream);
+int vv_gru_rh(const float* zr, const float* h, int64_t M, void* rh, int dtype, void* stream);        /* rh = sigmoid(zr[:,128:]) * h */
+int vv_gru_update(const float* zr, const float* q, int64_t M, float* h, void* h16, int dtype, void* stream); /* h = (1-z)h + z tanh(q) */
+int vv_add_flow(float* coords1, const float* dflow, int ld, int64_t M, void* stream);              /* coords1 += dflow[:, 0:2] */
+int vv_add_relu_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+int vv_convex_upsample(const float* coords1, const float* mask, int h, int w, float* out, void* stream);   /* -> flow [8h][8w][2] */
+int vv_fb_valid(const float* f_ab, const float* f_ba, int H, int W, uint8_t* valid, void* stream);
+/* fill the unknown pixels of frame t (cur_t [H][W][3] fp32, in place) from neighbour nb warped by `flow` (t -> nb) */
+int vv_prop_fill(float* cur_t, const float* cur_nb, uint8_t* known_t, const uint8_t* known_nb, const uint8_t* valid,
+                 const float* flow, int H, int W, uint8_t* filled_t, void* stream);
+int vv_prop_combine(const float* orig, const float* a, const float* b, const uint8_t* fa, const uint8_t* fb, const uint8_t* hole,
+                    int H, int W, const float* mean3, uint8_t* out, uint8_t* filled, void* stream);
+int vv_masked_sum_u8(const uint8_t* frame, const uint8_t* hole, int64_t npix, unsigned long long* sums4, void* stream);
+int vv_u8_to_f32(const uint8_t* in, float* out, int64_t n, void* stream);
+int vv_raft_prep(const uint8_t* img, int64_t npix, void* out8, int dtype, void* stream);           /* u8 RGB -> h16 [..][8], 2x/255-1 */
 
 /* model-side pre/post */
 /* frames u8 [T][H][W][3], mask u8 [T][H][W] -> img (x/127.5-1) and masked img (img*(1-m)) as h16 NHWC with C=8

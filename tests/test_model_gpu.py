@@ -160,3 +160,26 @@ def test_drop_in_run_infill_on_frames(gpu):
                                            num_inference_steps=2, scheduler="ddim", compat_reference_early_return=True)
     assert out2[0].shape == (H, W, 3) and out2[1].shape == (32, 32 * W // H // 8 * 8, 3) or out2[1].shape[0] <= 32   # frames 1.. at model size
     diffuerase.configure(None)
+
+
+def test_drop_in_computes_flow_prior_when_none_supplied(gpu):
+    """reference diffuerase.py:47-57: no `propainer_frames` => the prior is computed (here: RAFT flow propagation on HIP)."""
+    import diffuerase
+    from oracle import flowprop_ref as FP
+    from oracle import pipeline_ref as R
+    T, H, W = 3, 64, 96
+    frames, masks, _ = _clip(T, H, W, seed=77)
+    run = RunConfig(steps=2, chunk=4, overlap=2, seed=3, dtype="fp16", unet=TINY_UNET, vae=TINY_VAE)
+    diffuerase.configure(run)
+    diffuerase.propainter = None
+    progs = []
+    out = diffuerase.run_infill_on_frames(frames, masks, mask_dilation_iter=2, max_img_size=960, prog=lambda p, s: progs.append((p, s)),
+                                          num_inference_steps=2, scheduler="ddim")
+    assert (20, "running propainter prior") in progs and len(out) == T and out[0].shape == (H, W, 3)
+    dil = R.I.collapse_and_dilate(masks, 2)
+    prior = FP.flow_propagation_prior(frames, dil, iters=20)
+    ref = R.run_infill_on_frames(frames, masks, 2, prior, max_img_size=960, steps=2, chunk=4, overlap=2, seed=3, ucfg=TINY_UNET, vcfg=TINY_VAE)
+    du = np.abs(np.stack(out).astype(int) - np.stack(ref).astype(int))
+    _log("drop_in_with_flow_prior[tiny,fp16]", max_abs_u8=int(du.max()), frac_gt2=float((du > 2).mean()))
+    assert (du > 2).mean() <= 0.01
+    diffuerase.configure(None)

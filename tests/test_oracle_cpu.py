@@ -161,3 +161,49 @@ def test_pipeline_oracle_end_to_end_tiny():
     far = I.distance_transform_l2_5(np.bitwise_not(dil[0])) >= 3        # >= feather_px outside the mask: untouched
     assert (out[0][far] == frames[0][far]).all()
     assert (out[0][dil[0] > 0] != frames[0][dil[0] > 0]).any()
+
+
+# ---- flow oracle (RAFT + propagation) properties -------------------------------------------------------------------
+def test_flow_oracle_properties():
+    from oracle import flowprop_ref as FP
+    g = torch.Generator().manual_seed(3)
+    # lookup at integer coordinates returns the correlation values themselves (level 0, centre tap = channel 4*9+4)
+    h, w = 8, 10
+    f1, f2 = torch.randn(16, h, w, generator=g), torch.randn(16, h, w, generator=g)
+    pyr = FP.corr_pyramid(f1, f2)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    coords = torch.stack([xs, ys], -1).reshape(-1, 2)
+    look = FP.corr_lookup(pyr, coords)
+    n = torch.arange(h * w)
+    assert torch.allclose(look[:, 40], pyr[0].reshape(h * w, -1)[n, n])
+    assert look.shape == (h * w, 324)
+    # convex upsampling of a constant flow is 8x that constant (softmax weights sum to 1) away from the border
+    flow = torch.ones(1, 2, h, w) * torch.tensor([1.5, -2.0])[None, :, None, None]
+    up = FP.convex_upsample(flow, torch.randn(1, 576, h, w, generator=g))
+    assert torch.allclose(up[0, :, 8:-8, 8:-8], (8 * torch.tensor([1.5, -2.0]))[:, None, None].expand(2, 8 * h - 16, 8 * w - 16), atol=1e-4)
+    # warp by zero flow is the identity; integer shift moves pixels
+    img = torch.randn(3, 12, 14, generator=g)
+    assert torch.equal(FP.warp_frame(img, torch.zeros(2, 12, 14)), img)
+    sh = FP.warp_frame(img, torch.stack([torch.full((12, 14), 2.0), torch.zeros(12, 14)]))
+    assert torch.equal(sh[:, :, :12], img[:, :, 2:]) and (sh[:, :, 12:] == 0).all()
+    # consistent flows pass, inconsistent fail
+    f = torch.stack([torch.full((12, 14), 1.0), torch.full((12, 14), -1.0)])
+    assert FP.fb_consistency(f, -f)[2:-2, 2:-2].all() and not FP.fb_consistency(f, f)[2:-2, 2:-2].any()
+
+
+def test_flow_propagation_fills_from_neighbours():
+    from oracle import flowprop_ref as FP
+    rng = np.random.default_rng(5)
+    H, W = 24, 32
+    fr = np.stack([rng.integers(0, 256, (H, W, 3), dtype=np.uint8)] * 3)
+    mk = np.zeros((3, H, W), np.uint8)
+    mk[1, 6:14, 8:20] = 255
+    z = [torch.zeros(2, H, W)] * 2
+    out, filled = FP.propagate(fr, mk, z, z)
+    assert (out[1] == fr[0]).all() and filled[1].sum() == 8 * 12 and filled[0].sum() == 0
+    mk[:, 6:14, 8:20] = 255                 # hole in every frame: nothing to propagate -> mean colour of the unmasked pixels
+    out, filled = FP.propagate(fr, mk, z, z)
+    assert filled.sum() == 0
+    keep = mk[0] == 0
+    mean = np.floor(fr[0][keep].astype(np.int64).sum(0) / keep.sum() + 0.5)
+    assert (out[0][~keep] == mean.astype(np.uint8)).all() and (out[0][keep] == fr[0][keep]).all()

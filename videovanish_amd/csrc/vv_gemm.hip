@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int Cin = p.C0 + p.C1;
+    const int KW = p.ksize_w > 0 ? p.ksize_w : p.ksize;
     const int HWo = p.Hout * p.Wout;
     const int c8 = t & 7;                      // this thread's 16-byte slot inside the 64-wide k tile
     const int rsw = (t >> 3) & 7;              // (row & 7) of every row this thread stages (rows differ by 32)
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
         const int k0 = kt * BK;
         const int tap = k0 / Cin;
         int cc = k0 - tap * Cin;
-        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+        const int ky = tap / KW, kx = tap - ky * KW;
         const unsigned char* src = (const unsigned char*)p.in0;
         int Cs = p.C0;
         if (cc >= p.C0) { src = (const unsigned char*)p.in1; cc -= p.C0; Cs = p.C1; }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
         const bool kvalid = k < p.K;
         const int tap = kvalid ? k / Cin : 0;
         int cc = k - tap * Cin;
-        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+        const int ky = tap / KW, kx = tap - ky * KW;
         const unsigned char* src = (const unsigned char*)p.in0;
         int Cs = p.C0;
         if (cc >= p.C0) { src = (const unsigned char*)p.in1; cc -= p.C0; Cs = p.C1; }
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
                     if (r0f32) { const float4 r4 = *(const float4*)((const float*)p.res1 + rbase + n); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
                     else { const uint2 r2 = *(const uint2*)((const unsigned short*)p.res1 + rbase + n); v[0] += T::to_f32(r2.x & 0xffff); v[1] += T::to_f32(r2.x >> 16); v[2] += T::to_f32(r2.y & 0xffff); v[3] += T::to_f32(r2.y >> 16); }
                 }
+                if (p.act == VV_ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                 const int64_t oc = (int64_t)m * p.ldo + n;
                 if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + oc) = make_float4(v[0], v[1], v[2], v[3]);
                 else *(uint2*)((unsigned short*)p.out + oc) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
                 if (rowv) x += rowv[n + r];
                 if (p.res0) x += r0f32 ? ((const float*)p.res0)[ri + r] : T::to_f32(((const unsigned short*)p.res0)[ri + r]);
                 if (p.res1) x += r0f32 ? ((const float*)p.res1)[ri + r] : T::to_f32(((const unsigned short*)p.res1)[ri + r]);
+                if (p.act == VV_ACT_RELU) x = fmaxf(x, 0.f);
                 if (p.out_dtype == VV_F32) ((float*)p.out)[oc + r] = x;
                 else ((unsigned short*)p.out)[oc + r] = T::from_f32(x);
             }
@@ -376,9 +379,11 @@ extern "C" int vv_conv_gemm(const vv_conv_params* pp, int dtype, void* stream) {
     if (dtype != VV_BF16 && dtype != VV_F16) VV_FAIL(VV_E_ARG, "vv_conv_gemm: dtype must be VV_BF16 or VV_F16");
     if (!p.in0 || !p.weight || !p.out) VV_FAIL(VV_E_ARG, "vv_conv_gemm: null tensor pointer");
     if (p.C0 <= 0 || p.C0 % 8 || p.C1 < 0 || p.C1 % 8 || (p.C1 > 0 && !p.in1)) VV_FAIL(VV_E_ARG, "vv_conv_gemm: C0=%d C1=%d must be multiples of 8", p.C0, p.C1);
-    if (p.ksize != 1 && p.ksize != 3) VV_FAIL(VV_E_ARG, "vv_conv_gemm: ksize %d", p.ksize);
+    const int kw_ = p.ksize_w > 0 ? p.ksize_w : p.ksize;
+    if ((p.ksize != 1 && p.ksize != 3 && p.ksize != 5 && p.ksize != 7) || (kw_ != 1 && kw_ != 3 && kw_ != 5 && kw_ != 7)) VV_FAIL(VV_E_ARG, "vv_conv_gemm: kernel %dx%d", p.ksize, kw_);
+    if (p.act != VV_ACT_NONE && p.act != VV_ACT_RELU) VV_FAIL(VV_E_ARG, "vv_conv_gemm: act %d", p.act);
     if (p.stride != 1 && p.stride != 2) VV_FAIL(VV_E_ARG, "vv_conv_gemm: stride %d", p.stride);
-    if (p.K != p.ksize * p.ksize * (p.C0 + p.C1)) VV_FAIL(VV_E_ARG, "vv_conv_gemm: K=%d != ks^2*Cin", p.K);
+    if (p.K != p.ksize * kw_ * (p.C0 + p.C1)) VV_FAIL(VV_E_ARG, "vv_conv_gemm: K=%d != kh*kw*Cin", p.K);
     if (p.Kpad % BK || p.Kpad < p.K) VV_FAIL(VV_E_ARG, "vv_conv_gemm: Kpad=%d must be a multiple of 64 >= K", p.Kpad);
     if (p.in_dtype != VV_F32 && p.in_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_conv_gemm: in_dtype mismatch");
     if (p.out_dtype != VV_F32 && p.out_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_conv_gemm: out_dtype mismatch");

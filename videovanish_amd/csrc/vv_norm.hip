@@ -42,7 +42,7 @@ __device__ __forceinline__ void gn_load8(const vv_groupnorm_params& p, int64_t p
 
 template <typename T>
 __global__ void gn_stats_kernel(const vv_groupnorm_params p, const GNGeom g) {
-    __shared__ float sh[2 * 64];
+    __shared__ float sh[2 * 256];
     const int t = threadIdx.x, split = blockIdx.x, f = blockIdx.y;
     const int C = p.C0 + p.C1, cpg = C / p.groups;
     for (int i = t; i < 2 * p.groups; i += blockDim.x) sh[i] = 0.f;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const vv_groupnorm_par
     const int f0 = p.pool_frames ? 0 : blockIdx.x, f1 = p.pool_frames ? p.F : blockIdx.x + 1;
     const int sub = threadIdx.x & 7;
     float* fin = p.stats_ws + (int64_t)p.F * g.nsplit * p.groups * 2;
-    for (int grp = threadIdx.x >> 3; grp < p.groups; grp += 32) {
+    for (int grp = threadIdx.x >> 3; grp < p.groups; grp += 32) {   // 256 threads = 32 groups per pass
         double s = 0.0, q = 0.0;
         const int nparts = (f1 - f0) * g.nsplit;
         for (int i = sub; i < nparts; i += 8) {
@@ -130,7 +130,7 @@ __global__ void gn_apply_kernel(const vv_groupnorm_params p, const GNGeom g) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float y = v[e] * a[e] + b[e];
-            v[e] = p.silu ? silu_f(y) : y;
+            v[e] = p.silu == VV_ACT_SILU ? silu_f(y) : (p.silu == VV_ACT_RELU ? fmaxf(y, 0.f) : y);
         }
         const int64_t o = pix * C + chunk * 8;
         if (p.out_dtype == VV_F32) { float4* d = (float4*)((float*)p.out + o); d[0] = *(float4*)&v[0]; d[1] = *(float4*)&v[4]; }
@@ -210,7 +210,7 @@ extern "C" int vv_groupnorm(const vv_groupnorm_params* pp, int dtype, void* stre
     if (dtype != VV_BF16 && dtype != VV_F16) VV_FAIL(VV_E_ARG, "vv_groupnorm: bad dtype");
     if (!p.in0 || !p.out || !p.gamma || !p.beta || !p.stats_ws) VV_FAIL(VV_E_ARG, "vv_groupnorm: null pointer");
     if (p.C0 <= 0 || p.C0 % 8 || p.C1 % 8 || (p.C1 > 0 && !p.in1)) VV_FAIL(VV_E_ARG, "vv_groupnorm: channels must be multiples of 8 (C0=%d C1=%d)", p.C0, p.C1);
-    if (p.groups <= 0 || p.groups > 64 || C % p.groups) VV_FAIL(VV_E_ARG, "vv_groupnorm: groups=%d C=%d", p.groups, C);
+    if (p.groups <= 0 || p.groups > 256 || C % p.groups) VV_FAIL(VV_E_ARG, "vv_groupnorm: groups=%d C=%d", p.groups, C);
     if (C / 8 > 1024) VV_FAIL(VV_E_UNSUPPORTED, "vv_groupnorm: C=%d too large", C);
     if (p.in_dtype != VV_F32 && p.in_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_groupnorm: in_dtype mismatch");
     if (p.out_dtype != VV_F32 && p.out_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_groupnorm: out_dtype mismatch");

@@ -10,6 +10,8 @@ import torch
 
 BF16, F16, F32, U8 = 0, 1, 2, 3
 EPI_NONE, EPI_GEGLU = 0, 1
+ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
+ABI_VERSION = 2
 _DT = {"bf16": BF16, "fp16": F16}
 _TORCH_H16 = {BF16: torch.bfloat16, F16: torch.float16}
 
@@ -47,7 +49,8 @@ class ConvParams(C.Structure):
                 ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("weight", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32),
                 ("Kpad", C.c_int32), ("Npad", C.c_int32), ("bias", C.c_void_p), ("rowvec", C.c_void_p),
                 ("res0", C.c_void_p), ("res1", C.c_void_p), ("res_dtype", C.c_int32), ("out", C.c_void_p),
-                ("out_dtype", C.c_int32), ("ldo", C.c_int32), ("epilogue", C.c_int32), ("out_scale", C.c_float)]
+                ("out_dtype", C.c_int32), ("ldo", C.c_int32), ("epilogue", C.c_int32), ("out_scale", C.c_float), ("ksize_w", C.c_int32),
+                ("act", C.c_int32)]
 
 
 class GroupNormParams(C.Structure):
@@ -68,7 +71,10 @@ class AttnParams(C.Structure):
 EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name", "vv_conv_gemm", "vv_groupnorm_nsplit",
            "vv_groupnorm", "vv_layernorm", "vv_attention", "vv_axpby_f32", "vv_silu_f32", "vv_sched_step", "vv_add_inplace",
            "vv_mask_collapse_dilate", "vv_resize_bilinear_u8", "vv_resize_nearest_u8", "vv_feather_composite", "vv_chamfer_dt",
-           "vv_preprocess", "vv_brushnet_input", "vv_pad_channels", "vv_decode_blend", "vv_blur_compose"]
+           "vv_preprocess", "vv_brushnet_input", "vv_pad_channels", "vv_decode_blend", "vv_blur_compose",
+           "vv_avgpool2_f32", "vv_corr_lookup", "vv_raft_ctx_split", "vv_raft_flow_prep", "vv_gru_rh", "vv_gru_update", "vv_add_flow",
+           "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32",
+           "vv_raft_prep"]
 
 
 def lib():
@@ -84,8 +90,8 @@ def lib():
             if not hasattr(L, name):
                 raise RuntimeError(f"libvvhip.so does not export {name}")
         v = L.vv_abi_version()
-        if v != 1:
-            raise RuntimeError(f"libvvhip.so ABI version {v} != 1")
+        if v != ABI_VERSION:
+            raise RuntimeError(f"libvvhip.so ABI version {v} != {ABI_VERSION}")
         _lib = L
     return _lib
 
@@ -126,9 +132,9 @@ def _need_cuda(*ts):
 # ----------------------------------------------------------------------------------------------------------------
 def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, Wv=None, Hout=None, Wout=None, ksize=1,
               stride=1, pad_t=0, pad_l=0, bias=None, rowvec=None, res0=None, res1=None, out=None, out_dtype=None,
-              epilogue=EPI_NONE, out_scale=1.0, C0=None, C1=0):
+              epilogue=EPI_NONE, out_scale=1.0, C0=None, C1=0, ksize_w=0, act=ACT_NONE, out_col=0):
     """Launch vv_conv_gemm.  x0/x1: NHWC activations ([F,Hin,Win,C] or any shape with C last); weight: [Npad,Kpad] h16."""
-    _need_cuda(x0, x1, weight, bias, rowvec, res0, res1, out)
+    _need_cuda(x0, x1, weight, bias, rowvec, res0, res1, out)      # out_col: write into columns [out_col, out_col+N) of `out`
     Hv = Hin if Hv is None else Hv
     Wv = Win if Wv is None else Wv
     Hout = Hv if Hout is None else Hout
@@ -146,12 +152,13 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
                    weight=weight.data_ptr(), N=N, K=K, Kpad=weight.shape[1], Npad=weight.shape[0],
                    bias=bias.data_ptr() if bias is not None else 0, rowvec=rowvec.data_ptr() if rowvec is not None else 0,
                    res0=res0.data_ptr() if res0 is not None else 0, res1=res1.data_ptr() if res1 is not None else 0,
-                   res_dtype=dt_of(res0) if res0 is not None else F32, out=out.data_ptr(), out_dtype=dt_of(out), ldo=out.shape[-1],
-                   epilogue=epilogue, out_scale=out_scale)
+                   res_dtype=dt_of(res0) if res0 is not None else F32, out=out.data_ptr() + out_col * out.element_size(), out_dtype=dt_of(out),
+                   ldo=out.shape[-1],
+                   epilogue=epilogue, out_scale=out_scale, ksize_w=ksize_w, act=act)
     if PROFILE is not None:
         Npad = weight.shape[0]
         tile = "128x128" if epilogue == EPI_GEGLU else ("128x160" if Npad % 160 == 0 else ("128x128" if Npad % 128 == 0 else "128x16"))
-        key = f"conv_gemm[{tile},{'f32in' if x0.dtype == torch.float32 else 'h16in'},k{ksize}]"
+        key = f"conv_gemm[{tile},{'f32in' if x0.dtype == torch.float32 else 'h16in'},k{ksize}{'x%d' % ksize_w if ksize_w and ksize_w != ksize else ''}]"
         es = x0.element_size()
         nbytes = F * Hin * Win * (C0 + C1) * es + N * K * 2 + M * nout * out.element_size() + sum(
             M * N * r.element_size() for r in (res0, res1) if r is not None)
@@ -162,7 +169,7 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
     return out
 
 
-def groupnorm(dtype, x0, gamma, beta, groups, eps, *, x1=None, F, HW, silu=False, pool_frames=False, out_dtype=None):
+def groupnorm(dtype, x0, gamma, beta, groups, eps, *, x1=None, F, HW, silu=False, pool_frames=False, out_dtype=None, act=None):
     _need_cuda(x0, x1, gamma, beta)
     C0 = x0.shape[-1]
     C1 = x1.shape[-1] if x1 is not None else 0
@@ -172,7 +179,7 @@ def groupnorm(dtype, x0, gamma, beta, groups, eps, *, x1=None, F, HW, silu=False
     out = torch.empty((F * HW, Ctot), dtype=h16(dtype) if out_dtype is None else out_dtype, device=x0.device)
     p = GroupNormParams(in0=x0.data_ptr(), in1=x1.data_ptr() if x1 is not None else 0, in_dtype=dt_of(x0), C0=C0, C1=C1, F=F, HW=HW,
                         groups=groups, pool_frames=int(pool_frames), eps=eps, gamma=gamma.data_ptr(), beta=beta.data_ptr(),
-                        silu=int(silu), stats_ws=ws.data_ptr(), out=out.data_ptr(), out_dtype=dt_of(out))
+                        silu=int(act) if act is not None else int(silu), stats_ws=ws.data_ptr(), out=out.data_ptr(), out_dtype=dt_of(out))
     with _Prof("groupnorm", 0.0, F * HW * Ctot * (2 * x0.element_size() + out.element_size())):
         _check(lib().vv_groupnorm(C.byref(p), dtype, _stream()), "vv_groupnorm")
     return out
@@ -309,4 +316,109 @@ def blur_compose(pix01, orig, mask2d, taps21):
     out = torch.empty((T, H, W, 3), dtype=torch.uint8, device=pix01.device)
     taps = (C.c_float * 21)(*[float(x) for x in taps21])
     _check(lib().vv_blur_compose(_p(pix01), _p(orig), _p(mask2d), T, H, W, taps, _p(tmp), _p(out), _stream()), "vv_blur_compose")
+    return out
+
+
+# ---- K9/K10: RAFT / flow-guided propagation kernels ----------------------------------------------------------------
+def avgpool2(x):
+    """[N,h,w] fp32 -> [N,h//2,w//2]."""
+    _need_cuda(x)
+    N, h, w = x.shape
+    out = torch.empty((N, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    _check(lib().vv_avgpool2_f32(_p(x), C.c_int64(N), h, w, _p(out), _stream()), "vv_avgpool2_f32")
+    return out
+
+
+def corr_lookup(dtype, pyr, coords, cpad=384):
+    """pyr: 4 fp32 tensors [N,h_l,w_l]; coords [N,2] fp32 (x,y) -> h16 [N,cpad] (324 real channels)."""
+    _need_cuda(*pyr, coords)
+    N, h, w = pyr[0].shape
+    out = torch.empty((N, cpad), dtype=h16(dtype), device=coords.device)
+    _check(lib().vv_corr_lookup(_p(pyr[0]), _p(pyr[1]), _p(pyr[2]), _p(pyr[3]), h, w, _p(coords), C.c_int64(N), cpad, _p(out), dtype, _stream()),
+           "vv_corr_lookup")
+    return out
+
+
+def raft_ctx_split(dtype, cn, net, net16, xbuf):
+    _need_cuda(cn, net, net16, xbuf)
+    _check(lib().vv_raft_ctx_split(_p(cn), C.c_int64(cn.shape[0]), _p(net), _p(net16), _p(xbuf), dtype, _stream()), "vv_raft_ctx_split")
+
+
+def raft_flow_prep(dtype, coords1, w, flow8, xbuf):
+    _need_cuda(coords1, flow8, xbuf)
+    _check(lib().vv_raft_flow_prep(_p(coords1), C.c_int64(coords1.shape[0]), w, _p(flow8), _p(xbuf), dtype, _stream()), "vv_raft_flow_prep")
+
+
+def gru_rh(dtype, zr, h, rh):
+    _need_cuda(zr, h, rh)
+    _check(lib().vv_gru_rh(_p(zr), _p(h), C.c_int64(h.shape[0]), _p(rh), dtype, _stream()), "vv_gru_rh")
+
+
+def gru_update(dtype, zr, q, h, h16_out):
+    _need_cuda(zr, q, h, h16_out)
+    _check(lib().vv_gru_update(_p(zr), _p(q), C.c_int64(h.shape[0]), _p(h), _p(h16_out), dtype, _stream()), "vv_gru_update")
+
+
+def add_flow(coords1, dflow):
+    _need_cuda(coords1, dflow)
+    _check(lib().vv_add_flow(_p(coords1), _p(dflow), dflow.shape[-1], C.c_int64(coords1.shape[0]), _stream()), "vv_add_flow")
+
+
+def add_relu(a, b):
+    _need_cuda(a, b)
+    out = torch.empty_like(a)
+    _check(lib().vv_add_relu_f32(_p(a), _p(b), _p(out), C.c_int64(a.numel()), _stream()), "vv_add_relu_f32")
+    return out
+
+
+def convex_upsample(coords1, mask, h, w):
+    _need_cuda(coords1, mask)
+    out = torch.empty((8 * h, 8 * w, 2), dtype=torch.float32, device=coords1.device)
+    _check(lib().vv_convex_upsample(_p(coords1), _p(mask), h, w, _p(out), _stream()), "vv_convex_upsample")
+    return out
+
+
+def fb_valid(f_ab, f_ba):
+    _need_cuda(f_ab, f_ba)
+    H, W, _ = f_ab.shape
+    out = torch.empty((H, W), dtype=torch.uint8, device=f_ab.device)
+    _check(lib().vv_fb_valid(_p(f_ab), _p(f_ba), H, W, _p(out), _stream()), "vv_fb_valid")
+    return out
+
+
+def prop_fill(cur_t, cur_nb, known_t, known_nb, valid, flow, filled_t):
+    _need_cuda(cur_t, cur_nb, known_t, known_nb, valid, flow, filled_t)
+    H, W, _ = cur_t.shape
+    _check(lib().vv_prop_fill(_p(cur_t), _p(cur_nb), _p(known_t), _p(known_nb), _p(valid), _p(flow), H, W, _p(filled_t), _stream()), "vv_prop_fill")
+
+
+def prop_combine(orig, a, b, fa, fb, hole, mean3):
+    _need_cuda(orig, a, b, fa, fb, hole, mean3)
+    H, W, _ = orig.shape
+    out = torch.empty((H, W, 3), dtype=torch.uint8, device=orig.device)
+    filled = torch.empty((H, W), dtype=torch.uint8, device=orig.device)
+    _check(lib().vv_prop_combine(_p(orig), _p(a), _p(b), _p(fa), _p(fb), _p(hole), H, W, _p(mean3), _p(out), _p(filled), _stream()), "vv_prop_combine")
+    return out, filled
+
+
+def masked_sum_u8(frame, hole):
+    """-> int64 tensor [4] (sum r, g, b over non-hole pixels, count) on the device."""
+    _need_cuda(frame, hole)
+    sums = torch.empty(4, dtype=torch.int64, device=frame.device)
+    _check(lib().vv_masked_sum_u8(_p(frame), _p(hole), C.c_int64(hole.numel()), _p(sums), _stream()), "vv_masked_sum_u8")
+    return sums
+
+
+def u8_to_f32(x):
+    _need_cuda(x)
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _check(lib().vv_u8_to_f32(_p(x), _p(out), C.c_int64(x.numel()), _stream()), "vv_u8_to_f32")
+    return out
+
+
+def raft_prep(dtype, img):
+    """u8 [..., 3] -> h16 [..., 8] scaled to [-1,1]."""
+    _need_cuda(img)
+    out = torch.empty(img.shape[:-1] + (8,), dtype=h16(dtype), device=img.device)
+    _check(lib().vv_raft_prep(_p(img), C.c_int64(img.numel() // 3), _p(out), dtype, _stream()), "vv_raft_prep")
     return out
