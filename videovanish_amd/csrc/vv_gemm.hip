@@ -358,7 +358,7 @@ template <typename T, int MODE>
 int launch_t(const vv_conv_params& p, int M, hipStream_t st) {
     // tile choice: GEGLU needs an even number of N tiles per wave; N % 160 == 0 -> 128x160; tiny N -> 128x16
     if (p.epilogue == VV_EPI_GEGLU) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, M, st);
-    if (p.Npad % 160 == 0) return launch_cfg<T, 2, 2, 4, 5, MODE>(p, M, st);
+    if (p.Npad % 160 == 0) return launch_cfg<T, 2, 2, 4, 5, MODE>(p, M, st);   // (a 256x160 4-wave tile measured the same: profiles/r1_gemm_ab.txt)
     if (p.Npad % 128 == 0) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, M, st);
     if (p.Npad % 16 == 0 && p.Npad <= 64) return launch_cfg<T, 4, 1, 2, 1, MODE>(p, M, st);
     VV_FAIL(VV_E_ARG, "vv_conv_gemm: unsupported Npad %d (need %%160, %%128 or 16..64 %%16)", p.Npad);
