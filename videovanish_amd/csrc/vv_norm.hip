@@ -40,13 +40,16 @@ __device__ __forceinline__ void gn_load8(const vv_groupnorm_params& p, int64_t p
     }
 }
 
+// Partial statistics of one (frame, row-split): DETERMINISTIC reduction (no float atomics): every thread parks its 8
+// per-channel sums in LDS, then one thread per group adds the group's channels over the block's row lanes in a fixed
+// order.  (The multi-GPU path promises bit-identical output for every world size: nothing may depend on arrival order.)
 template <typename T>
 __global__ void gn_stats_kernel(const vv_groupnorm_params p, const GNGeom g) {
-    __shared__ float sh[2 * 256];
+    extern __shared__ float part[];          // [2][krows][C]
     const int t = threadIdx.x, split = blockIdx.x, f = blockIdx.y;
     const int C = p.C0 + p.C1, cpg = C / p.groups;
-    for (int i = t; i < 2 * p.groups; i += blockDim.x) sh[i] = 0.f;
-    __syncthreads();
+    float* ps = part;
+    float* pq = part + g.krows * C;
     if (t < g.threads) {
         const int chunk = t % g.C8, r0 = t / g.C8;
         float s[8], q[8];
@@ -60,21 +63,17 @@ __global__ void gn_stats_kernel(const vv_groupnorm_params p, const GNGeom g) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
         }
-        // combine the 8 channels into their groups (a chunk may straddle up to 8 groups when cpg is small)
-        int c = chunk * 8;
-        float ss = 0.f, qq = 0.f;
-        int gcur = c / cpg;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ge = (c + e) / cpg;
-            if (ge != gcur) { atomicAdd(&sh[2 * gcur], ss); atomicAdd(&sh[2 * gcur + 1], qq); ss = 0.f; qq = 0.f; gcur = ge; }
-            ss += s[e]; qq += q[e];
-        }
-        atomicAdd(&sh[2 * gcur], ss); atomicAdd(&sh[2 * gcur + 1], qq);
+        for (int e = 0; e < 8; ++e) { ps[r0 * C + chunk * 8 + e] = s[e]; pq[r0 * C + chunk * 8 + e] = q[e]; }
     }
     __syncthreads();
     float* ws = p.stats_ws + ((int64_t)f * g.nsplit + split) * p.groups * 2;
-    for (int i = t; i < 2 * p.groups; i += blockDim.x) ws[i] = sh[i];
+    for (int grp = t; grp < p.groups; grp += blockDim.x) {
+        float ss = 0.f, qq = 0.f;
+        for (int r = 0; r < g.krows; ++r)
+            for (int c = grp * cpg; c < (grp + 1) * cpg; ++c) { ss += ps[r * C + c]; qq += pq[r * C + c]; }
+        ws[2 * grp] = ss; ws[2 * grp + 1] = qq;
+    }
 }
 
 // one block per frame (or one block when statistics pool over the clip): partials -> mean / rstd.
@@ -192,7 +191,7 @@ int gn_launch(const vv_groupnorm_params& p, hipStream_t st) {
     const int C = p.C0 + p.C1;
     const GNGeom g = gn_geom(p.HW, C);
     const int threads = (g.threads + 63) / 64 * 64;
-    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
+    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), (size_t)2 * g.krows * C * sizeof(float), st, p, g);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.pool_frames ? 1 : p.F), dim3(256), 0, st, p, g);
     hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
     VV_CHECK_LAUNCH("vv_groupnorm");
