@@ -26,7 +26,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
     constexpr int DK = (D + 31) / 32 * 32, DKC = DK / 8, KS = DK / 32;
     constexpr int DV = (D + 15) / 16 * 16, DVC = DV / 8, NDT = DV / 16;
     constexpr int KT = KVT / 16, US = KVT / 32;
-    constexpr int PK = DK * 2 + 16, PV = DV * 2 + 16;
+    constexpr int PK = DK * 2 + 32, PV = DV * 2 + ((DV * 2) % 64 == 0 ? 32 : 0);   // conflict-free ds_read_b128 / ds_read_b64_tr_b16 (bank model: tools/lds_bank_model.py)
     constexpr int NT = NW * 64;
     constexpr int KCH = (KVT * DKC + NT - 1) / NT, VCH = (KVT * DVC + NT - 1) / NT;
     constexpr int BQ = NW * QT * 16;
@@ -154,21 +154,31 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
             mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), (16 << 10) | 0x1f)));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mnew = fmaxf(mrun[j], mx);
-            const float alpha = __builtin_amdgcn_exp2f((mrun[j] - mnew) * c);
-            mrun[j] = mnew;
+            // the kernel is VALU-issue bound (every wave64 VALU op costs 4 cycles, v_exp 8): use packed fp32 ops for the
+            // exponent arguments, and skip the O^T / l rescale when no query row of this wave raised its maximum
+            const bool grew = __builtin_amdgcn_ballot_w64(mnew > mrun[j]) != 0;     // wave-uniform
             const float mc = mnew * c;
-            float ps = 0.f;
+            const vv_f32x2 c2 = {c, c}, nmc2 = {-mc, -mc};
+            vv_f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(sacc[kt][j][r] * c - mc);
-                    sacc[kt][j][r] = e;
-                    ps += e;
+                for (int r = 0; r < 4; r += 2) {
+                    const vv_f32x2 a2 = __builtin_elementwise_fma((vv_f32x2){sacc[kt][j][r], sacc[kt][j][r + 1]}, c2, nmc2);   // v_pk_fma_f32
+                    const float e0 = __builtin_amdgcn_exp2f(a2.x), e1 = __builtin_amdgcn_exp2f(a2.y);
+                    sacc[kt][j][r] = e0; sacc[kt][j][r + 1] = e1;
+                    ps2 += (vv_f32x2){e0, e1};                                   // v_pk_add_f32
                 }
-            lrun[j] = lrun[j] * alpha + ps;
+            const float ps = ps2.x + ps2.y;
+            if (grew) {
+                const float alpha = __builtin_amdgcn_exp2f((mrun[j] - mnew) * c);
+                lrun[j] = lrun[j] * alpha + ps;
 #pragma unroll
-            for (int d = 0; d < NDT; ++d) oacc[d][j] *= alpha;
+                for (int d = 0; d < NDT; ++d) oacc[d][j] *= alpha;
+            } else {
+                lrun[j] += ps;
+            }
+            mrun[j] = mnew;
 #pragma unroll
             for (int u = 0; u < US; ++u)
                 pb[u][j] = make_uint4(pack2<T>(sacc[2 * u][j][0], sacc[2 * u][j][1]), pack2<T>(sacc[2 * u][j][2], sacc[2 * u][j][3]),
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
 template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1>
 int attn_launch(const vv_attn_params& p, hipStream_t st) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
-    constexpr int PK = DK * 2 + 16, PV = DV * 2 + 16;
+    constexpr int PK = DK * 2 + 32, PV = DV * 2 + ((DV * 2) % 64 == 0 ? 32 : 0);   // conflict-free ds_read_b128 / ds_read_b64_tr_b16 (bank model: tools/lds_bank_model.py)
     constexpr int BQ = NW * QT * 16;
     const size_t lds = (size_t)KVT * (PK + PV);
     const int nqt = (p.Nq + BQ - 1) / BQ;
@@ -254,6 +264,9 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
             if (var == 2) return attn_launch<T, D, 2, 64, 4, true, 4>(p, st);      // capped at 128 VGPRs (4 waves/SIMD)
             if (var == 3) return attn_launch<T, D, 2, 64, 4, false, 4>(p, st);     // both
             if (var == 4) return attn_launch<T, D, 2, 32, 4, true, 4>(p, st);      // 32-key tiles, capped
+            if (var == 5) return attn_launch<T, D, 1, 64, 4, true, 1>(p, st);      // 16 queries per wave, 64 per block
+            if (var == 6) return attn_launch<T, D, 1, 64, 8, true, 1>(p, st);      // 16 queries per wave, 8 waves = 128 per block
+            if (var == 7) return attn_launch<T, D, 2, 64, 8, true, 1>(p, st);      // 32 queries per wave, 8 waves = 256 per block
         }
         return attn_launch<T, D, 2, 64, 4, true>(p, st);
     }
