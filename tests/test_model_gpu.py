@@ -183,3 +183,46 @@ def test_drop_in_computes_flow_prior_when_none_supplied(gpu):
     _log("drop_in_with_flow_prior[tiny,fp16]", max_abs_u8=int(du.max()), frac_gt2=float((du > 2).mean()))
     assert (du > 2).mean() <= 0.01
     diffuerase.configure(None)
+
+
+def test_full_architecture_one_step(gpu):
+    """The FULL SD-1.5 UNet + BrushNet + motion modules (320/640/1280/1280, 8 heads, d = 40/80/160) and the full SD-VAE
+    (128/256/512/512, mid attention d = 512) at a small spatial size, fp16 operands, against the fp32 oracle with the same
+    2.4 B seeded weights: this is the architecture bench.py times, only the image is smaller."""
+    from oracle import model_ref as M
+    from videovanish_amd import hip
+    from videovanish_amd.nn import Ctx
+    from videovanish_amd.unet import Denoiser
+    from videovanish_amd.vae import VAE
+    ucfg, vcfg = UNetConfig(), VAEConfig()
+    P = M.Params(0)
+    g = torch.Generator().manual_seed(13)
+    Fr, h, w = 3, 8, 10
+    lat = torch.randn(Fr, 4, h, w, generator=g)
+    cond = torch.randn(Fr, 4, h, w, generator=g)
+    mask = (torch.rand(Fr, h * 8, w * 8, generator=g) > 0.6).to(torch.uint8) * 255
+    m_lat = torch.nn.functional.interpolate((mask > 0).float()[:, None], size=(h, w), mode="nearest")
+    text = M.text_states(P, ucfg)
+    with torch.no_grad():
+        ref = M.unet_forward(P, lat, 441, text, ucfg, M.brushnet_forward(P, torch.cat([lat, cond, m_lat], 1), 441, text, ucfg))
+    ctx = Ctx("cuda:0", "fp16", 0)
+    den = Denoiser(ctx, ucfg, ctx.src.normal("text_states", (1, ucfg.text_len, ucfg.cross_dim)))
+    eps = den(_nhwc(lat).to(gpu), _nhwc(cond).to(gpu), mask.to(gpu), 441, Fr, h, w, h * 8, w * 8)
+    emax, erms = _rel(eps.cpu().permute(0, 3, 1, 2), ref)
+    _log("denoiser[FULL,fp16]", rel_max=emax, rel_rms=erms)
+    assert emax <= 6e-3 and erms <= 4e-3
+    del den
+    P.cache.clear()
+    fr = torch.randint(0, 256, (1, 64, 64, 3), generator=g, dtype=torch.uint8)
+    img = fr.float().permute(0, 3, 1, 2) / 127.5 - 1.0
+    with torch.no_grad():
+        zr = M.vae_encode(P, img, vcfg)
+        dr = M.vae_decode(P, zr, vcfg)
+    vae = VAE(ctx, vcfg)
+    img8, _ = hip.preprocess(ctx.dt, fr.to(gpu), None, want_masked=False)
+    z = vae.encode(img8.view(64 * 64, 8), 1, 64, 64)
+    zmax, _ = _rel(z.cpu().permute(0, 3, 1, 2), zr)
+    d = vae.decode(_nhwc(zr).to(gpu), 1, 8, 8)
+    dmax, _ = _rel(d.cpu().permute(0, 3, 1, 2), dr)
+    _log("vae[FULL,fp16]", enc_rel_max=zmax, dec_rel_max=dmax)
+    assert zmax <= 4e-3 and dmax <= 4e-3

@@ -30,6 +30,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
     constexpr int NT = NW * 64;
     constexpr int KCH = (KVT * DKC + NT - 1) / NT, VCH = (KVT * DVC + NT - 1) / NT;
     constexpr int BQ = NW * QT * 16;
+    // spare zero-padded V column (d = 40 -> 48): put 1.0 there, then row D of O^T accumulates sum_k P = the softmax
+    // denominator on the MATRIX pipe instead of 16 packed adds per tile on the (issue-bound) VALU
+    constexpr bool ONES = DV > D;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sK = smem;
     unsigned char* sV = smem + KVT * PK;
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
             const int row = idx / DVC, ch = idx - row * DVC;
             const int key = kv0 + row;
             rv[i] = (idx < KVT * DVC && key < p.Nkv && ch * 8 < D) ? *(const uint4*)(Vp + (int64_t)key * p.v_rs + ch * 8) : make_uint4(0, 0, 0, 0);
+            if (ONES && ch * 8 == D) rv[i].x = (unsigned)T::from_f32(1.0f);        // V[key][D] = 1 (low half-word), rest of the pad stays 0
         }
     };
     auto store_kv = [&]() {
@@ -167,16 +171,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
                     const vv_f32x2 a2 = __builtin_elementwise_fma((vv_f32x2){sacc[kt][j][r], sacc[kt][j][r + 1]}, c2, nmc2);   // v_pk_fma_f32
                     const float e0 = __builtin_amdgcn_exp2f(a2.x), e1 = __builtin_amdgcn_exp2f(a2.y);
                     sacc[kt][j][r] = e0; sacc[kt][j][r + 1] = e1;
-                    ps2 += (vv_f32x2){e0, e1};                                   // v_pk_add_f32
+                    if (!ONES) ps2 += (vv_f32x2){e0, e1};                      // v_pk_add_f32
                 }
             const float ps = ps2.x + ps2.y;
             if (grew) {
                 const float alpha = __builtin_amdgcn_exp2f((mrun[j] - mnew) * c);
-                lrun[j] = lrun[j] * alpha + ps;
+                if (!ONES) lrun[j] = lrun[j] * alpha + ps;
 #pragma unroll
                 for (int d = 0; d < NDT; ++d) oacc[d][j] *= alpha;
             } else {
-                lrun[j] += ps;
+                if (!ONES) lrun[j] += ps;
             }
             mrun[j] = mnew;
 #pragma unroll
@@ -211,9 +215,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
     // ---- finalize: O[q][d] = O^T[d][q] / l
 #pragma unroll
     for (int j = 0; j < QT; ++j) {
-        float l = lrun[j];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        float l;
+        if (ONES) {
+            // denominator = O^T[D][q]: register (D % 16) % 4 of d-tile D/16 on lane group (D % 16) / 4
+            l = __shfl(oacc[D / 16][j][(D % 16) % 4], ((D % 16) / 4) * 16 + li);
+        } else {
+            l = lrun[j];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
         const float inv = 1.0f / l;
         const int q = q0 + j * 16 + li;
         if (q < p.Nq) {
