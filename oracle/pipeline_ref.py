@@ -83,7 +83,7 @@ def denoise_chunk(P, img, m, prior, noise, steps, ucfg, vcfg, scheduler="ddim", 
             lat = M.ddim_step(lat, eps, t, steps, ac)
         else:
             lat = M.tcd_step(lat, eps, t, ts[i + 1] if i + 1 < len(ts) else None, ac,
-                             tcd_noise[i] if tcd_noise is not None else torch.zeros_like(lat))
+                             tcd_noise[i] if (tcd_noise is not None and i < len(tcd_noise)) else torch.zeros_like(lat))
     if trace is not None:
         trace.update(lat_final=lat.clone())
     dec = M.vae_decode(P, lat, vcfg)
@@ -114,7 +114,10 @@ def diffueraser_forward(frames, masks2d, priori, max_img_size=960, steps=50, chu
             m = torch.from_numpy(np.stack(mk[s:e]) > 0).float()[:, None]
             f = 2 ** (len(vcfg.block_out) - 1)                # VAE down-factor (8 for the SD VAE)
             noise = chunk_noise(seed, ci, (e - s, 4, H // f, W // f))
-            dec = denoise_chunk(P, img, m, prior, noise, steps, ucfg, vcfg, scheduler)
+            tcd_noise = None
+            if scheduler == "tcd":
+                tcd_noise = [chunk_noise(seed + 104729 * (i + 1), ci, (e - s, 4, H // f, W // f)) for i in range(steps - 1)]
+            dec = denoise_chunk(P, img, m, prior, noise, steps, ucfg, vcfg, scheduler, tcd_noise=tcd_noise)
             w = torch.from_numpy(wts[ci])[:, None, None, None]
             acc[s:e] = (acc[s:e] * (1.0 - w)) + (dec * w)        # sequential cross-fade, fp32, chunk order
     out = []

@@ -210,7 +210,7 @@ def test_full_architecture_one_step(gpu):
     eps = den(_nhwc(lat).to(gpu), _nhwc(cond).to(gpu), mask.to(gpu), 441, Fr, h, w, h * 8, w * 8)
     emax, erms = _rel(eps.cpu().permute(0, 3, 1, 2), ref)
     _log("denoiser[FULL,fp16]", rel_max=emax, rel_rms=erms)
-    assert emax <= 6e-3 and erms <= 4e-3
+    assert emax <= 4e-3 and erms <= 3e-3
     del den
     P.cache.clear()
     fr = torch.randint(0, 256, (1, 64, 64, 3), generator=g, dtype=torch.uint8)
@@ -226,3 +226,64 @@ def test_full_architecture_one_step(gpu):
     dmax, _ = _rel(d.cpu().permute(0, 3, 1, 2), dr)
     _log("vae[FULL,fp16]", enc_rel_max=zmax, dec_rel_max=dmax)
     assert zmax <= 4e-3 and dmax <= 4e-3
+
+
+def test_reference_default_two_step_tcd(gpu):
+    """The reference's own default (diffuerase.py:37: ckpt forced to "2-Step" => 2 TCD steps, gamma 0.3, seeded re-noising)."""
+    import diffuerase
+    from oracle import pipeline_ref as R
+    T, H, W = 4, 32, 40
+    frames, masks, prior = _clip(T, H, W, seed=55)
+    run = RunConfig(steps=50, chunk=4, overlap=2, seed=9, dtype="fp16", unet=TINY_UNET, vae=TINY_VAE)
+    diffuerase.configure(run)
+    out = diffuerase.run_infill_on_frames(frames, masks, mask_dilation_iter=1, propainer_frames=prior)      # all reference defaults
+    ref = R.run_infill_on_frames(frames, masks, 1, prior, steps=2, scheduler="tcd", chunk=4, overlap=2, seed=9, ucfg=TINY_UNET, vcfg=TINY_VAE)
+    du = np.abs(np.stack(out).astype(int) - np.stack(ref).astype(int))
+    _log("drop_in_default_tcd2[tiny,fp16]", max_abs_u8=int(du.max()), frac_differ=float((du > 0).mean()))
+    assert du.max() <= 3
+    diffuerase.configure(None)
+
+
+def test_config_c1_geometry_vs_oracle(gpu):
+    """BASELINE config 1 geometry (8 frames, 256x256, 10 DDIM steps, one 8-frame clip) end to end against the oracle.
+    The oracle needs ~45 TFLOP at full width for this config (minutes to hours on host cores), so the width is the tiny
+    config; the full-width architecture is checked by test_full_architecture_one_step."""
+    from oracle import pipeline_ref as R
+    from videovanish_amd.pipeline import DiffuEraserHIP
+    T, H, W = 8, 256, 256
+    frames, masks, prior = _clip(T, H, W, seed=1234)
+    m2d = [np.any(m > 0, axis=2).astype(np.uint8) * 255 for m in masks]
+    kw = dict(steps=10, chunk=32, overlap=8, seed=42)
+    ref = R.diffueraser_forward(frames, m2d, prior, ucfg=TINY_UNET, vcfg=TINY_VAE, return_float=True, **kw)
+    model = DiffuEraserHIP(RunConfig(dtype="fp16", unet=TINY_UNET, vae=TINY_VAE, **kw))
+    got, (lo, hi) = model.forward(frames, m2d, prior, return_float=True)
+    err = np.abs(got - ref)
+    _log("c1_geometry[tiny,fp16,10 steps]", max_abs=float(err.max()), mean_abs=float(err.mean()))
+    assert (lo, hi) == (0, T) and err.max() <= 5e-3
+
+
+def test_config_c2_geometry_properties(gpu):
+    """BASELINE config 2 geometry at FULL width: 64 frames of 848x480 (latent 60x106 -> 30x53 -> 15x27 -> 8x14: odd sizes on
+    the way down and up), three 32-frame chunks (0/24/32) blended locally, 1 DDIM step.  No oracle at this size: checks the
+    size-independent properties -- finite output, bit-reproducible, pixels far from the mask untouched by compose."""
+    from videovanish_amd.pipeline import DiffuEraserHIP, chunk_plan
+    T, H, W = 64, 480, 848
+    rng = np.random.default_rng(7)
+    frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(T)]
+    m2d = []
+    for t in range(T):
+        m = np.zeros((H, W), np.uint8)
+        m[160:280, 200 + 2 * t: 412 + 2 * t] = 255
+        m2d.append(m)
+    assert chunk_plan(T, 32, 8) == [(0, 32), (24, 56), (32, 64)]
+    model = DiffuEraserHIP(RunConfig(steps=1, chunk=32, overlap=8, seed=1, dtype="bf16"))
+    a = model.forward(frames, m2d, frames, steps=1)
+    b = model.forward(frames, m2d, frames, steps=1)
+    A, B = np.stack(a), np.stack(b)
+    assert A.shape == (T, H, W, 3) and A.dtype == np.uint8 and np.array_equal(A, B)
+    far = np.ones((T, H, W), bool)
+    for t in range(T):
+        far[t, 160 - 12:280 + 12, 200 + 2 * t - 12: 412 + 2 * t + 12] = False
+    assert (A[far] == np.stack(frames)[far]).all()
+    inside = np.stack(m2d) > 0
+    assert (A[inside] != np.stack(frames)[inside]).mean() > 0.5

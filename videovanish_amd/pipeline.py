@@ -280,8 +280,13 @@ class DiffuEraserHIP:
             cb = None
             if progress is not None:
                 cb = lambda i, n, k=k: progress(k * n + i, n_my * n)
+            tcd_noise = None
+            if scheduler == "tcd":      # TCD re-noising between steps: explicit, seeded per (chunk, step) like the initial noise
+                nst = steps or run.steps
+                tcd_noise = [chunk_noise(run.seed + 104729 * (i + 1), ci, (e - s, 4, H // f, W // f)).permute(0, 2, 3, 1).contiguous().to(dev)
+                             for i in range(nst - 1)]
             pending[ci] = self.denoise_chunk(fr[s - base:e - base], pr[s - base:e - base], mk[s - base:e - base], noise, steps=steps,
-                                             scheduler=scheduler, progress=cb)
+                                             scheduler=scheduler, tcd_noise=tcd_noise, progress=cb)
         accT, (lo, hi) = exchange_and_blend(plan, wts, owner, chunk_rank, rank, world, pending, (H, W), dev)
         if accT is None:
             return None, (0, 0)
