@@ -53,7 +53,8 @@ def cpu_baseline(H, W, steps, chunk, overlap, sample_hw=(192, 256), vae_hw=(96, 
     from videovanish_amd import flops
     from videovanish_amd.config import UNetConfig, VAEConfig
     ucfg, vcfg = UNetConfig(), VAEConfig()
-    cores = torch.get_num_threads()
+    cores = min(32, os.cpu_count() or 1)      # a modest pool: one thread per core of a 128+-core host is SLOWER on this small-tensor oracle
+    torch.set_num_threads(cores)
     P = M.Params(0)
     sh, sw = sample_hw
     h, w = sh // 8, sw // 8

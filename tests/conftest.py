@@ -9,6 +9,13 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    # the oracle is small-tensor fp32 torch: on the many-core GPU box the default (one thread per core) is several times
+    # SLOWER than a modest pool because of fork/join overhead
+    try:
+        import torch
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+    except Exception:
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 

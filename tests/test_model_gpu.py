@@ -250,12 +250,13 @@ def test_config_c1_geometry_vs_oracle(gpu):
     config; the full-width architecture is checked by test_full_architecture_one_step."""
     from oracle import pipeline_ref as R
     from videovanish_amd.pipeline import DiffuEraserHIP
+    C1_VAE = VAEConfig(block_out=(32, 64, 64, 64), layers_per_block=1, groups=8)     # 4 levels: the real 8x latent factor (32x32 latents)
     T, H, W = 8, 256, 256
     frames, masks, prior = _clip(T, H, W, seed=1234)
     m2d = [np.any(m > 0, axis=2).astype(np.uint8) * 255 for m in masks]
     kw = dict(steps=10, chunk=32, overlap=8, seed=42)
-    ref = R.diffueraser_forward(frames, m2d, prior, ucfg=TINY_UNET, vcfg=TINY_VAE, return_float=True, **kw)
-    model = DiffuEraserHIP(RunConfig(dtype="fp16", unet=TINY_UNET, vae=TINY_VAE, **kw))
+    ref = R.diffueraser_forward(frames, m2d, prior, ucfg=TINY_UNET, vcfg=C1_VAE, return_float=True, **kw)
+    model = DiffuEraserHIP(RunConfig(dtype="fp16", unet=TINY_UNET, vae=C1_VAE, **kw))
     got, (lo, hi) = model.forward(frames, m2d, prior, return_float=True)
     err = np.abs(got - ref)
     _log("c1_geometry[tiny,fp16,10 steps]", max_abs=float(err.max()), mean_abs=float(err.mean()))
