@@ -158,6 +158,8 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
     if PROFILE is not None:
         Npad = weight.shape[0]
         tile = "128x128" if epilogue == EPI_GEGLU else ("128x160" if Npad % 160 == 0 else ("128x128" if Npad % 128 == 0 else "128x16"))
+        if os.environ.get("VV_PROFILE_SHAPES"):
+            tile = f"M{M},N{N},K{K}|" + tile
         key = f"conv_gemm[{tile},{'f32in' if x0.dtype == torch.float32 else 'h16in'},k{ksize}{'x%d' % ksize_w if ksize_w and ksize_w != ksize else ''}]"
         es = x0.element_size()
         nbytes = F * Hin * Win * (C0 + C1) * es + N * K * 2 + M * nout * out.element_size() + sum(
@@ -202,6 +204,8 @@ def attention(dtype, q, k, v, out, *, B, heads, Nq, Nkv, D, q_bs, k_bs, v_bs, o_
                    q_bs=q_bs, k_bs=k_bs, v_bs=v_bs, o_bs=o_bs, q_rs=q_rs, k_rs=k_rs, v_rs=v_rs, o_rs=o_rs, B=B, heads=heads, Nq=Nq,
                    Nkv=Nkv, D=D, scale=float(D) ** -0.5)
     kind = "temporal" if (Nq <= 32 and Nkv <= 32) else ("cross" if Nkv < 128 and Nq != Nkv else "spatial")
+    if os.environ.get("VV_PROFILE_SHAPES"):
+        kind = f"B{B},N{Nq}|" + kind
     with _Prof(f"attention[{kind},d{D}]", 4.0 * B * heads * Nq * Nkv * D, 2 * B * heads * D * (2 * Nq + 2 * Nkv)):
         _check(lib().vv_attention(C.byref(p), dtype, _stream()), "vv_attention")
     return out
