@@ -182,6 +182,7 @@ int vv_prop_combine(const float* orig, const float* a, const float* b, const uin
                     int H, int W, const float* mean3, uint8_t* out, uint8_t* filled, void* stream);
 int vv_masked_sum_u8(const uint8_t* frame, const uint8_t* hole, int64_t npix, unsigned long long* sums4, void* stream);
 int vv_u8_to_f32(const uint8_t* in, float* out, int64_t n, void* stream);
+int vv_u8_is_zero(const uint8_t* in, uint8_t* out, int64_t n, void* stream);                     /* known map = (hole == 0) */
 int vv_raft_prep(const uint8_t* img, int64_t npix, void* out8, int dtype, void* stream);           /* u8 RGB -> h16 [..][8], 2x/255-1 */
 
 /* model-side pre/post */

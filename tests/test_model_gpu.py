@@ -288,3 +288,35 @@ def test_config_c2_geometry_properties(gpu):
     assert (A[far] == np.stack(frames)[far]).all()
     inside = np.stack(m2d) > 0
     assert (A[inside] != np.stack(frames)[inside]).mean() > 0.5
+
+
+@pytest.mark.parametrize("T,H,W,mx,mask_kind", [(1, 32, 40, 960, "box"), (33, 24, 32, 960, "box"), (3, 37, 53, 32, "box"),
+                                                (2, 32, 32, 960, "none"), (2, 32, 32, 960, "all")])
+def test_edge_cases_vs_oracle(gpu, T, H, W, mx, mask_kind):
+    """Ragged / degenerate inputs through the drop-in entry point: a single frame (1-frame clip), T = chunk+1 (31-frame
+    overlap), a size that is not a multiple of 8 and needs the resize path, an empty mask, an all-ones mask."""
+    import diffuerase
+    from oracle import pipeline_ref as R
+    rng = np.random.default_rng(T * 1000 + H)
+    frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(T)]
+    masks = []
+    for t in range(T):
+        m = np.zeros((H, W, 3), np.uint8)
+        if mask_kind == "box":
+            m[H // 4: H // 2, W // 4: W // 2, t % 3] = 200
+        elif mask_kind == "all":
+            m[:] = 255
+        masks.append(m)
+    prior = [f.copy() for f in frames]
+    run = RunConfig(steps=2, chunk=32, overlap=8, seed=11, dtype="fp16", unet=TINY_UNET, vae=TINY_VAE)
+    diffuerase.configure(run)
+    out = diffuerase.run_infill_on_frames(frames, masks, mask_dilation_iter=2, propainer_frames=prior, max_img_size=mx,
+                                          num_inference_steps=2, scheduler="ddim")
+    ref = R.run_infill_on_frames(frames, masks, 2, prior, max_img_size=mx, steps=2, chunk=32, overlap=8, seed=11, ucfg=TINY_UNET, vcfg=TINY_VAE)
+    assert len(out) == T and all(o.shape == (H, W, 3) for o in out)
+    du = np.abs(np.stack(out).astype(int) - np.stack(ref).astype(int))
+    _log(f"edge[{T}x{H}x{W},mx{mx},{mask_kind}]", max_abs_u8=int(du.max()), frac_differ=float((du > 0).mean()))
+    assert du.max() <= 3
+    if mask_kind == "none":
+        assert np.array_equal(np.stack(out), np.stack(frames))          # nothing masked + keep_unmasked_original => identity
+    diffuerase.configure(None)

@@ -222,6 +222,7 @@ __global__ void masked_sum_kernel(const uint8_t* frame, const uint8_t* hole, int
         if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sums[k], v);
     }
 }
+__global__ void u8_is_zero_kernel(const uint8_t* in, uint8_t* out, int64_t n) { GRID_STRIDE(i, n) out[i] = in[i] == 0 ? 1 : 0; }
 __global__ void u8_to_f32_kernel(const uint8_t* in, float* out, int64_t n) { GRID_STRIDE(i, n) out[i] = (float)in[i]; }
 // image [T][H][W][3] u8 -> h16 [T][H][W][8] scaled to [-1,1] as 2*(x/255)-1 (RAFT input)
 template <typename T>
@@ -333,6 +334,13 @@ extern "C" int vv_masked_sum_u8(const uint8_t* frame, const uint8_t* hole, int64
     if (hipMemsetAsync(sums4, 0, 4 * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) VV_FAIL(VV_E_LAUNCH, "vv_masked_sum_u8: memset failed");
     hipLaunchKernelGGL(masked_sum_kernel, grid_for(npix), dim3(EB), 0, (hipStream_t)stream, frame, hole, npix, sums4);
     VV_CHECK_LAUNCH("vv_masked_sum_u8");
+    return VV_OK;
+}
+
+extern "C" int vv_u8_is_zero(const uint8_t* in, uint8_t* out, int64_t n, void* stream) {
+    if (!in || !out || n <= 0) VV_FAIL(VV_E_ARG, "vv_u8_is_zero: bad args");
+    hipLaunchKernelGGL(u8_is_zero_kernel, grid_for(n), dim3(EB), 0, (hipStream_t)stream, in, out, n);
+    VV_CHECK_LAUNCH("vv_u8_is_zero");
     return VV_OK;
 }
 

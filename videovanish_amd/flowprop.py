@@ -38,7 +38,7 @@ def propagate(frames_u8, masks_u8, fw, bw):
 
     def sweep(order, flow_to_nb, flow_from_nb):
         cur = img.clone()
-        known = (hole == 0).to(torch.uint8)              # byte-map initialisation (memory plumbing)
+        known = hip.u8_is_zero(hole)
         filled = torch.zeros((T, H, W), dtype=torch.uint8, device=dev)
         for t, nb, k in order:
             valid = hip.fb_valid(flow_to_nb[k], flow_from_nb[k])

@@ -73,7 +73,7 @@ EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name
            "vv_mask_collapse_dilate", "vv_resize_bilinear_u8", "vv_resize_nearest_u8", "vv_feather_composite", "vv_chamfer_dt",
            "vv_preprocess", "vv_brushnet_input", "vv_pad_channels", "vv_decode_blend", "vv_blur_compose",
            "vv_avgpool2_f32", "vv_corr_lookup", "vv_raft_ctx_split", "vv_raft_flow_prep", "vv_gru_rh", "vv_gru_update", "vv_add_flow",
-           "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32",
+           "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32", "vv_u8_is_zero",
            "vv_raft_prep"]
 
 
@@ -417,6 +417,13 @@ def u8_to_f32(x):
     _need_cuda(x)
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     _check(lib().vv_u8_to_f32(_p(x), _p(out), C.c_int64(x.numel()), _stream()), "vv_u8_to_f32")
+    return out
+
+
+def u8_is_zero(x):
+    _need_cuda(x)
+    out = torch.empty_like(x)
+    _check(lib().vv_u8_is_zero(_p(x), _p(out), C.c_int64(x.numel()), _stream()), "vv_u8_is_zero")
     return out
 
 

@@ -147,7 +147,7 @@ class RAFT:
         Returns flow 1->2, fp32 [8h, 8w, 2]."""
         ctx, dt, dev = self.ctx, self.ctx.dt, f1.device
         M = h * w
-        f1_16, f2_16 = f1.to(ctx.h16), f2.to(ctx.h16)          # dtype cast = memory plumbing (A/B operands are h16 anyway)
+        f1_16, f2_16 = hip.pad_channels(dt, f1, 256), hip.pad_channels(dt, f2, 256)      # fp32 -> h16 MFMA operands
         pyr = self.corr_pyramid(f1_16, f2_16, h, w)
         net = torch.empty((M, 128), dtype=torch.float32, device=dev)
         net16 = torch.empty((M, 128), dtype=ctx.h16, device=dev)
