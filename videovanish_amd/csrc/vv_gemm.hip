@@ -30,17 +30,24 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gp_t)gptr, (lp_t)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int WR, int WC, int MT, int NT, int MODE, int SPLIT>
+template <typename T, int WR, int WC, int MT, int NT, int MODE, int SPLIT, int BKT>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params p, const int M, const int tilesM, const int tilesN) {
     constexpr int BM = WR * MT * 16, BN = WC * NT * 16;
-    constexpr int AR = BM / 32;                 // A rows staged per thread
-    constexpr int BCH = (BN * 8 + 255) / 256;   // B chunks staged per thread
+    constexpr int CH = BKT / 8;                 // 16-byte chunks per tile row (8 for a 64-wide k tile, 4 for 32)
+    constexpr int SH = CH == 8 ? 3 : 2;         // log2(CH)
+    constexpr int RP = BKT * 2;                 // LDS row pitch in bytes
+    constexpr int RPB = 256 >> SH;              // tile rows filled by one 256-thread pass (32 or 64)
+    constexpr int AR = BM / RPB;                // A chunks staged per thread
+    constexpr int BCH = (BN + RPB - 1) / RPB;   // B chunks staged per thread
+    constexpr int KS = BKT / 32;                // MFMA k steps per tile
     constexpr bool AF32 = MODE == MODE_F32, FAST = MODE == MODE_FAST;
-    __shared__ __attribute__((aligned(16))) unsigned char sA0[SPLIT == 0 ? 16 : BM * 128];
-    __shared__ __attribute__((aligned(16))) unsigned char sA1[SPLIT == 1 ? BM * 128 : 16];
-    __shared__ __attribute__((aligned(16))) unsigned char sB0[SPLIT == 0 ? 16 : BN * 128];
-    __shared__ __attribute__((aligned(16))) unsigned char sB1[SPLIT == 1 ? BN * 128 : 16];
-    __shared__ __attribute__((aligned(16))) unsigned char sAB[SPLIT == 0 ? 2 * (BM + BN) * 128 : 16];
+    // XOR swizzle of the chunk index that makes the ds_read_b128 operand reads conflict free (tools/lds_bank_model.py)
+    auto SWZ = [](int row) { return CH == 8 ? (row & 7) : ((row >> 1) & 3); };
+    __shared__ __attribute__((aligned(16))) unsigned char sA0[SPLIT == 0 ? 16 : BM * RP];
+    __shared__ __attribute__((aligned(16))) unsigned char sA1[SPLIT == 1 ? BM * RP : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char sB0[SPLIT == 0 ? 16 : BN * RP];
+    __shared__ __attribute__((aligned(16))) unsigned char sB1[SPLIT == 1 ? BN * RP : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char sAB[SPLIT == 0 ? 2 * (BM + BN) * RP : 16];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave / WC, wc = wave % WC;
@@ -58,14 +65,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
     const int Cin = p.C0 + p.C1;
     const int KW = p.ksize_w > 0 ? p.ksize_w : p.ksize;
     const int HWo = p.Hout * p.Wout;
-    const int c8 = t & 7;                      // this thread's 16-byte slot inside the 64-wide k tile
-    const int rsw = (t >> 3) & 7;              // (row & 7) of every row this thread stages (rows differ by 32)
+    const int c8 = t & (CH - 1);               // this thread's 16-byte slot inside the k tile row
+    const int rsw = SWZ(t >> SH);              // swizzle key of every row this thread stages (rows differ by RPB, key unchanged)
     // per-row gather state
     int rpix[AR], ryb[AR], rxb[AR], rfr[FAST ? AR : 1];
     bool rv[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int m = m0 + (t >> 3) + 32 * i;
+        const int m = m0 + (t >> SH) + RPB * i;
         rv[i] = m < M;
         const int mm = rv[i] ? m : 0;
         const int f = mm / HWo, rem = mm - f * HWo;
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
 
     // ---- FAST: LDS-DMA fill of k tile kt (lies inside one tap and one source) into the given buffers
     auto dma_tile = [&](int kt, unsigned char* bufA, unsigned char* bufB) {
-        const int k0 = kt * BK;
+        const int k0 = kt * BKT;
         const int tap = k0 / Cin;
         int cc = k0 - tap * Cin;
         const int ky = tap / KW, kx = tap - ky * KW;
@@ -100,18 +107,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
             int pix = rpix[i] + dpix;
             if (resize) pix = (rfr[i] * p.Hin + (yv * p.Hin) / p.Hv) * p.Win + (xv * p.Win) / p.Wv;   // fused nearest upsample
             const void* g = ok ? (const void*)(src + ((int64_t)pix * Cs + csrc) * 2) : (const void*)g_zero_page;
-            glds16(g, a + i * 32 * 128);
+            glds16(g, a + i * RPB * RP);
         }
         unsigned char* b = bufB + wave * 1024;
-        const unsigned short* wrow = wbase + (int64_t)(n0 + (t >> 3)) * p.Kpad + k0 + ((c8 ^ rsw) << 3);
+        const unsigned short* wrow = wbase + (int64_t)(n0 + (t >> SH)) * p.Kpad + k0 + ((c8 ^ rsw) << 3);
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
-            if (BN * 8 % 256 == 0 || t + 256 * i < BN * 8) glds16(wrow + (int64_t)(32 * i) * p.Kpad, b + i * 32 * 128);
+            if (BN % RPB == 0 || (t >> SH) + RPB * i < BN) glds16(wrow + (int64_t)(RPB * i) * p.Kpad, b + i * RPB * RP);
         }
     };
     // ---- generic: register staged
     auto load_tile = [&](int kt) {
-        const int k = kt * BK + c8 * 8;
+        const int k = kt * BKT + c8 * 8;
         const bool kvalid = k < p.K;
         const int tap = kvalid ? k / Cin : 0;
         int cc = k - tap * Cin;
@@ -136,32 +143,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
         }
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
-            const int ch = t + 256 * i;
-            if (BN * 8 % 256 == 0 || ch < BN * 8) {
-                const int row = ch >> 3, c = ch & 7;
-                rb[i] = *(const uint4*)(wbase + (int64_t)(n0 + row) * p.Kpad + kt * BK + c * 8);
-            }
+            const int row = (t >> SH) + RPB * i;
+            if (BN % RPB == 0 || row < BN) rb[i] = *(const uint4*)(wbase + (int64_t)(n0 + row) * p.Kpad + kt * BKT + c8 * 8);
         }
     };
     auto store_tile = [&](unsigned char* a, unsigned char* b) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const int row = (t >> 3) + 32 * i;
+            const int row = (t >> SH) + RPB * i;
             uint4 v;
             if (AF32) {
                 float f[8];
                 *(uint4*)&f[0] = ra[i]; *(uint4*)&f[4] = ra2[i];
                 v = pack8<T>(f);
             } else v = ra[i];
-            *(uint4*)(a + row * 128 + ((c8 ^ (row & 7)) << 4)) = v;
+            *(uint4*)(a + row * RP + ((c8 ^ SWZ(row)) << 4)) = v;
         }
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
-            const int ch = t + 256 * i;
-            if (BN * 8 % 256 == 0 || ch < BN * 8) {
-                const int row = ch >> 3, c = ch & 7;
-                *(uint4*)(b + row * 128 + ((c ^ (row & 7)) << 4)) = rb[i];
-            }
+            const int row = (t >> SH) + RPB * i;
+            if (BN % RPB == 0 || row < BN) *(uint4*)(b + row * RP + ((c8 ^ SWZ(row)) << 4)) = rb[i];
         }
     };
 
@@ -171,27 +172,27 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.Kpad / BK;
+    const int nk = p.Kpad / BKT;
     const int lr = lane & 15, lq = lane >> 4;
     // one k tile: prefetch the next tile into (nA,nB), run the MFMAs on (cA,cB), then barrier
     auto k_step = [&](int kt, const unsigned char* cA, const unsigned char* cB, unsigned char* nA, unsigned char* nB) {
         const bool more = kt + 1 < nk;
         if (more) { if (FAST) dma_tile(kt + 1, nA, nB); else load_tile(kt + 1); }
-        const unsigned char* a = cA + (wr * MT * 16) * 128;
-        const unsigned char* b = cB + (wc * NT * 16) * 128;
+        const unsigned char* a = cA + (wr * MT * 16) * RP;
+        const unsigned char* b = cB + (wc * NT * 16) * RP;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < KS; ++s) {
             uint4 af[MT], bf[NT];
             const int ch = s * 4 + lq;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int row = i * 16 + lr;
-                af[i] = *(const uint4*)(a + row * 128 + ((ch ^ (row & 7)) << 4));
+                af[i] = *(const uint4*)(a + row * RP + ((ch ^ SWZ(row)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int row = j * 16 + lr;
-                bf[j] = *(const uint4*)(b + row * 128 + ((ch ^ (row & 7)) << 4));
+                bf[j] = *(const uint4*)(b + row * RP + ((ch ^ SWZ(row)) << 4));
             }
             // swapped operands: D[n-in-tile][m-in-tile] -> lane (lr,lq) owns row m = ..+lr, channels n = ..+4*lq+{0..3}
 #pragma unroll
@@ -220,13 +221,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
             if (kt + 1 < nk) k_step(kt + 1, sA1, sB1, sA0, sB0);
         }
     } else {
-        unsigned char* a2 = sAB; unsigned char* b2 = sAB + 2 * BM * 128;
+        unsigned char* a2 = sAB; unsigned char* b2 = sAB + 2 * BM * RP;
         if (FAST) dma_tile(0, a2, b2);
         else { load_tile(0); store_tile(a2, b2); }
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
-            k_step(kt, a2 + cur * BM * 128, b2 + cur * BN * 128, a2 + (cur ^ 1) * BM * 128, b2 + (cur ^ 1) * BN * 128);
+            k_step(kt, a2 + cur * BM * RP, b2 + cur * BN * RP, a2 + (cur ^ 1) * BM * RP, b2 + (cur ^ 1) * BN * RP);
         }
     }
 
@@ -347,9 +348,10 @@ int launch_cfg(const vv_conv_params& p, int M, hipStream_t st) {
     const int tilesM = (M + BM - 1) / BM, tilesN = p.Npad / BN;
     static int split = -1;
     if (split < 0) { const char* e = getenv("VV_GEMM_SPLIT"); split = e ? atoi(e) : 2; }
-    if (split == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 1>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
-    else if (split == 2) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
-    else hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 0>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
+    if (split == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 1, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
+    else if (split == 3 && MODE == MODE_FAST) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 1, 32>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
+    else if (split == 0) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 0, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     VV_CHECK_LAUNCH("vv_conv_gemm");
     return VV_OK;
 }
