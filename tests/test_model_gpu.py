@@ -320,3 +320,22 @@ def test_edge_cases_vs_oracle(gpu, T, H, W, mx, mask_kind):
     if mask_kind == "none":
         assert np.array_equal(np.stack(out), np.stack(frames))          # nothing masked + keep_unmasked_original => identity
     diffuerase.configure(None)
+
+
+def test_checkpoint_weight_source_round_trip(gpu):
+    """the model built from a diffusers-layout checkpoint (here: the synthetic weights exported under their
+    checkpoint names, incl. the motion-module / BrushNet renames) is bit-identical to the model built from the generator."""
+    from videovanish_amd.checkpoint import CheckpointWeights, RecordingWeights
+    from videovanish_amd.pipeline import DiffuEraserHIP
+    from videovanish_amd.weights import SyntheticWeights
+    T, H, W = 3, 32, 40
+    frames, masks, prior = _clip(T, H, W, seed=5)
+    m2d = [np.any(m > 0, axis=2).astype(np.uint8) * 255 for m in masks]
+    run = RunConfig(steps=2, chunk=4, overlap=2, seed=2, dtype="bf16", unet=TINY_UNET, vae=TINY_VAE)
+    rec = RecordingWeights(SyntheticWeights(0))
+    a, _ = DiffuEraserHIP(run, weights=rec).forward(frames, m2d, prior, return_float=True)
+    assert set(rec.components) == {"unet", "brushnet", "vae"}
+    assert any("temporal_transformer" in k for k in rec.components["unet"]) and "conv_in_condition.weight" in rec.components["brushnet"]
+    ck = CheckpointWeights(rec.components, text_states=rec.text_states)
+    b, _ = DiffuEraserHIP(run, weights=ck).forward(frames, m2d, prior, return_float=True)
+    assert np.array_equal(a, b)

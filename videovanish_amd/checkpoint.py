@@ -1,0 +1,112 @@
+"""Real-weight source: serves the same interface as weights.SyntheticWeights from diffusers-format
+state dicts / safetensors files, so the HIP model can be built from the checkpoints the reference names at
+diffuerase.py:41-43,49 (SD-1.5 UNet + motion adapter, BrushNet, sd-vae-ft-mse, RAFT) when they are available locally.
+
+Internal parameter names are the diffusers names prefixed by a component ("unet.", "brushnet.", "vae.", "raft."); the only
+renames are listed in `map_name`.  No network access is attempted: pass local files or in-memory dicts.
+"""
+import re
+
+import torch
+
+
+def map_name(name):
+    """internal name -> (component, key in that component's state dict), without the .weight/.bias suffix."""
+    comp, key = name.split(".", 1)
+    if comp == "unet":
+        # diffusers UNetMotionModel: motion_modules.N.temporal_transformer.{norm,proj_in,transformer_blocks,proj_out}
+        key = re.sub(r"(motion_modules\.\d+)\.", r"\1.temporal_transformer.", key)
+    elif comp == "brushnet":
+        if key.startswith("conv_in"):
+            key = "conv_in_condition" + key[len("conv_in"):]
+    elif comp == "raft":
+        key = re.sub(r"^update\.", "update_block.", key)      # princeton-vl RAFT: fnet.*, cnet.*, update_block.*
+    elif comp != "vae":
+        raise KeyError(f"unknown component in parameter name {name!r}")
+    return comp, key
+
+
+class CheckpointWeights:
+    """Drop-in for SyntheticWeights backed by real tensors.  `components`: {"unet": state_dict, "brushnet": ..., "vae": ...,
+    "raft": ...}; `text_states`: the [1,77,768] CLIP encoding of the empty prompt (the reference's prompt is "")."""
+
+    def __init__(self, components, text_states=None):
+        self.components = components
+        self.text_states = text_states
+
+    @classmethod
+    def from_safetensors(cls, paths, text_states=None):
+        from safetensors.torch import load_file
+        return cls({comp: load_file(path) for comp, path in paths.items()}, text_states)
+
+    def _get(self, name, suffix, shape):
+        comp, key = map_name(name)
+        if comp not in self.components:
+            raise KeyError(f"no checkpoint loaded for component {comp!r} (needed by {name})")
+        full = key + suffix
+        sd = self.components[comp]
+        if full not in sd:
+            raise KeyError(f"checkpoint of {comp!r} has no tensor {full!r} (internal name {name}{suffix})")
+        t = sd[full].to(torch.float32)
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            if t.numel() == int(torch.tensor(shape).prod()) and len(shape) == 4 and t.dim() == 2:
+                t = t.reshape(shape)          # linear-projection checkpoints of 1x1 convs
+            else:
+                raise ValueError(f"{comp}:{full} has shape {tuple(t.shape)}, the architecture needs {tuple(shape)}")
+        return t.contiguous()
+
+    def conv(self, name, cin, cout, k, gain=1.0):
+        return self._get(name, ".weight", (cout, cin, k, k)), self._get(name, ".bias", (cout,))
+
+    def linear(self, name, cin, cout, gain=1.0, bias=True):
+        return self._get(name, ".weight", (cout, cin)), (self._get(name, ".bias", (cout,)) if bias else None)
+
+    def norm(self, name, c):
+        return self._get(name, ".weight", (c,)), self._get(name, ".bias", (c,))
+
+    def normal(self, name, shape, std=1.0, mean=0.0):
+        """Only non-layer tensors go through here: the text states, and RAFT tensors requested by raw suffix."""
+        if name == "text_states":
+            if self.text_states is None:
+                raise KeyError("CheckpointWeights needs `text_states` (CLIP encoding of the empty prompt, [1,77,768])")
+            return self.text_states.to(torch.float32).reshape(shape)
+        for suffix in (".weight", ".bias", ".running_mean", ".running_var"):
+            if name.endswith(suffix):
+                return self._get(name[: -len(suffix)], suffix, shape)
+        raise KeyError(f"CheckpointWeights cannot synthesise {name!r}")
+
+
+class RecordingWeights:
+    """Wraps a weight source and records every tensor it serves under its CHECKPOINT name (used to export a synthetic model
+    in diffusers layout: tests round-trip it through CheckpointWeights)."""
+
+    def __init__(self, src):
+        self.src, self.components = src, {}
+
+    def _rec(self, name, suffix, t):
+        if t is not None:
+            comp, key = map_name(name)
+            self.components.setdefault(comp, {})[key + suffix] = t.clone()
+        return t
+
+    def conv(self, name, cin, cout, k, gain=1.0):
+        w, b = self.src.conv(name, cin, cout, k, gain)
+        return self._rec(name, ".weight", w), self._rec(name, ".bias", b)
+
+    def linear(self, name, cin, cout, gain=1.0, bias=True):
+        w, b = self.src.linear(name, cin, cout, gain, bias)
+        return self._rec(name, ".weight", w), self._rec(name, ".bias", b)
+
+    def norm(self, name, c):
+        g, b = self.src.norm(name, c)
+        return self._rec(name, ".weight", g), self._rec(name, ".bias", b)
+
+    def normal(self, name, shape, std=1.0, mean=0.0):
+        t = self.src.normal(name, shape, std, mean)
+        if name == "text_states":
+            self.text_states = t.clone()
+            return t
+        for suffix in (".weight", ".bias", ".running_mean", ".running_var"):
+            if name.endswith(suffix):
+                return self._rec(name[: -len(suffix)], suffix, t)
+        return t

@@ -8,7 +8,7 @@ from .pipeline import DiffuEraserHIP
 
 class DiffuEraser:
     def __init__(self, device, base_model_path="stable-diffusion-v1-5/stable-diffusion-v1-5", vae_path="stabilityai/sd-vae-ft-mse",
-                 diffueraser_path="lixiaowen/diffuEraser", ckpt="2-Step", run: RunConfig = None, dist=None):
+                 diffueraser_path="lixiaowen/diffuEraser", ckpt="2-Step", run: RunConfig = None, dist=None, weights=None):
         # model ids are accepted for signature compatibility; weights are seeded random-init of the same
         # architecture (no network on the build/bench machines; real-weight loading is row n2 of SURVEY 8f)
         self.ids = (base_model_path, vae_path, diffueraser_path)
@@ -16,7 +16,7 @@ class DiffuEraser:
         self.run = run or RunConfig()
         self.dist = dist
         dev = device if isinstance(device, str) and device.startswith("cuda") else "cuda:0"
-        self.model = DiffuEraserHIP(self.run, dev)
+        self.model = DiffuEraserHIP(self.run, dev, weights=weights)
 
     def forward(self, frames, masks, priori, max_img_size=960, mask_dilation_iter=0, guidance_scale=None, progress=None,
                 num_inference_steps=None, scheduler=None):

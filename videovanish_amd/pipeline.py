@@ -139,9 +139,10 @@ def exchange_and_blend(plan, wts, owner, chunk_rank, rank, world, pending, hw, d
 
 # ---- the model ---------------------------------------------------------------------------------------------------
 class DiffuEraserHIP:
-    def __init__(self, run: RunConfig = None, device="cuda:0"):
+    def __init__(self, run: RunConfig = None, device="cuda:0", weights=None):
+        """weights: None = seeded random init (weights.SyntheticWeights); or a checkpoint.CheckpointWeights."""
         self.run = run or RunConfig()
-        self.ctx = Ctx(device, self.run.dtype, self.run.weight_seed)
+        self.ctx = Ctx(device, self.run.dtype, self.run.weight_seed, weights=weights)
         text = self.ctx.src.normal("text_states", (1, self.run.unet.text_len, self.run.unet.cross_dim))
         self.denoiser = Denoiser(self.ctx, self.run.unet, text)
         self.vae = VAE(self.ctx, self.run.vae)
