@@ -198,7 +198,7 @@ def main():
         "metric": "inpainted frames/sec at 720p, 50 denoise steps", "value": round(distinct / dt, 5), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"c3 chunk: {args.chunk}-frame {W}x{H} chunk, {args.denoise_steps} DDIM steps, {args.chunk}/{args.overlap} chunk/overlap, "
+        "config": {"workload": f"{ {480: 'c2', 720: 'c3', 1080: 'c4'}.get(H, 'custom') } chunk: {args.chunk}-frame {W}x{H} chunk, {args.denoise_steps} DDIM steps, {args.chunk}/{args.overlap} chunk/overlap, "
                                f"{args.arch} SD-1.5 UNet+BrushNet+motion / SD-VAE, random-init weights",
                    "frames_per_step": args.chunk, "credited_frames_per_step": stride, "chunks_per_rank": args.steps,
                    "parallelism": f"chunk-dp{world}", "model_build_s": round(t_build, 1)},
