@@ -139,3 +139,36 @@ def test_denoiser_determinism_and_frame_independence(gpu):
     assert torch.equal(xa[: xb.shape[0]], xb)
     for (ta, _, _), (tb, _, _) in zip(sk_a, sk_b):
         assert torch.equal(ta[: tb.shape[0]], tb)
+
+
+def test_image_kernels_full_size_bit_exact(gpu):
+    """uint8 steps at 1280x720 against the plain-C oracle (oracle/imageops_ref.c): dilation k = 8 and k = 0, the 5x5 chamfer
+    distance transform inside the feather window, the feathered composite, bilinear resize 720p <-> 540x960."""
+    from oracle import imageops_c as IC
+    from videovanish_amd import hip
+    rng = np.random.default_rng(71)
+    T, Hh, Ww = 3, 720, 1280
+    masks = np.zeros((T, Hh, Ww, 3), np.uint8)
+    for t in range(T):
+        masks[t, 200:380, 300 + 2 * t: 620 + 2 * t, t % 3] = 255
+        ys, xs = rng.integers(0, Hh, 40), rng.integers(0, Ww, 40)
+        masks[t, ys, xs, 0] = 9                                           # isolated specks
+    md = torch.from_numpy(masks).to(gpu)
+    d8 = hip.mask_collapse_dilate(md, 8).cpu().numpy()
+    for t in range(T):
+        assert np.array_equal(d8[t], IC.dilate_cross(masks[t].max(2), 8)), t
+    assert (hip.mask_collapse_dilate(md, 0).cpu().numpy() == 255).all()      # k = 0: to convergence = whole frame
+    dt = hip.chamfer_dt(torch.from_numpy(d8).to(gpu), 4).cpu().numpy()
+    ref = IC.distance_transform_l2_5(d8[0])
+    sel = ref <= 4
+    assert np.array_equal(dt[0][sel], ref[sel]) and (dt[0][~sel] > 4).all()
+    inp = rng.integers(0, 256, (T, Hh, Ww, 3), dtype=np.uint8)
+    orig = rng.integers(0, 256, (T, Hh, Ww, 3), dtype=np.uint8)
+    for feather in (3.0, 0.0):
+        got = hip.feather_composite(torch.from_numpy(inp).to(gpu), torch.from_numpy(orig).to(gpu), torch.from_numpy(d8).to(gpu), feather).cpu().numpy()
+        for t in range(T):
+            assert np.array_equal(got[t], IC.feather_composite(inp[t], orig[t], d8[t], feather)), (feather, t)
+    small = hip.resize_u8(torch.from_numpy(inp).to(gpu), 540, 960).cpu().numpy()
+    assert np.array_equal(small[1], IC.resize_bilinear_u8(inp[1], 960, 540))
+    back = hip.resize_u8(torch.from_numpy(small).to(gpu), Hh, Ww).cpu().numpy()
+    assert np.array_equal(back[2], IC.resize_bilinear_u8(small[2], Ww, Hh))

@@ -207,3 +207,20 @@ def test_flow_propagation_fills_from_neighbours():
     keep = mk[0] == 0
     mean = np.floor(fr[0][keep].astype(np.int64).sum(0) / keep.sum() + 0.5)
     assert (out[0][~keep] == mean.astype(np.uint8)).all() and (out[0][keep] == fr[0][keep]).all()
+
+
+def test_c_oracle_equals_numpy_oracle():
+    """oracle/imageops_ref.c (used for full-size checks) == the numpy oracle that is pinned to the reference fixtures."""
+    from oracle import imageops_c as IC
+    rng = np.random.default_rng(12)
+    for dens in (0.03, 0.5, 0.97):
+        m = np.where(rng.random((33, 41)) < dens, 255, 0).astype(np.uint8)
+        assert np.array_equal(IC.distance_transform_l2_5(m), I.distance_transform_l2_5(m))
+        for k in (0, 1, 4):
+            assert np.array_equal(IC.dilate_cross(m, k), I.dilate_cross(m > 0, k).astype(np.uint8) * 255)
+    m = np.zeros((30, 36), np.uint8); m[8:19, 10:25] = 7
+    inp, orig = rng.integers(0, 256, (30, 36, 3), dtype=np.uint8), rng.integers(0, 256, (30, 36, 3), dtype=np.uint8)
+    for f in (3.0, 1.5, 0.0):
+        assert np.array_equal(IC.feather_composite(inp, orig, m, f), I.composite(inp, orig, I.feather_alpha(m, f)))
+    for (Hd, Wd) in [(17, 50), (60, 72), (30, 36)]:
+        assert np.array_equal(IC.resize_bilinear_u8(inp, Wd, Hd), I.resize_bilinear_u8(inp, Wd, Hd))
