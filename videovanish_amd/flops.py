@@ -96,3 +96,19 @@ def per_output_frame(H, W, F, steps, ucfg=None, vcfg=None):
     f = 2 ** (len((vcfg or VAEConfig()).block_out) - 1)
     enc, dec = vae_per_frame(H, W, vcfg)
     return steps * denoise_step_per_frame(H // f, W // f, F, ucfg) + 2 * enc + dec
+
+
+def temporal_block_per_frame(h, w, F, cfg: UNetConfig = None):
+    """FLOP per frame per denoise step of the 21 motion modules (GroupNorm-free count: proj in/out, 2 x (QKV + core + out),
+    GEGLU FF) -- the 'fused temporal block' the north star prices against the MFMA roofline."""
+    cfg = cfg or UNetConfig()
+    bo, L, lpb = cfg.block_out, len(cfg.block_out), cfg.layers_per_block
+    sz = level_sizes(h, w, L)
+    fl = 0.0
+    for i, co in enumerate(bo):
+        fl += lpb * _motion(co, sz[i][0] * sz[i][1], F)
+    fl += _motion(bo[-1], sz[-1][0] * sz[-1][1], F)
+    for i, co in enumerate(reversed(bo)):
+        lvl = L - 1 - i
+        fl += (lpb + 1) * _motion(co, sz[lvl][0] * sz[lvl][1], F)
+    return fl

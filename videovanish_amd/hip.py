@@ -15,6 +15,7 @@ ABI_VERSION = 2
 _DT = {"bf16": BF16, "fp16": F16}
 _TORCH_H16 = {BF16: torch.bfloat16, F16: torch.float16}
 
+PROFILE_TAG = ""   # prefix added to profile keys (nn.MotionModule sets "motion:" so bench.py can price the temporal block)
 PROFILE = None   # bench.py sets this to a list: every MFMA-kernel launch is then bracketed by HIP events on the launch stream
 
 
@@ -24,7 +25,7 @@ class _Prof:
     def __init__(self, key, flops, nbytes):
         self.rec = None
         if PROFILE is not None:
-            self.rec = [key, flops, nbytes, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+            self.rec = [PROFILE_TAG + key, flops, nbytes, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
 
     def __enter__(self):
         if self.rec is not None:

@@ -233,6 +233,13 @@ class MotionModule:
         self.pe = pe_table          # [max_seq, C] fp32 on device
 
     def __call__(self, x, F, H, W, res1=None, out_dtype=torch.float32):
+        prev, hip.PROFILE_TAG = hip.PROFILE_TAG, "motion:"
+        try:
+            return self._run(x, F, H, W, res1, out_dtype)
+        finally:
+            hip.PROFILE_TAG = prev
+
+    def _run(self, x, F, H, W, res1, out_dtype):
         HW = H * W
         if F > self.pe.shape[0]:
             raise RuntimeError(f"motion module: clip of {F} frames exceeds the positional table ({self.pe.shape[0]})")
