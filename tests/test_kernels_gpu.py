@@ -33,6 +33,10 @@ def _nhwc(t):
     dict(F=2, H=5, W=6, cin=8, cout=64, k=3, stride=1),           # padded conv_in style (K=72 -> 128)
     dict(F=1, H=17, W=19, cin=64, cout=320, k=3, stride=1, f32in=True),
     dict(F=2, H=33, W=29, cin=192, cout=96, k=3, stride=1),       # N padded to 128, several M tiles
+    dict(F=2, H=13, W=21, cin=128, cout=160, k=1, stride=1, f32in=True),   # fp32 A tile by LDS-DMA (FAST32), several M tiles
+    dict(F=2, H=12, W=10, cin=192, cout=128, k=3, stride=2, f32in=True),
+    dict(F=1, H=9, W=9, cin=64, cout=4, k=3, stride=1, f32in=True),
+    dict(F=1, H=9, W=9, cin=72, cout=64, k=3, stride=1, f32in=True),       # C % 64 != 0 -> register-staged fp32 loader
 ])
 def test_conv_gemm(gpu, dname, td, ulp, case):
     from videovanish_amd import hip, packing
@@ -82,6 +86,10 @@ def test_conv_gemm_epilogues(gpu, dname, td, ulp):
     ref16 = F.conv2d(up, _r(wt, td), bias, padding=1)
     got16 = out16.float().cpu().reshape(Fr, H, W, cout).permute(0, 3, 1, 2)
     assert (got16 - ref16).abs().max().item() <= 2 * ulp * ref16.abs().max().item()
+    # fp32 concat input + fused nearest upsample (VAE decoder / up-block shortcut style): same result as pre-rounded operands
+    out32 = hip.conv_gemm(dt, _nhwc(_r(a, td)).to(gpu), wp.to(gpu), cout, K, **{**kw, "x1": _nhwc(_r(s, td)).to(gpu)}, out_dtype=torch.float32)
+    got32 = out32.cpu().reshape(Fr, H, W, cout).permute(0, 3, 1, 2)
+    assert (got32 - ref16).abs().max().item() <= 3e-4 * ref16.abs().max().item()
     # VAE-encoder style downsample: pad (0,1,0,1), stride 2, pad 0
     x = torch.randn(2, 64, 10, 12, generator=g)
     wd = torch.randn(128, 64, 3, 3, generator=g) / 24.0

@@ -38,10 +38,17 @@ def gemm_cases():
         ("conv3 L2 1280->1280", dict(F=F, H=23, W=40, cin=1280, cout=1280, k=3)),
         ("conv3 L3 2560->1280", dict(F=F, H=12, W=20, cin=2560, cout=1280, k=3)),
         ("projout L0 f32in K320 N320", dict(F=F, H=h, W=w, cin=320, cout=320, k=1, f32in=True, res=True)),
+        ("shortcut L0 f32in K640 N320", dict(F=F, H=h, W=w, cin=640, cout=320, k=1, f32in=True)),
+        ("shortcut L2 f32in K2560 N1280", dict(F=F, H=23, W=40, cin=2560, cout=1280, k=1, f32in=True)),
+        ("vae conv3 256->256 f32in 720p x1f", dict(F=1, H=720, W=1280, cin=256, cout=256, k=3, f32in=True)),
+        ("stem conv3 8->320 (K72, H16 mode)", dict(F=F, H=h, W=w, cin=8, cout=320, k=3)),
         ("vae conv3 128->128 720p x2f", dict(F=2, H=720, W=1280, cin=128, cout=128, k=3)),
         ("vae conv3 512->512 360p x2f", dict(F=2, H=180, W=320, cin=512, cout=512, k=3)),
     ]
+    only = os.environ.get("VV_BENCH_ONLY")
     for name, c in cases:
+        if only and only not in name:
+            continue
         Fr, H, W, cin, cout, k = c["F"], c["H"], c["W"], c["cin"], c["cout"], c["k"]
         M = Fr * H * W
         x = torch.randn(M, cin, device=dev)

@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int BK = 64;
-enum { MODE_H16 = 0, MODE_F32 = 1, MODE_FAST = 2 };
+enum { MODE_H16 = 0, MODE_F32 = 1, MODE_FAST = 2, MODE_FAST32 = 3 };
 
 __device__ __attribute__((aligned(64))) const unsigned int g_zero_page[16] = {0};
 
@@ -40,10 +40,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
     constexpr int AR = BM / RPB;                // A chunks staged per thread
     constexpr int BCH = (BN + RPB - 1) / RPB;   // B chunks staged per thread
     constexpr int KS = BKT / 32;                // MFMA k steps per tile
-    constexpr bool AF32 = MODE == MODE_F32, FAST = MODE == MODE_FAST;
+    constexpr bool AF32 = MODE == MODE_F32, A32 = MODE == MODE_FAST32, FAST = MODE == MODE_FAST || A32;
+    // FAST32: the fp32 A tile is DMA'd as fp32 (256-byte rows, 16 chunks) and rounded to h16 when the operand is read
+    constexpr int RPA = A32 ? BKT * 4 : RP;     // A row pitch
+    constexpr int SHA = A32 ? 4 : SH;           // log2(A chunks per row)
+    constexpr int RPBA = 256 >> SHA;            // A rows filled per pass
+    constexpr int ARA = BM / RPBA;              // A chunks staged per thread
     // XOR swizzle of the chunk index that makes the ds_read_b128 operand reads conflict free (tools/lds_bank_model.py)
     auto SWZ = [](int row) { return CH == 8 ? (row & 7) : ((row >> 1) & 3); };
-    __shared__ __attribute__((aligned(16))) unsigned char sA0[SPLIT == 0 ? 16 : BM * RP];
+    __shared__ __attribute__((aligned(16))) unsigned char sA0[SPLIT == 0 ? 16 : BM * RPA];
     __shared__ __attribute__((aligned(16))) unsigned char sA1[SPLIT == 1 ? BM * RP : 16];
     __shared__ __attribute__((aligned(16))) unsigned char sB0[SPLIT == 0 ? 16 : BN * RP];
     __shared__ __attribute__((aligned(16))) unsigned char sB1[SPLIT == 1 ? BN * RP : 16];
@@ -68,18 +73,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
     const int c8 = t & (CH - 1);               // this thread's 16-byte slot inside the k tile row
     const int rsw = SWZ(t >> SH);              // swizzle key of every row this thread stages (rows differ by RPB, key unchanged)
     // per-row gather state
-    int rpix[AR], ryb[AR], rxb[AR], rfr[FAST ? AR : 1];
-    bool rv[AR];
+    int rpix[ARA], ryb[ARA], rxb[ARA], rfr[ARA];
+    bool rv[ARA];
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        const int m = m0 + (t >> SH) + RPB * i;
+    for (int i = 0; i < ARA; ++i) {
+        const int m = m0 + (t >> SHA) + RPBA * i;
         rv[i] = m < M;
         const int mm = rv[i] ? m : 0;
         const int f = mm / HWo, rem = mm - f * HWo;
         const int y = rem / p.Wout, x = rem - y * p.Wout;
         ryb[i] = y * p.stride - p.pad_t; rxb[i] = x * p.stride - p.pad_l;
-        rpix[i] = FAST ? (f * p.Hin + ryb[i]) * p.Win + rxb[i] : f;     // FAST: pixel index of tap (0,0); else frame
-        if (FAST) rfr[i] = f;
+        rpix[i] = (f * p.Hin + ryb[i]) * p.Win + rxb[i];     // pixel index of tap (0,0)
+        rfr[i] = f;
     }
     const bool resize = (p.Hv != p.Hin) || (p.Wv != p.Win);
     const unsigned short* wbase = (const unsigned short*)p.weight;
@@ -98,16 +103,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
         int Cs = p.C0;
         if (cc >= p.C0) { src = (const unsigned char*)p.in1; cc -= p.C0; Cs = p.C1; }
         const int dpix = ky * p.Win + kx;
-        const int csrc = cc + ((c8 ^ rsw) << 3);              // swizzle on the SOURCE address, LDS image stays lane-linear
+        // swizzle on the SOURCE address, LDS image stays lane-linear.  FAST32: physical 16-byte chunk pc of row r holds the
+        // logical 8-float group c = (pc>>1) ^ (r&7), half h = (pc&1) ^ (c&1)  (both ds_read_b128 of an operand conflict free)
+        const int c32 = ((t & 15) >> 1) ^ ((t >> 4) & 7);
+        const int csrc = A32 ? cc + c32 * 8 + (((t & 1) ^ (c32 & 1)) << 2) : cc + ((c8 ^ rsw) << 3);
+        constexpr int ES = A32 ? 4 : 2;
         unsigned char* a = bufA + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
+        for (int i = 0; i < ARA; ++i) {
             const int yv = ryb[i] + ky, xv = rxb[i] + kx;
             const bool ok = rv[i] && yv >= 0 && yv < p.Hv && xv >= 0 && xv < p.Wv;
             int pix = rpix[i] + dpix;
             if (resize) pix = (rfr[i] * p.Hin + (yv * p.Hin) / p.Hv) * p.Win + (xv * p.Win) / p.Wv;   // fused nearest upsample
-            const void* g = ok ? (const void*)(src + ((int64_t)pix * Cs + csrc) * 2) : (const void*)g_zero_page;
-            glds16(g, a + i * RPB * RP);
+            const void* g = ok ? (const void*)(src + ((int64_t)pix * Cs + csrc) * ES) : (const void*)g_zero_page;
+            glds16(g, a + i * RPBA * RPA);
         }
         unsigned char* b = bufB + wave * 1024;
         const unsigned short* wrow = wbase + (int64_t)(n0 + (t >> SH)) * p.Kpad + k0 + ((c8 ^ rsw) << 3);
@@ -126,13 +135,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
         const unsigned char* src = (const unsigned char*)p.in0;
         int Cs = p.C0;
         if (cc >= p.C0) { src = (const unsigned char*)p.in1; cc -= p.C0; Cs = p.C1; }
+        const int dpix = ky * p.Win + kx;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            int yv = ryb[i] + ky, xv = rxb[i] + kx;
+            const int yv = ryb[i] + ky, xv = rxb[i] + kx;
             const bool ok = kvalid && rv[i] && yv >= 0 && yv < p.Hv && xv >= 0 && xv < p.Wv;
-            if (resize) { yv = (yv * p.Hin) / p.Hv; xv = (xv * p.Win) / p.Wv; }
-            const int64_t pix = ((int64_t)rpix[i] * p.Hin + yv) * p.Win + xv;
-            const int64_t off = pix * Cs + cc;
+            int pix = rpix[i] + dpix;
+            if (resize) pix = (rfr[i] * p.Hin + (yv * p.Hin) / p.Hv) * p.Win + (xv * p.Win) / p.Wv;
+            const int64_t off = (int64_t)pix * Cs + cc;
             if (AF32) {
                 const float4* g = (const float4*)(src + off * 4);
                 if (ok) { ra[i] = *(const uint4*)g; ra2[i] = *(const uint4*)(g + 1); }
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
     auto k_step = [&](int kt, const unsigned char* cA, const unsigned char* cB, unsigned char* nA, unsigned char* nB) {
         const bool more = kt + 1 < nk;
         if (more) { if (FAST) dma_tile(kt + 1, nA, nB); else load_tile(kt + 1); }
-        const unsigned char* a = cA + (wr * MT * 16) * RP;
+        const unsigned char* a = cA + (wr * MT * 16) * RPA;
         const unsigned char* b = cB + (wc * NT * 16) * RP;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -187,7 +197,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int row = i * 16 + lr;
-                af[i] = *(const uint4*)(a + row * RP + ((ch ^ SWZ(row)) << 4));
+                if constexpr (A32) {
+                    const int q = (ch ^ (row & 7)) << 1, hb = ch & 1;
+                    float f[8];
+                    *(uint4*)&f[0] = *(const uint4*)(a + row * RPA + ((q | hb) << 4));
+                    *(uint4*)&f[4] = *(const uint4*)(a + row * RPA + ((q | (hb ^ 1)) << 4));
+                    af[i] = pack8<T>(f);
+                } else af[i] = *(const uint4*)(a + row * RP + ((ch ^ SWZ(row)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -348,7 +364,8 @@ int launch_cfg(const vv_conv_params& p, int M, hipStream_t st) {
     const int tilesM = (M + BM - 1) / BM, tilesN = p.Npad / BN;
     static int split = -1;
     if (split < 0) { const char* e = getenv("VV_GEMM_SPLIT"); split = e ? atoi(e) : 2; }
-    if (split == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 1, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
+    if constexpr (MODE == MODE_FAST32) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
+    else if (split == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 1, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     else if (split == 3 && MODE == MODE_FAST) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 1, 32>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     else if (split == 0) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 0, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     else hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
@@ -368,8 +385,9 @@ int launch_t(const vv_conv_params& p, int M, hipStream_t st) {
 
 template <typename T>
 int launch_mode(const vv_conv_params& p, int M, hipStream_t st) {
-    if (p.in_dtype == VV_F32) return launch_t<T, MODE_F32>(p, M, st);
-    const bool fast = (p.C0 % 64 == 0) && (p.C1 % 64 == 0) && p.Kpad == p.K && (int64_t)p.F * p.Hin * p.Win < 0x7fffffff;
+    const bool fast = (p.C0 % 64 == 0) && (p.C1 % 64 == 0) && p.Kpad == p.K;
+    static const bool no32 = getenv("VV_GEMM_NO_FAST32") != nullptr;
+    if (p.in_dtype == VV_F32) return (fast && !no32) ? launch_t<T, MODE_FAST32>(p, M, st) : launch_t<T, MODE_F32>(p, M, st);
     return fast ? launch_t<T, MODE_FAST>(p, M, st) : launch_t<T, MODE_H16>(p, M, st);
 }
 
@@ -393,7 +411,7 @@ extern "C" int vv_conv_gemm(const vv_conv_params* pp, int dtype, void* stream) {
     if (p.epilogue == VV_EPI_GEGLU && (p.N % 32 || p.rowvec || p.res0 || p.res1 || (p.ldo & 3))) VV_FAIL(VV_E_ARG, "vv_conv_gemm: GEGLU needs N%%32==0, ldo%%4==0 and no residual/rowvec");
     if (p.F <= 0 || p.Hout <= 0 || p.Wout <= 0 || p.Hin <= 0 || p.Win <= 0 || p.Hv <= 0 || p.Wv <= 0) VV_FAIL(VV_E_ARG, "vv_conv_gemm: bad geometry");
     const int64_t M64 = (int64_t)p.F * p.Hout * p.Wout;
-    if (M64 > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_conv_gemm: M too large");
+    if (M64 > 0x7fffffff || (int64_t)p.F * p.Hin * p.Win > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_conv_gemm: more than 2^31 pixels");
     const int M = (int)M64;
     hipStream_t st = (hipStream_t)stream;
     return dtype == VV_BF16 ? launch_mode<BF16>(p, M, st) : launch_mode<F16>(p, M, st);
