@@ -21,7 +21,20 @@ __device__ __forceinline__ uint2 ds_read_tr16(const unsigned char* lds_ptr) {
     return __builtin_bit_cast(uint2, v);
 }
 
-template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1>
+// 64-byte pages the K/V LDS-DMA reads for slots that hold no tensor data: zeros (head-dim / pitch padding, keys past Nkv) and
+// {1.0, 0, ...} for the ONES column of V (index 0: bf16, 1: fp16)
+__device__ __attribute__((aligned(64))) const unsigned int g_attn_zero[16] = {0};
+__device__ __attribute__((aligned(64))) const unsigned int g_attn_ones[2][16] = {{0x3f80u}, {0x3c00u}};
+
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+    typedef const void __attribute__((address_space(1))) * gp_t;
+    typedef void __attribute__((address_space(3))) * lp_t;
+    __builtin_amdgcn_global_load_lds((gp_t)gptr, (lp_t)lds_wave_base, 16, 0, 0);
+}
+
+// DMA = true: K/V tiles go global -> LDS by LDS-DMA into two static buffers (tile k+1 in flight during the MFMAs and the
+// softmax of tile k, ONE barrier per tile, no staging registers); DMA = false: register staged through dynamic LDS.
+template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false>
 __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params p, const int nqt) {
     constexpr int DK = (D + 31) / 32 * 32, DKC = DK / 8, KS = DK / 32;
     constexpr int DV = (D + 15) / 16 * 16, DVC = DV / 8, NDT = DV / 16;
@@ -36,8 +49,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sK = smem;
     unsigned char* sV = smem + KVT * PK;
+    constexpr int NSK = KVT * PK / 16, NSV = KVT * PV / 16;            // 16-byte LDS slots per K / V tile (multiples of 64)
+    constexpr int KP = (NSK + NT - 1) / NT, VP = (NSV + NT - 1) / NT;  // DMA passes
+    static_assert(!DMA || (NSK % 64 == 0 && NSV % 64 == 0), "K/V tile must be whole 1 KB wave blocks");
+    __shared__ __attribute__((aligned(1024))) unsigned char dK0[DMA ? KVT * PK : 16];
+    __shared__ __attribute__((aligned(1024))) unsigned char dK1[DMA ? KVT * PK : 16];
+    __shared__ __attribute__((aligned(1024))) unsigned char dV0[DMA ? KVT * PV : 16];
+    __shared__ __attribute__((aligned(1024))) unsigned char dV1[DMA ? KVT * PV : 16];
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 15, lg = lane >> 4;
     // XCD-aware decode: blocks i and i+8 share an XCD (and its L2).  Give every XCD its own (batch, head) pairs and walk
     // that pair's query tiles on it, so the pair's K/V (re-read by every query tile) stays resident in ONE 4 MiB L2.
@@ -112,14 +132,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
     };
 
     const int ntiles = (p.Nkv + KVT - 1) / KVT;
-    load_kv(0);
-    store_kv();
-    __syncthreads();
-    // one KV tile; MASK is a compile-time flag so that only the LAST (ragged) tile pays for the key mask
-    auto tile_step = [&](const int it, auto mask_tag) {
+    // one KV tile out of (sK, sV); MASK is a compile-time flag so that only the LAST (ragged) tile pays for the key mask
+    auto compute = [&](const int it, const unsigned char* sK, const unsigned char* sV, auto mask_tag) {
         constexpr bool MASK = decltype(mask_tag)::value;
         const int kv0 = it * KVT;
-        if (PREFETCH && it + 1 < ntiles) load_kv(kv0 + KVT);
 
         // ---- S^T = K Q^T
         f32x4 sacc[KT][QT];
@@ -201,17 +217,87 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
                 for (int j = 0; j < QT; ++j) oacc[d][j] = T::mfma(vf, pb[u][j], oacc[d][j]);
             }
         }
-        __syncthreads();
-        if (it + 1 < ntiles) {
-            if (!PREFETCH) load_kv(kv0 + KVT);
-            store_kv();
-            __syncthreads();
-        }
     };
     const bool ragged = (p.Nkv % KVT) != 0;
-    const int nfull = ragged ? ntiles - 1 : ntiles;
-    for (int it = 0; it < nfull; ++it) tile_step(it, std::false_type{});
-    if (ragged) tile_step(ntiles - 1, std::true_type{});
+    if constexpr (DMA) {
+        // ---- per-thread DMA slots: LDS slot (pass i, thread t) <-> (tile row, 16-byte chunk).  Slots that hold no tensor
+        // data (head-dim / pitch padding, the ONES column) are written ONCE here (with the rest of both buffers) and never
+        // touched by the DMA: the lanes that own them are masked off (a masked lane's LDS slot = M0 + 16 * lane is not written).
+        unsigned koff[KP], voff[VP];      // byte offsets from Kp / Vp of the slot's source in the NEXT tile to issue
+        bool kdata[KP], vdata[VP];
+#pragma unroll
+        for (int i = 0; i < KP; ++i) {
+            const int sidx = i * NT + t, row = sidx / (PK / 16), ch = sidx - row * (PK / 16);
+            kdata[i] = ch * 8 < D && sidx < NSK;
+            koff[i] = (unsigned)(row * (int)p.k_rs + ch * 8) * 2u;
+            if (sidx < NSK) { *(uint4*)(dK0 + sidx * 16) = make_uint4(0, 0, 0, 0); *(uint4*)(dK1 + sidx * 16) = make_uint4(0, 0, 0, 0); }
+        }
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            const int sidx = i * NT + t, row = sidx / (PV / 16), ch = sidx - row * (PV / 16);
+            vdata[i] = ch * 8 < D && sidx < NSV;
+            voff[i] = (unsigned)(row * (int)p.v_rs + ch * 8) * 2u;
+            if (sidx < NSV) {
+                const uint4 fill = make_uint4((ONES && ch * 8 == D) ? (unsigned)T::from_f32(1.0f) : 0u, 0, 0, 0);
+                *(uint4*)(dV0 + sidx * 16) = fill; *(uint4*)(dV1 + sidx * 16) = fill;
+            }
+        }
+        __syncthreads();    // the fill is complete before the first DMA lands (rows past Nkv of a ragged tile stay finite)
+        const unsigned kstep = (unsigned)(KVT * (int)p.k_rs * 2), vstep = (unsigned)(KVT * (int)p.v_rs * 2);
+        int issued = 0;     // tiles issued so far (= index of the tile the offsets address)
+        auto dma_issue = [&](unsigned char* bK, unsigned char* bV, auto check_tag) {
+            constexpr bool CHECK = decltype(check_tag)::value;      // ragged last tile: rows past Nkv keep the stale (finite) tile
+            const int kv0 = issued * KVT;
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+                if (NSK % NT == 0 || i * NT + wave * 64 < NSK) {
+                    if (kdata[i] && (!CHECK || kv0 + (i * NT + t) / (PK / 16) < p.Nkv)) glds16((const unsigned char*)Kp + koff[i], bK + (i * NT + wave * 64) * 16);
+                    koff[i] += kstep;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < VP; ++i) {
+                if (NSV % NT == 0 || i * NT + wave * 64 < NSV) {
+                    if (vdata[i] && (!CHECK || kv0 + (i * NT + t) / (PV / 16) < p.Nkv)) glds16((const unsigned char*)Vp + voff[i], bV + (i * NT + wave * 64) * 16);
+                    voff[i] += vstep;
+                }
+            }
+            ++issued;
+        };
+        auto step = [&](const int it, unsigned char* cK, unsigned char* cV, unsigned char* nK, unsigned char* nV) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of tile `it` has landed
+            __syncthreads();                                      // ... everybody's has, and everybody is done with tile it-1
+            if (it + 1 < ntiles) {
+                if (ragged && it + 2 == ntiles) dma_issue(nK, nV, std::true_type{});
+                else dma_issue(nK, nV, std::false_type{});
+            }
+            if (ragged && it + 1 == ntiles) compute(it, cK, cV, std::true_type{});
+            else compute(it, cK, cV, std::false_type{});
+        };
+        if (ragged && ntiles == 1) dma_issue(dK0, dV0, std::true_type{});
+        else dma_issue(dK0, dV0, std::false_type{});
+        for (int it = 0; it < ntiles; it += 2) {
+            step(it, dK0, dV0, dK1, dV1);
+            if (it + 1 < ntiles) step(it + 1, dK1, dV1, dK0, dV0);
+        }
+    } else {
+        load_kv(0);
+        store_kv();
+        __syncthreads();
+        auto tile_step = [&](const int it, auto mask_tag) {
+            if (PREFETCH && it + 1 < ntiles) load_kv((it + 1) * KVT);
+            compute(it, sK, sV, mask_tag);
+            __syncthreads();
+            if (it + 1 < ntiles) {
+                if (!PREFETCH) load_kv((it + 1) * KVT);
+                store_kv();
+                __syncthreads();
+            }
+        };
+        const int nfull = ragged ? ntiles - 1 : ntiles;
+        for (int it = 0; it < nfull; ++it) tile_step(it, std::false_type{});
+        if (ragged) tile_step(ntiles - 1, std::true_type{});
+    }
     // ---- finalize: O[q][d] = O^T[d][q] / l
 #pragma unroll
     for (int j = 0; j < QT; ++j) {
@@ -239,16 +325,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
     }
 }
 
-template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1>
+template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false>
 int attn_launch(const vv_attn_params& p, hipStream_t st) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
     constexpr int PK = DK * 2 + 32, PV = DV * 2 + ((DV * 2) % 64 == 0 ? 32 : 0);   // conflict-free ds_read_b128 / ds_read_b64_tr_b16 (bank model: tools/lds_bank_model.py)
     constexpr int BQ = NW * QT * 16;
-    const size_t lds = (size_t)KVT * (PK + PV);
+    const size_t lds = DMA ? 0 : (size_t)KVT * (PK + PV);
     const int nqt = (p.Nq + BQ - 1) / BQ;
     const int64_t nblk = (int64_t)p.B * p.heads * nqt;
     if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_attention: grid too large");
-    auto kern = attn_kernel<T, D, QT, KVT, NW, PREFETCH, OCC>;
+    auto kern = attn_kernel<T, D, QT, KVT, NW, PREFETCH, OCC, DMA>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -277,6 +363,12 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
             if (var == 5) return attn_launch<T, D, 1, 64, 4, true, 1>(p, st);      // 16 queries per wave, 64 per block
             if (var == 6) return attn_launch<T, D, 1, 64, 8, true, 1>(p, st);      // 16 queries per wave, 8 waves = 128 per block
             if (var == 7) return attn_launch<T, D, 2, 64, 8, true, 1>(p, st);      // 32 queries per wave, 8 waves = 256 per block
+            if (var == 8) return attn_launch<T, D, 2, 64, 4, true>(p, st);         // register-staged K/V (the pre-DMA default)
+            if (var == 9) return attn_launch<T, D, 2, 64, 4, false, 3, true>(p, st);   // DMA, capped at 168 VGPRs (3 waves/SIMD)
+            if (var == 11) return attn_launch<T, D, 2, 64, 4, false, 4, true>(p, st);   // DMA, capped at 128 VGPRs (4 waves/SIMD)
+            if (var == 10) return attn_launch<T, D, 2, 64, 4, false, 1, true>(p, st);   // DMA, uncapped registers (2 waves/SIMD)
+            // default for d <= 64: K/V by LDS-DMA, double buffered, 3 waves/SIMD (d = 80 would spill: stays register staged)
+            if (D <= 64) return attn_launch<T, D, 2, 64, 4, false, 3, true>(p, st);
         }
         return attn_launch<T, D, 2, 64, 4, true>(p, st);
     }
