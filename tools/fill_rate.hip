@@ -1,0 +1,78 @@
+// Micro-benchmark: achievable L2 -> LDS fill rate with global_load_lds (LDS-DMA) in the access pattern of vv_conv_gemm's FAST
+// loader (128 rows x 128 B of A + 160 rows x 128 B of B per k tile, single 36 KB buffer, barrier per tile), NO MFMAs.
+//   hipcc --offload-arch=gfx950 -O3 tools/fill_rate.hip -o tools/fill_rate.bin && tools/fill_rate.bin
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    typedef const void __attribute__((address_space(1))) * gp_t;
+    typedef void __attribute__((address_space(3))) * lp_t;
+    __builtin_amdgcn_global_load_lds((gp_t)g, (lp_t)l, 16, 0, 0);
+}
+// MODE 0: DMA, no barrier; 1: DMA + barrier per tile; 2: like 1 but every block reads the same 8 m-tiles (L2 resident);
+// 3: plain global_load_dwordx4 into registers (no LDS), same addresses as 1
+template <int BARRIER>
+__global__ __launch_bounds__(256, 2) void fill(const unsigned char* A, const unsigned char* B, int K, int tilesN, int nk, float* out) {
+    __shared__ __attribute__((aligned(16))) unsigned char sA[128 * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char sB[160 * 128];
+    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tile_n = blockIdx.x % tilesN, tile_m = BARRIER == 2 ? (blockIdx.x / tilesN) % 8 : blockIdx.x / tilesN;
+    const unsigned char* a = A + ((size_t)(tile_m * 128 + (t >> 3)) * K) * 2 + (t & 7) * 16;
+    const unsigned char* b = B + ((size_t)(tile_n * 160 + (t >> 3)) * K) * 2 + (t & 7) * 16;
+    float acc = 0.f;
+    if (BARRIER == 3) {
+        uint4 s4 = make_uint4(0, 0, 0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const uint4 v = *(const uint4*)(a + (size_t)(32 * i) * K * 2 + kt * 128); s4.x ^= v.x; s4.y ^= v.y; s4.z ^= v.z; s4.w ^= v.w; }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { const uint4 v = *(const uint4*)(b + (size_t)(32 * i) * K * 2 + kt * 128); s4.x ^= v.x; s4.y ^= v.y; s4.z ^= v.z; s4.w ^= v.w; }
+        }
+        if ((s4.x ^ s4.y ^ s4.z ^ s4.w) == 0x12345u) out[0] = 1.f;
+        return;
+    }
+    // modes >= 4: + s_sleep ~ the MFMA phase of the real kernel; 5: + software L2 prefetch of the A lines of tile kt+4
+    // (one global_load_ubyte per 128-byte line, threads 0..127), issued after the wait so that it is never waited on early
+    unsigned pf = 0;
+    const unsigned char* arow = A + ((size_t)(tile_m * 128 + (t & 127)) * K) * 2;
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(a + (size_t)(32 * i) * K * 2 + kt * 128, sA + wave * 1024 + i * 4096);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) glds16(b + (size_t)(32 * i) * K * 2 + kt * 128, sB + wave * 1024 + i * 4096);
+        if (BARRIER) {
+            __syncthreads(); acc += *(float*)(sA + t * 4);
+            if (BARRIER == 5 && t < 128 && kt + 4 < nk) pf ^= arow[(kt + 4) * 128];
+            if (BARRIER >= 4) { __builtin_amdgcn_s_sleep(10); }
+            __syncthreads();
+        }
+    }
+    if (pf == 0x1234567u) out[0] = 2.f;
+    asm volatile("s_waitcnt vmcnt(0)");
+    acc += *(float*)(sB + t * 4);
+    if (acc == 123.456f) out[0] = acc;
+}
+int main() {
+    const int M = 115200, N = 640, K = 5760;    // conv3 L1 640->640 as a GEMM
+    unsigned char *A, *B; float* out;
+    hipMalloc(&A, (size_t)(M + 256) * K * 2); hipMalloc(&B, (size_t)(N + 256) * K * 2); hipMalloc(&out, 4);
+    hipMemset(A, 0, (size_t)(M + 256) * K * 2); hipMemset(B, 0, (size_t)(N + 256) * K * 2);
+    const int tilesM = M / 128, tilesN = N / 160, nk = K / 64;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int mode = 0; mode < 6; ++mode) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            if (mode == 0) fill<0><<<tilesM * tilesN, 256>>>(A, B, K, tilesN, nk, out);
+            if (mode == 1) fill<1><<<tilesM * tilesN, 256>>>(A, B, K, tilesN, nk, out);
+            if (mode == 2) fill<2><<<tilesM * tilesN, 256>>>(A, B, K, tilesN, nk, out);
+            if (mode == 3) fill<3><<<tilesM * tilesN, 256>>>(A, B, K, tilesN, nk, out);
+            if (mode == 4) fill<4><<<tilesM * tilesN, 256>>>(A, B, K, tilesN, nk, out);
+            if (mode == 5) fill<5><<<tilesM * tilesN, 256>>>(A, B, K, tilesN, nk, out);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            const double bytes = (double)tilesM * tilesN * nk * 36864.0;
+            printf("%s: %.3f ms, %.2f TB/s L2->LDS (%.1f B/clk/CU at 2.1 GHz); the GEMM of this shape does %.0f TF/s-equivalent at this fill rate\n",
+                   mode == 0 ? "DMA, no barrier          " : mode == 1 ? "DMA + barrier per tile   " : mode == 2 ? "DMA + barrier, L2-resident A" : mode == 3 ? "global_load_dwordx4 -> regs" : mode == 4 ? "DMA + barrier + sleep(MFMA)" : "DMA + barrier + sleep + L2 prefetch(kt+4)", ms, bytes / ms / 1e9, bytes / ms / 1e-3 / 256 / 2.1e9, 2.0 * M * N * K / ms / 1e9);
+        }
+    }
+    return 0;
+}
