@@ -37,6 +37,9 @@ def _nhwc(t):
     dict(F=2, H=12, W=10, cin=192, cout=128, k=3, stride=2, f32in=True),
     dict(F=1, H=9, W=9, cin=64, cout=4, k=3, stride=1, f32in=True),
     dict(F=1, H=9, W=9, cin=72, cout=64, k=3, stride=1, f32in=True),       # C % 64 != 0 -> register-staged fp32 loader
+    dict(F=2, H=16, W=32, cin=64, cout=160, k=3, stride=1),                # 3x3 halo-tile path: exact 8x16 patches
+    dict(F=3, H=23, W=47, cin=128, cout=128, k=3, stride=1),               # halo path, ragged patches on both edges
+    dict(F=1, H=40, W=31, cin=192, cout=320, k=3, stride=1),               # halo path, 3 channel chunks, 2 N tiles
 ])
 def test_conv_gemm(gpu, dname, td, ulp, case):
     from videovanish_amd import hip, packing
@@ -90,6 +93,19 @@ def test_conv_gemm_epilogues(gpu, dname, td, ulp):
     out32 = hip.conv_gemm(dt, _nhwc(_r(a, td)).to(gpu), wp.to(gpu), cout, K, **{**kw, "x1": _nhwc(_r(s, td)).to(gpu)}, out_dtype=torch.float32)
     got32 = out32.cpu().reshape(Fr, H, W, cout).permute(0, 3, 1, 2)
     assert (got32 - ref16).abs().max().item() <= 3e-4 * ref16.abs().max().item()
+    # halo-tile 3x3 path with concat input (chunks from two sources) + rowvec + two residuals, fp32 and h16 outputs
+    Hh, Wh = 24, 47
+    ah, sh = torch.randn(Fr, c0, Hh, Wh, generator=g), torch.randn(Fr, c1, Hh, Wh, generator=g)
+    r0h, r1h = torch.randn(Fr, cout, Hh, Wh, generator=g), torch.randn(Fr, cout, Hh, Wh, generator=g)
+    refh = F.conv2d(torch.cat([_r(ah, td), _r(sh, td)], 1), _r(wt, td), bias, padding=1)
+    kwh = dict(x1=_nhwc(sh).to(td).to(gpu), F=Fr, Hin=Hh, Win=Wh, ksize=3, pad_t=1, pad_l=1, bias=bias.to(gpu))
+    outh = hip.conv_gemm(dt, _nhwc(ah).to(td).to(gpu), wp.to(gpu), cout, K, rowvec=temb.to(gpu), res0=_nhwc(r0h).to(gpu), res1=_nhwc(r1h).to(gpu),
+                         out_dtype=torch.float32, **kwh)
+    goth = outh.cpu().reshape(Fr, Hh, Wh, cout).permute(0, 3, 1, 2)
+    refh_full = refh + temb[:, :, None, None] + r0h + r1h
+    assert (goth - refh_full).abs().max().item() <= 3e-4 * refh_full.abs().max().item()
+    outh16 = hip.conv_gemm(dt, _nhwc(ah).to(td).to(gpu), wp.to(gpu), cout, K, **kwh)
+    assert (outh16.float().cpu().reshape(Fr, Hh, Wh, cout).permute(0, 3, 1, 2) - refh).abs().max().item() <= 2 * ulp * refh.abs().max().item()
     # VAE-encoder style downsample: pad (0,1,0,1), stride 2, pad 0
     x = torch.randn(2, 64, 10, 12, generator=g)
     wd = torch.randn(128, 64, 3, 3, generator=g) / 24.0

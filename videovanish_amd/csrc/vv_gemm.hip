@@ -20,7 +20,8 @@
 namespace {
 
 constexpr int BK = 64;
-enum { MODE_H16 = 0, MODE_F32 = 1, MODE_FAST = 2, MODE_FAST32 = 3 };
+enum { MODE_H16 = 0, MODE_F32 = 1, MODE_FAST = 2, MODE_FAST32 = 3, MODE_HALO = 4 };
+constexpr int HALO_PX = 184;   // (8+2) x (16+2) = 180 halo pixels of an 8x16 output patch, padded to whole 1 KB DMA blocks
 
 __device__ __attribute__((aligned(64))) const unsigned int g_zero_page[16] = {0};
 
@@ -40,7 +41,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
     constexpr int AR = BM / RPB;                // A chunks staged per thread
     constexpr int BCH = (BN + RPB - 1) / RPB;   // B chunks staged per thread
     constexpr int KS = BKT / 32;                // MFMA k steps per tile
-    constexpr bool AF32 = MODE == MODE_F32, A32 = MODE == MODE_FAST32, FAST = MODE == MODE_FAST || A32;
+    // HALO (3x3, stride 1, h16): the M tile is an 8 x 16 pixel patch of one frame; per 64-channel chunk its 10 x 18 halo is
+    // DMA'd ONCE and the 9 taps read their A operands out of it (L2->LDS bytes per 9 k tiles: 23 + 9*20 KB instead of 9*36)
+    constexpr bool AF32 = MODE == MODE_F32, A32 = MODE == MODE_FAST32, HALO = MODE == MODE_HALO, FAST = MODE == MODE_FAST || A32 || HALO;
+    static_assert(!HALO || (WR * MT == 8 && SPLIT == 2 && BKT == 64), "HALO: 128-row tile, single buffer");
+    constexpr int HP = HALO ? (HALO_PX * 8 + 255) / 256 : 1;    // halo DMA passes
     // FAST32: the fp32 A tile is DMA'd as fp32 (256-byte rows, 16 chunks) and rounded to h16 when the operand is read
     constexpr int RPA = A32 ? BKT * 4 : RP;     // A row pitch
     constexpr int SHA = A32 ? 4 : SH;           // log2(A chunks per row)
@@ -48,13 +53,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
     constexpr int ARA = BM / RPBA;              // A chunks staged per thread
     // XOR swizzle of the chunk index that makes the ds_read_b128 operand reads conflict free (tools/lds_bank_model.py)
     auto SWZ = [](int row) { return CH == 8 ? (row & 7) : ((row >> 1) & 3); };
-    __shared__ __attribute__((aligned(16))) unsigned char sA0[SPLIT == 0 ? 16 : BM * RPA];
+    __shared__ __attribute__((aligned(16))) unsigned char sA0[SPLIT == 0 ? 16 : (HALO ? HALO_PX * 128 : BM * RPA)];
     __shared__ __attribute__((aligned(16))) unsigned char sA1[SPLIT == 1 ? BM * RP : 16];
     __shared__ __attribute__((aligned(16))) unsigned char sB0[SPLIT == 0 ? 16 : BN * RP];
     __shared__ __attribute__((aligned(16))) unsigned char sB1[SPLIT == 1 ? BN * RP : 16];
     __shared__ __attribute__((aligned(16))) unsigned char sAB[SPLIT == 0 ? 2 * (BM + BN) * RP : 16];
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave / WC, wc = wave % WC;
 
     // ---- XCD-aware block remap (bijective): blocks b and b+8 share an XCD -> give each XCD a contiguous range
@@ -66,6 +71,24 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
     }
     const int tile_n = bid % tilesN, tile_m = bid / tilesN;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // HALO: tile_m -> (frame, patch row, patch column)
+    int hf = 0, hy0 = 0, hx0 = 0;
+    if (HALO) {
+        const int PW = (p.Win + 15) >> 4, PH = (p.Hin + 7) >> 3;
+        hf = tile_m / (PH * PW);
+        const int r = tile_m - hf * (PH * PW);
+        hy0 = (r / PW) * 8; hx0 = (r % PW) * 16;
+    }
+    // tile row -> output row m (and whether it exists)
+    auto row_m = [&](int row, bool& ok) -> int {
+        if (HALO) {
+            const int y = hy0 + (row >> 4), x = hx0 + (row & 15);
+            ok = y < p.Hin && x < p.Win;
+            return (hf * p.Hin + y) * p.Win + x;
+        }
+        ok = m0 + row < M;
+        return m0 + row;
+    };
 
     const int Cin = p.C0 + p.C1;
     const int KW = p.ksize_w > 0 ? p.ksize_w : p.ksize;
@@ -85,6 +108,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
         ryb[i] = y * p.stride - p.pad_t; rxb[i] = x * p.stride - p.pad_l;
         rpix[i] = (f * p.Hin + ryb[i]) * p.Win + rxb[i];     // pixel index of tap (0,0)
         rfr[i] = f;
+    }
+    // HALO slots: LDS slot (pass i, thread t) = halo pixel hp, physical chunk hc; holds logical chunk hc ^ (hp & 7)
+    int hpix[HP]; bool hok[HP];
+    if (HALO) {
+#pragma unroll
+        for (int i = 0; i < HP; ++i) {
+            const int idx = i * 256 + t, hp = idx >> 3;
+            const int y = hy0 - 1 + hp / 18, x = hx0 - 1 + hp % 18;
+            hok[i] = hp < 180 && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+            hpix[i] = (hf * p.Hin + y) * p.Win + x;
+            if (idx < HALO_PX * 8) *(uint4*)(sA0 + idx * 16) = make_uint4(0, 0, 0, 0);     // out-of-image halo stays zero (those lanes are masked in the DMA)
+        }
+        __syncthreads();
     }
     const bool resize = (p.Hv != p.Hin) || (p.Wv != p.Win);
     const unsigned short* wbase = (const unsigned short*)p.weight;
@@ -120,6 +156,28 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
         }
         unsigned char* b = bufB + wave * 1024;
         const unsigned short* wrow = wbase + (int64_t)(n0 + (t >> SH)) * p.Kpad + k0 + ((c8 ^ rsw) << 3);
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            if (BN % RPB == 0 || (t >> SH) + RPB * i < BN) glds16(wrow + (int64_t)(RPB * i) * p.Kpad, b + i * RPB * RP);
+        }
+    };
+    // ---- HALO: halo of channel chunk c (64 channels of one source); B tile of (chunk, tap)
+    auto dma_halo = [&](int c) {
+        int cc = c * 64;
+        const unsigned char* src = (const unsigned char*)p.in0;
+        int Cs = p.C0;
+        if (cc >= p.C0) { src = (const unsigned char*)p.in1; cc -= p.C0; Cs = p.C1; }
+        const int cs = cc + ((((t & 7) ^ ((t >> 3) & 7))) << 3);      // (pass*256 + t) >> 3 has the same low 3 bits as t >> 3
+#pragma unroll
+        for (int i = 0; i < HP; ++i) {
+            if (i * 256 + wave * 64 < HALO_PX * 8) {
+                if (hok[i]) glds16(src + ((int64_t)hpix[i] * Cs + cs) * 2, sA0 + (i * 256 + wave * 64) * 16);
+            }
+        }
+    };
+    auto dma_b = [&](int kofs, unsigned char* bufB) {
+        unsigned char* b = bufB + wave * 1024;
+        const unsigned short* wrow = wbase + (int64_t)(n0 + (t >> SH)) * p.Kpad + kofs + ((c8 ^ rsw) << 3);
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
             if (BN % RPB == 0 || (t >> SH) + RPB * i < BN) glds16(wrow + (int64_t)(RPB * i) * p.Kpad, b + i * RPB * RP);
@@ -185,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
     const int nk = p.Kpad / BKT;
     const int lr = lane & 15, lq = lane >> 4;
     // one k tile: prefetch the next tile into (nA,nB), run the MFMAs on (cA,cB), then barrier
-    auto k_step = [&](int kt, const unsigned char* cA, const unsigned char* cB, unsigned char* nA, unsigned char* nB) {
+    auto k_step = [&](int kt, const unsigned char* cA, const unsigned char* cB, unsigned char* nA, unsigned char* nB, int tapofs = 0) {
         const bool more = kt + 1 < nk;
         if (more) { if (FAST) dma_tile(kt + 1, nA, nB); else load_tile(kt + 1); }
         const unsigned char* a = cA + (wr * MT * 16) * RPA;
@@ -197,7 +255,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int row = i * 16 + lr;
-                if constexpr (A32) {
+                if constexpr (HALO) {
+                    const int hp = (wr * MT + i) * 18 + lr + tapofs;       // halo pixel of (patch row, column lr) shifted by the tap
+                    af[i] = *(const uint4*)(cA + hp * 128 + ((ch ^ (hp & 7)) << 4));
+                } else if constexpr (A32) {
                     const int q = (ch ^ (row & 7)) << 1, hb = ch & 1;
                     float f[8];
                     *(uint4*)&f[0] = *(const uint4*)(a + row * RPA + ((q | hb) << 4));
@@ -220,7 +281,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
         __syncthreads();     // with LDS-DMA in flight hipcc drains vmcnt(0) here: the prefetch overlapped the MFMAs
     };
 
-    if (SPLIT == 2) {
+    if constexpr (HALO) {
+        const int nchunks = Cin >> 6;
+        for (int c = 0; c < nchunks; ++c) {
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap == 0) dma_halo(c);
+                dma_b(tap * Cin + c * 64, sB0);
+                __syncthreads();
+                k_step(nk, sA0, sB0, sA0, sB0, (tap / 3) * 18 + tap % 3);
+            }
+        }
+    } else if (SPLIT == 2) {
         // single buffer: fill -> barrier -> MFMAs -> barrier; half the LDS, so twice the co-resident blocks hide the fill
         for (int kt = 0; kt < nk; ++kt) {
             if (FAST) dma_tile(kt, sA0, sB0);
@@ -264,8 +336,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const int m = m0 + wr * MT * 16 + i * 16 + lr;
-                if (m >= M) continue;
+                bool mok;
+                const int m = row_m(wr * MT * 16 + i * 16 + lr, mok);
+                if (!mok) continue;
 #pragma unroll
                 for (int j = 0; j < NT; j += 2) {
                     const int nt0 = n0 + wc * NT * 16 + j * 16;
@@ -292,8 +365,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int m = m0 + wr * MT * 16 + i * 16 + lr;
-            const bool mok = m < M;
+            bool mok;
+            const int m = row_m(wr * MT * 16 + i * 16 + lr, mok);
             const int64_t rbase = (int64_t)(mok ? m : 0) * N;
             float4 ra4[NT];
             // issue every res0 load of this strip first (the common residual); rarer addends are read in place
@@ -332,8 +405,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
     // scalar tail path (N or ldo not a multiple of 4: e.g. the 3-channel VAE conv_out)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int m = m0 + wr * MT * 16 + i * 16 + lr;
-        if (m >= M) continue;
+        bool mok;
+        const int m = row_m(wr * MT * 16 + i * 16 + lr, mok);
+        if (!mok) continue;
         const float* rowv = p.rowvec ? p.rowvec + (int64_t)(m / HWo) * N : nullptr;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -361,10 +435,12 @@ template <typename T, int WR, int WC, int MT, int NT, int MODE>
 int launch_cfg(const vv_conv_params& p, int M, hipStream_t st) {
     constexpr int BM = WR * MT * 16, BN = WC * NT * 16;
     if (p.Npad % BN != 0) VV_FAIL(VV_E_ARG, "vv_conv_gemm: Npad %d not a multiple of tile N %d", p.Npad, BN);
-    const int tilesM = (M + BM - 1) / BM, tilesN = p.Npad / BN;
+    int tilesM = (M + BM - 1) / BM;
+    const int tilesN = p.Npad / BN;
+    if constexpr (MODE == MODE_HALO) tilesM = p.F * ((p.Hin + 7) / 8) * ((p.Win + 15) / 16);
     static int split = -1;
     if (split < 0) { const char* e = getenv("VV_GEMM_SPLIT"); split = e ? atoi(e) : 2; }
-    if constexpr (MODE == MODE_FAST32) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
+    if constexpr (MODE == MODE_FAST32 || MODE == MODE_HALO) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     else if (split == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 1, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     else if (split == 3 && MODE == MODE_FAST) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 1, 32>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     else if (split == 0) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 0, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
@@ -387,6 +463,13 @@ template <typename T>
 int launch_mode(const vv_conv_params& p, int M, hipStream_t st) {
     const bool fast = (p.C0 % 64 == 0) && (p.C1 % 64 == 0) && p.Kpad == p.K;
     static const bool no32 = getenv("VV_GEMM_NO_FAST32") != nullptr;
+    static const bool nohalo = getenv("VV_GEMM_NO_HALO") != nullptr;
+    if (fast && !nohalo && p.in_dtype != VV_F32 && p.ksize == 3 && (p.ksize_w == 0 || p.ksize_w == 3) && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 &&
+        p.Hv == p.Hin && p.Wv == p.Win && p.Hout == p.Hin && p.Wout == p.Win && p.epilogue != VV_EPI_GEGLU && (p.Npad % 160 == 0 || p.Npad % 128 == 0)) {
+        // patch grid waste <= 10 %
+        const int64_t cover = (int64_t)((p.Hin + 7) / 8) * 8 * ((p.Win + 15) / 16) * 16;
+        if (cover * 10 <= (int64_t)p.Hin * p.Win * 11) return launch_t<T, MODE_HALO>(p, M, st);
+    }
     if (p.in_dtype == VV_F32) return (fast && !no32) ? launch_t<T, MODE_FAST32>(p, M, st) : launch_t<T, MODE_F32>(p, M, st);
     return fast ? launch_t<T, MODE_FAST>(p, M, st) : launch_t<T, MODE_H16>(p, M, st);
 }
