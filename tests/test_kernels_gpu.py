@@ -40,8 +40,11 @@ def _nhwc(t):
     dict(F=2, H=16, W=32, cin=64, cout=160, k=3, stride=1),                # 3x3 halo-tile path: exact 8x16 patches
     dict(F=3, H=23, W=47, cin=128, cout=128, k=3, stride=1),               # halo path, ragged patches on both edges
     dict(F=1, H=40, W=31, cin=192, cout=320, k=3, stride=1),               # halo path, 3 channel chunks, 2 N tiles
+    dict(F=2, H=31, W=48, cin=128, cout=160, k=3, stride=1, halo256=True),  # opt-in 256-pixel halo kernel (vv_conv3.hip), ragged bottom edge
+    dict(F=1, H=32, W=47, cin=320, cout=320, k=3, stride=1, halo256=True),  # 5 chunks (odd), 2 N tiles, ragged right edge
+    dict(F=1, H=48, W=32, cin=64, cout=128, k=3, stride=1, halo256=True),   # one chunk, 128-wide N tile
 ])
-def test_conv_gemm(gpu, dname, td, ulp, case):
+def test_conv_gemm(gpu, dname, td, ulp, case, monkeypatch):
     from videovanish_amd import hip, packing
     dt = hip.dtype_id(dname)
     g = torch.Generator().manual_seed(1)
@@ -54,6 +57,8 @@ def test_conv_gemm(gpu, dname, td, ulp, case):
     Ho, Wo = ref.shape[-2:]
     wp, K = packing.pack_conv(w, td)
     xin = _nhwc(x).to(gpu) if f32in else _nhwc(x).to(td).to(gpu)
+    if case.get("halo256"):
+        monkeypatch.setenv("VV_CONV3_HALO256", "1")
     out = hip.conv_gemm(dt, xin, wp.to(gpu), cout, K, F=Fr, Hin=H, Win=W, Hout=Ho, Wout=Wo, ksize=k, stride=stride, pad_t=k // 2,
                         pad_l=k // 2, bias=b.to(gpu), out_dtype=torch.float32)
     got = out.cpu().reshape(Fr, Ho, Wo, cout).permute(0, 3, 1, 2)
@@ -62,7 +67,7 @@ def test_conv_gemm(gpu, dname, td, ulp, case):
 
 
 @pytest.mark.parametrize("dname,td,ulp", DT)
-def test_conv_gemm_epilogues(gpu, dname, td, ulp):
+def test_conv_gemm_epilogues(gpu, dname, td, ulp, monkeypatch):
     """concat input + fused nearest upsample + temb rowvec + two residuals + h16 output; asymmetric pad; GEGLU."""
     from videovanish_amd import hip, packing
     dt = hip.dtype_id(dname)
@@ -106,6 +111,21 @@ def test_conv_gemm_epilogues(gpu, dname, td, ulp):
     assert (goth - refh_full).abs().max().item() <= 3e-4 * refh_full.abs().max().item()
     outh16 = hip.conv_gemm(dt, _nhwc(ah).to(td).to(gpu), wp.to(gpu), cout, K, **kwh)
     assert (outh16.float().cpu().reshape(Fr, Hh, Wh, cout).permute(0, 3, 1, 2) - refh).abs().max().item() <= 2 * ulp * refh.abs().max().item()
+    # the same through the opt-in 256-pixel halo kernel (32 x 46: 16 x 16 patch grid wastes 4 %)
+    monkeypatch.setenv("VV_CONV3_HALO256", "1")
+    Hh, Wh = 32, 46
+    ah, sh = torch.randn(Fr, c0, Hh, Wh, generator=g), torch.randn(Fr, c1, Hh, Wh, generator=g)
+    r0h, r1h = torch.randn(Fr, cout, Hh, Wh, generator=g), torch.randn(Fr, cout, Hh, Wh, generator=g)
+    refh = F.conv2d(torch.cat([_r(ah, td), _r(sh, td)], 1), _r(wt, td), bias, padding=1)
+    kwh = dict(x1=_nhwc(sh).to(td).to(gpu), F=Fr, Hin=Hh, Win=Wh, ksize=3, pad_t=1, pad_l=1, bias=bias.to(gpu))
+    outh = hip.conv_gemm(dt, _nhwc(ah).to(td).to(gpu), wp.to(gpu), cout, K, rowvec=temb.to(gpu), res0=_nhwc(r0h).to(gpu), res1=_nhwc(r1h).to(gpu),
+                         out_dtype=torch.float32, **kwh)
+    goth = outh.cpu().reshape(Fr, Hh, Wh, cout).permute(0, 3, 1, 2)
+    refh_full = refh + temb[:, :, None, None] + r0h + r1h
+    assert (goth - refh_full).abs().max().item() <= 3e-4 * refh_full.abs().max().item()
+    outh16 = hip.conv_gemm(dt, _nhwc(ah).to(td).to(gpu), wp.to(gpu), cout, K, **kwh)
+    assert (outh16.float().cpu().reshape(Fr, Hh, Wh, cout).permute(0, 3, 1, 2) - refh).abs().max().item() <= 2 * ulp * refh.abs().max().item()
+    monkeypatch.delenv("VV_CONV3_HALO256")
     # VAE-encoder style downsample: pad (0,1,0,1), stride 2, pad 0
     x = torch.randn(2, 64, 10, 12, generator=g)
     wd = torch.randn(128, 64, 3, 3, generator=g) / 24.0

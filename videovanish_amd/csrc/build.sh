@@ -7,12 +7,12 @@ mkdir -p build
 pids=()
 compile() {   # compile <src> <obj> [extra flags]
   local src=$1 obj=$2; shift 2
-  if [ ! -f build/$obj.o ] || [ $src.hip -nt build/$obj.o ] || [ vv_common.h -nt build/$obj.o ] || [ ../../include/vvhip.h -nt build/$obj.o ] || [ build.sh -nt build/$obj.o ]; then
+  if [ ! -f build/$obj.o ] || [ $src.hip -nt build/$obj.o ] || [ vv_common.h -nt build/$obj.o ] || [ vv_gemm_epilogue.h -nt build/$obj.o ] || [ ../../include/vvhip.h -nt build/$obj.o ] || [ build.sh -nt build/$obj.o ]; then
     hipcc $FLAGS "$@" -c $src.hip -o build/$obj.o &
     pids+=($!)
   fi
 }
-for f in vv_api vv_gemm vv_norm vv_elem vv_image vv_flow; do
+for f in vv_api vv_gemm vv_conv3 vv_norm vv_elem vv_image vv_flow; do
   [ -f $f.hip ] && compile $f $f
 done
 # attention, small head dims: MFMA results feed VALU code (softmax) every tile -> keep accumulators in arch VGPRs

@@ -21,11 +21,6 @@ __device__ __forceinline__ uint2 ds_read_tr16(const unsigned char* lds_ptr) {
     return __builtin_bit_cast(uint2, v);
 }
 
-// 64-byte pages the K/V LDS-DMA reads for slots that hold no tensor data: zeros (head-dim / pitch padding, keys past Nkv) and
-// {1.0, 0, ...} for the ONES column of V (index 0: bf16, 1: fp16)
-__device__ __attribute__((aligned(64))) const unsigned int g_attn_zero[16] = {0};
-__device__ __attribute__((aligned(64))) const unsigned int g_attn_ones[2][16] = {{0x3f80u}, {0x3c00u}};
-
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
     typedef const void __attribute__((address_space(1))) * gp_t;
     typedef void __attribute__((address_space(3))) * lp_t;
@@ -365,7 +360,6 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
             if (var == 7) return attn_launch<T, D, 2, 64, 8, true, 1>(p, st);      // 32 queries per wave, 8 waves = 256 per block
             if (var == 8) return attn_launch<T, D, 2, 64, 4, true>(p, st);         // register-staged K/V (the pre-DMA default)
             if (var == 9) return attn_launch<T, D, 2, 64, 4, false, 3, true>(p, st);   // DMA, capped at 168 VGPRs (3 waves/SIMD)
-            if (var == 11) return attn_launch<T, D, 2, 64, 4, false, 4, true>(p, st);   // DMA, capped at 128 VGPRs (4 waves/SIMD)
             if (var == 10) return attn_launch<T, D, 2, 64, 4, false, 1, true>(p, st);   // DMA, uncapped registers (2 waves/SIMD)
             // default for d <= 64: K/V by LDS-DMA, double buffered, 3 waves/SIMD (d = 80 would spill: stays register staged)
             if (D <= 64) return attn_launch<T, D, 2, 64, 4, false, 3, true>(p, st);

@@ -15,7 +15,11 @@
 // of one output row: the epilogue (bias, time-embedding vector, residuals, GEGLU, cast) is 16-byte vectorised.
 // The block index is remapped so that the column tiles of one row panel run on the same XCD (shared L2).
 #include <stdlib.h>
+#include <type_traits>
 #include "vv_common.h"
+#include "vv_gemm_epilogue.h"
+
+extern "C" int vv_conv3_halo_try(const vv_conv_params* pp, int dtype, void* stream);
 
 namespace {
 
@@ -319,116 +323,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params 
         }
     }
 
-    // ---- epilogue: lane owns out[m][n .. n+3].  All bias / time-embedding / residual loads of one 16-row strip are issued
-    // back to back into registers BEFORE their first use (one wait per strip instead of one per load).
-    const bool geglu = p.epilogue == VV_EPI_GEGLU;
-    const int N = p.N;
-    const bool vec = (N & 3) == 0 && (p.ldo & 3) == 0;
-    const bool r0f32 = p.res_dtype == VV_F32;
-    if (geglu) {
-        if constexpr (NT % 2 == 0) {
-            float4 bv[NT / 2], bg[NT / 2];
-#pragma unroll
-            for (int j = 0; j < NT; j += 2) {
-                const int n = n0 + wc * NT * 16 + j * 16 + 4 * lq;
-                bv[j / 2] = (p.bias && n < N) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                bg[j / 2] = (p.bias && n < N) ? *(const float4*)(p.bias + n + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                bool mok;
-                const int m = row_m(wr * MT * 16 + i * 16 + lr, mok);
-                if (!mok) continue;
-#pragma unroll
-                for (int j = 0; j < NT; j += 2) {
-                    const int nt0 = n0 + wc * NT * 16 + j * 16;
-                    if (nt0 + 4 * lq >= N) continue;
-                    const float bvv[4] = {bv[j / 2].x, bv[j / 2].y, bv[j / 2].z, bv[j / 2].w};
-                    const float bgg[4] = {bg[j / 2].x, bg[j / 2].y, bg[j / 2].z, bg[j / 2].w};
-                    float o[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (acc[i][j][r] + bvv[r]) * gelu_f(acc[i][j + 1][r] + bgg[r]);
-                    const int64_t oc = (int64_t)m * p.ldo + (nt0 >> 1) + 4 * lq;
-                    if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + oc) = make_float4(o[0], o[1], o[2], o[3]);
-                    else *(uint2*)((unsigned short*)p.out + oc) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
-                }
-            }
-        }
-        return;
-    }
-    if (vec) {
-        float4 b4[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = n0 + wc * NT * 16 + j * 16 + 4 * lq;
-            b4[j] = (p.bias && n < N) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            bool mok;
-            const int m = row_m(wr * MT * 16 + i * 16 + lr, mok);
-            const int64_t rbase = (int64_t)(mok ? m : 0) * N;
-            float4 ra4[NT];
-            // issue every res0 load of this strip first (the common residual); rarer addends are read in place
-            if (p.res0 && r0f32) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int n = n0 + wc * NT * 16 + j * 16 + 4 * lq;
-                    ra4[j] = (mok && n < N) ? *(const float4*)((const float*)p.res0 + rbase + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-            if (!mok) continue;
-            const float* rowv = p.rowvec ? p.rowvec + (int64_t)(m / HWo) * N : nullptr;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = n0 + wc * NT * 16 + j * 16 + 4 * lq;
-                if (n >= N) continue;
-                float v[4] = {(acc[i][j][0] + b4[j].x) * p.out_scale, (acc[i][j][1] + b4[j].y) * p.out_scale,
-                              (acc[i][j][2] + b4[j].z) * p.out_scale, (acc[i][j][3] + b4[j].w) * p.out_scale};
-                if (rowv) { const float4 t4 = *(const float4*)(rowv + n); v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w; }
-                if (p.res0) {
-                    if (r0f32) { v[0] += ra4[j].x; v[1] += ra4[j].y; v[2] += ra4[j].z; v[3] += ra4[j].w; }
-                    else { const uint2 r2 = *(const uint2*)((const unsigned short*)p.res0 + rbase + n); v[0] += T::to_f32(r2.x & 0xffff); v[1] += T::to_f32(r2.x >> 16); v[2] += T::to_f32(r2.y & 0xffff); v[3] += T::to_f32(r2.y >> 16); }
-                }
-                if (p.res1) {
-                    if (r0f32) { const float4 r4 = *(const float4*)((const float*)p.res1 + rbase + n); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
-                    else { const uint2 r2 = *(const uint2*)((const unsigned short*)p.res1 + rbase + n); v[0] += T::to_f32(r2.x & 0xffff); v[1] += T::to_f32(r2.x >> 16); v[2] += T::to_f32(r2.y & 0xffff); v[3] += T::to_f32(r2.y >> 16); }
-                }
-                if (p.act == VV_ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                const int64_t oc = (int64_t)m * p.ldo + n;
-                if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + oc) = make_float4(v[0], v[1], v[2], v[3]);
-                else *(uint2*)((unsigned short*)p.out + oc) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
-            }
-        }
-        return;
-    }
-    // scalar tail path (N or ldo not a multiple of 4: e.g. the 3-channel VAE conv_out)
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        bool mok;
-        const int m = row_m(wr * MT * 16 + i * 16 + lr, mok);
-        if (!mok) continue;
-        const float* rowv = p.rowvec ? p.rowvec + (int64_t)(m / HWo) * N : nullptr;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = n0 + wc * NT * 16 + j * 16 + 4 * lq;
-            const int64_t ri = (int64_t)m * N + n;
-            const int64_t oc = (int64_t)m * p.ldo + n;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (n + r >= N) continue;
-                float x = acc[i][j][r];
-                if (p.bias) x += p.bias[n + r];
-                x *= p.out_scale;
-                if (rowv) x += rowv[n + r];
-                if (p.res0) x += r0f32 ? ((const float*)p.res0)[ri + r] : T::to_f32(((const unsigned short*)p.res0)[ri + r]);
-                if (p.res1) x += r0f32 ? ((const float*)p.res1)[ri + r] : T::to_f32(((const unsigned short*)p.res1)[ri + r]);
-                if (p.act == VV_ACT_RELU) x = fmaxf(x, 0.f);
-                if (p.out_dtype == VV_F32) ((float*)p.out)[oc + r] = x;
-                else ((unsigned short*)p.out)[oc + r] = T::from_f32(x);
-            }
-        }
-    }
+    gemm_epilogue<T, MT, NT>(p, acc, wr * MT * 16, n0 + wc * NT * 16, lr, lq, HWo, row_m);
 }
 
 template <typename T, int WR, int WC, int MT, int NT, int MODE>
@@ -463,6 +358,10 @@ template <typename T>
 int launch_mode(const vv_conv_params& p, int M, hipStream_t st) {
     const bool fast = (p.C0 % 64 == 0) && (p.C1 % 64 == 0) && p.Kpad == p.K;
     static const bool no32 = getenv("VV_GEMM_NO_FAST32") != nullptr;
+    {   // large 3x3 feature maps: the 256-pixel halo kernel (vv_conv3.hip) when the shape is eligible
+        const int r = vv_conv3_halo_try(&p, std::is_same<T, BF16>::value ? VV_BF16 : VV_F16, (void*)st);
+        if (r > -1000) return r;
+    }
     static const bool nohalo = getenv("VV_GEMM_NO_HALO") != nullptr;
     if (fast && !nohalo && p.in_dtype != VV_F32 && p.ksize == 3 && (p.ksize_w == 0 || p.ksize_w == 3) && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 &&
         p.Hv == p.Hin && p.Wv == p.Win && p.Hout == p.Hin && p.Wout == p.Win && p.epilogue != VV_EPI_GEGLU && (p.Npad % 160 == 0 || p.Npad % 128 == 0)) {
