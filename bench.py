@@ -202,7 +202,7 @@ def main():
                     "seconds_per_step": round(t_motion / args.steps, 3), "share_of_step_time": round(t_motion / dt, 3),
                     "note": "all kernels launched by the motion modules (GroupNorm, LayerNorm+pos-emb, projections, temporal attention core, GEGLU FF)"}
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
         cpu = cpu_baseline(H, W, args.denoise_steps, args.chunk, args.overlap)
     res = {
         "metric": "inpainted frames/sec at 720p, 50 denoise steps", "value": round(distinct / dt, 5), "unit": "frames/s", "n_gpus": world,
