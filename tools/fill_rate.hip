@@ -51,7 +51,75 @@ __global__ __launch_bounds__(256, 2) void fill(const unsigned char* A, const uns
     acc += *(float*)(sB + t * 4);
     if (acc == 123.456f) out[0] = acc;
 }
+// short-K experiment: the fill stream of the QKV linear at level 0 (M=460800, N=960, K=320: 5 k tiles per block) followed by an
+// epilogue-like 40 KB store per block; PERSIST = 1: one resident block per slot walks over its tiles and issues the first
+// fill of the NEXT tile before the store of the current one
+template <int PERSIST>
+__global__ __launch_bounds__(256, 2) void shortk(const unsigned char* A, const unsigned char* B, unsigned char* O, int K, int tilesN, int ntiles, float* out) {
+    __shared__ __attribute__((aligned(16))) unsigned char sA[128 * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char sB[160 * 128];
+    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nk = K / 64;
+    float acc = 0.f;
+    auto fill1 = [&](int tile, int kt) {
+        const int tile_n = tile % tilesN, tile_m = tile / tilesN;
+        const unsigned char* a = A + ((size_t)(tile_m * 128 + (t >> 3)) * K) * 2 + (t & 7) * 16;
+        const unsigned char* b = B + ((size_t)(tile_n * 160 + (t >> 3)) * K) * 2 + (t & 7) * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(a + (size_t)(32 * i) * K * 2 + kt * 128, sA + wave * 1024 + i * 4096);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) glds16(b + (size_t)(32 * i) * K * 2 + kt * 128, sB + wave * 1024 + i * 4096);
+    };
+    auto store = [&](int tile) {
+        const int tile_n = tile % tilesN, tile_m = tile / tilesN;
+        uint4 v = make_uint4(__float_as_uint(acc), 1, 2, 3);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {      // 128 rows x 320 B
+            const int idx = i * 256 + t, row = idx / 20, ch = idx % 20;
+            *(uint4*)(O + ((size_t)(tile_m * 128 + row) * (tilesN * 160) + tile_n * 160) * 2 + ch * 16) = v;
+        }
+    };
+    if (PERSIST) {
+        int tile = blockIdx.x;
+        if (tile < ntiles) fill1(tile, 0);
+        for (; tile < ntiles; tile += gridDim.x) {
+            for (int kt = 0; kt < nk; ++kt) {
+                __syncthreads(); acc += *(float*)(sA + t * 4); __builtin_amdgcn_s_sleep(5); __syncthreads();
+                if (kt + 1 < nk) fill1(tile, kt + 1);
+                else if (tile + (int)gridDim.x < ntiles) fill1(tile + gridDim.x, 0);
+            }
+            store(tile);
+        }
+    } else {
+        const int tile = blockIdx.x;
+        for (int kt = 0; kt < nk; ++kt) {
+            fill1(tile, kt);
+            __syncthreads(); acc += *(float*)(sA + t * 4); __builtin_amdgcn_s_sleep(5); __syncthreads();
+        }
+        store(tile);
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+void run_shortk() {
+    const int M = 460800, N = 960, K = 320;
+    unsigned char *A, *B, *O; float* out;
+    hipMalloc(&A, (size_t)(M + 256) * K * 2); hipMalloc(&B, (size_t)(N + 256) * K * 2); hipMalloc(&O, (size_t)M * N * 2); hipMalloc(&out, 4);
+    hipMemset(A, 0, (size_t)(M + 256) * K * 2); hipMemset(B, 0, (size_t)(N + 256) * K * 2);
+    const int tilesM = M / 128, tilesN = N / 160, ntiles = tilesM * tilesN;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int mode = 0; mode < 2; ++mode)
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            if (mode == 0) shortk<0><<<ntiles, 256>>>(A, B, O, K, tilesN, ntiles, out);
+            else shortk<1><<<256 * 3, 256>>>(A, B, O, K, tilesN, ntiles, out);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("short-K (QKV L0) %s: %.3f ms  (fill %.2f TB/s, the GEMM would do %.0f TF/s)\n", mode ? "persistent, next tile's fill before the store" : "one block per tile            ",
+                   ms, (double)ntiles * 5 * 36864.0 / ms / 1e9, 2.0 * M * N * K / ms / 1e9);
+        }
+}
 int main() {
+    run_shortk();
     const int M = 115200, N = 640, K = 5760;    // conv3 L1 640->640 as a GEMM
     unsigned char *A, *B; float* out;
     hipMalloc(&A, (size_t)(M + 256) * K * 2); hipMalloc(&B, (size_t)(N + 256) * K * 2); hipMalloc(&out, 4);
