@@ -49,3 +49,39 @@ def test_round_trip_and_errors(tmp_path):
         ck.conv("brushnet.conv_in", 9, 16, 3)                              # component not loaded
     with pytest.raises(KeyError):
         CheckpointWeights(rec.components).normal("text_states", (1, 7, 8))  # text states must be supplied
+
+
+def test_merge_lora_formats():
+    """PCM-LoRA style merge: peft, diffusers and kohya naming give W + scale*alpha/rank * up@down."""
+    from videovanish_amd.checkpoint import merge_lora
+    g = torch.Generator().manual_seed(5)
+    base = {"down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight": torch.randn(16, 16, generator=g),
+            "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.bias": torch.randn(16, generator=g),
+            "down_blocks.0.resnets.0.conv1.weight": torch.randn(8, 4, 3, 3, generator=g),
+            "mid_block.attentions.0.proj_in.weight": torch.randn(16, 16, 1, 1, generator=g)}
+    q, cv, pi = (k for k in base if k.endswith(".weight"))
+    dq, uq = torch.randn(4, 16, generator=g), torch.randn(16, 4, generator=g)
+    dc, uc = torch.randn(2, 4, 3, 3, generator=g), torch.randn(8, 2, 1, 1, generator=g)
+    dp, up = torch.randn(4, 16, generator=g), torch.randn(16, 4, generator=g)
+    want_q = base[q] + 0.5 * (uq @ dq)
+    want_c = base[cv] + 0.5 * (8.0 / 2) * torch.einsum("or,rikl->oikl", uc[:, :, 0, 0], dc)
+    want_p = base[pi] + 0.5 * (up @ dp)[:, :, None, None]
+    lora = {"unet." + q[:-7] + ".lora_A.weight": dq, "unet." + q[:-7] + ".lora_B.weight": uq,                       # peft
+            "lora_unet_" + cv[:-7].replace(".", "_") + ".lora_down.weight": dc,                                      # kohya conv + alpha
+            "lora_unet_" + cv[:-7].replace(".", "_") + ".lora_up.weight": uc,
+            "lora_unet_" + cv[:-7].replace(".", "_") + ".alpha": torch.tensor(8.0),
+            pi[:-7] + ".lora.down.weight": dp, pi[:-7] + ".lora.up.weight": up}                                      # diffusers, linear LoRA on a 1x1 conv
+    sd = {k: v.clone() for k, v in base.items()}
+    merged = merge_lora(sd, lora, scale=0.5)
+    assert sorted(merged) == sorted([q[:-7], cv[:-7], pi[:-7]])
+    assert torch.allclose(sd[q], want_q, atol=1e-6) and torch.allclose(sd[cv], want_c, atol=1e-5) and torch.allclose(sd[pi], want_p, atol=1e-6)
+    assert torch.equal(sd[q[:-7] + ".bias"], base[q[:-7] + ".bias"])
+    # a merged layer behaves like base + LoRA branch
+    x = torch.randn(3, 16, generator=g)
+    assert torch.allclose(x @ sd[q].t(), x @ base[q].t() + 0.5 * (x @ dq.t()) @ uq.t(), atol=1e-5)
+    with pytest.raises(KeyError):
+        merge_lora({k: v.clone() for k, v in base.items()}, {"unet.up_blocks.9.to_q.lora_A.weight": dq, "unet.up_blocks.9.to_q.lora_B.weight": uq})
+    with pytest.raises(KeyError):
+        merge_lora({k: v.clone() for k, v in base.items()}, {"unet." + q[:-7] + ".lora_A.weight": dq})
+    with pytest.raises(KeyError):
+        merge_lora({k: v.clone() for k, v in base.items()}, {"something.else": dq})

@@ -110,3 +110,67 @@ class RecordingWeights:
             if name.endswith(suffix):
                 return self._rec(name[: -len(suffix)], suffix, t)
         return t
+
+
+# ---- LoRA merge (the reference loads the PCM "2-Step" LoRA on top of the SD-1.5 UNet: diffuerase.py:37 -> ckpt="2-Step") -------
+
+_LORA_PAIRS = ((".lora_A.weight", ".lora_B.weight"),            # peft
+               (".lora.down.weight", ".lora.up.weight"),        # diffusers attention-processor format
+               (".lora_down.weight", ".lora_up.weight"))        # kohya
+
+
+def _kohya_key(module_key):
+    return "lora_unet_" + module_key.replace(".", "_")
+
+
+def merge_lora(state_dict, lora, scale=1.0, prefix="unet."):
+    """Fold a LoRA into a component state dict IN PLACE: W += scale * (alpha / rank) * up @ down for every targeted layer.
+
+    `lora` may use the peft (`<module>.lora_A/lora_B.weight`), diffusers (`<module>.lora.down/up.weight`) or kohya
+    (`lora_unet_<module with _>.lora_down/up.weight` + `.alpha`) naming; an optional leading `prefix` ("unet.") is ignored.
+    Linear and k x k convolution LoRAs (down k x k, up 1 x 1) are supported.  Returns the list of merged module keys;
+    raises KeyError when a LoRA tensor targets a module the state dict does not have (nothing is silently dropped)."""
+    mods = {k[: -len(".weight")] for k in state_dict if k.endswith(".weight")}
+    kohya = {_kohya_key(m): m for m in mods}
+    pairs, alphas = {}, {}
+    for key, t in lora.items():
+        k = key[len(prefix):] if prefix and key.startswith(prefix) else key
+        if k.endswith(".alpha"):
+            alphas[k[: -len(".alpha")]] = float(t)
+            continue
+        for down_s, up_s in _LORA_PAIRS:
+            for s, slot in ((down_s, 0), (up_s, 1)):
+                if k.endswith(s):
+                    pairs.setdefault(k[: -len(s)], [None, None])[slot] = t
+                    break
+            else:
+                continue
+            break
+        else:
+            raise KeyError(f"merge_lora: unrecognised LoRA tensor name {key!r}")
+    merged = []
+    for base, (down, up) in pairs.items():
+        if down is None or up is None:
+            raise KeyError(f"merge_lora: {base!r} has only one of its down/up matrices")
+        # diffusers >= 0.22 names attention projections "to_q" in the model but "to_q_lora"/"processor.to_q_lora" in old LoRAs
+        mod = base.replace(".processor", "").replace("_lora", "")
+        mod = kohya.get(mod, mod)
+        if mod not in mods:
+            raise KeyError(f"merge_lora: LoRA targets {base!r} but the checkpoint has no module {mod!r}")
+        w = state_dict[mod + ".weight"]
+        rank = down.shape[0]
+        alpha = alphas.get(base, float(rank))
+        d32, u32 = down.to(torch.float32), up.to(torch.float32)
+        if w.dim() == 4:
+            if u32.dim() == 2:
+                u32 = u32[:, :, None, None]
+            if d32.dim() == 2:
+                d32 = d32[:, :, None, None]
+            delta = torch.einsum("or,rikl->oikl", u32.reshape(u32.shape[0], rank), d32)     # up is 1x1
+            if delta.shape != w.shape:
+                delta = delta.reshape(w.shape)
+        else:
+            delta = u32.reshape(u32.shape[0], rank) @ d32.reshape(rank, -1)
+        state_dict[mod + ".weight"] = (w.to(torch.float32) + (scale * alpha / rank) * delta).to(w.dtype)
+        merged.append(mod)
+    return merged
