@@ -365,9 +365,9 @@ int launch_mode(const vv_conv_params& p, int M, hipStream_t st) {
     static const bool nohalo = getenv("VV_GEMM_NO_HALO") != nullptr;
     if (fast && !nohalo && p.in_dtype != VV_F32 && p.ksize == 3 && (p.ksize_w == 0 || p.ksize_w == 3) && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 &&
         p.Hv == p.Hin && p.Wv == p.Win && p.Hout == p.Hin && p.Wout == p.Win && p.epilogue != VV_EPI_GEGLU && (p.Npad % 160 == 0 || p.Npad % 128 == 0)) {
-        // patch grid waste <= 10 %
+        // patch grid waste <= 15 % (the halo tile is worth 17-25 %)
         const int64_t cover = (int64_t)((p.Hin + 7) / 8) * 8 * ((p.Win + 15) / 16) * 16;
-        if (cover * 10 <= (int64_t)p.Hin * p.Win * 11) return launch_t<T, MODE_HALO>(p, M, st);
+        if (cover * 100 <= (int64_t)p.Hin * p.Win * 115) return launch_t<T, MODE_HALO>(p, M, st);
     }
     if (p.in_dtype == VV_F32) return (fast && !no32) ? launch_t<T, MODE_FAST32>(p, M, st) : launch_t<T, MODE_F32>(p, M, st);
     return fast ? launch_t<T, MODE_FAST>(p, M, st) : launch_t<T, MODE_H16>(p, M, st);
