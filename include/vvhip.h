@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VV_ABI_VERSION 2
+#define VV_ABI_VERSION 3
 
 enum { VV_BF16 = 0, VV_F16 = 1, VV_F32 = 2, VV_U8 = 3 };
 enum { VV_OK = 0, VV_E_ARG = -1, VV_E_UNSUPPORTED = -2, VV_E_LAUNCH = -3 };
@@ -77,6 +77,11 @@ typedef struct {
     float out_scale;      /* multiplies the accumulated product+bias before residuals (1.0f = none) */
     int32_t ksize_w;      /* kernel width (0 = same as ksize); k = (ky*ksize_w + kx)*Cin + c */
     int32_t act;          /* VV_ACT_NONE or VV_ACT_RELU applied last (after residuals) */
+    int32_t split_heads;  /* > 0: head-major store for a fused QKV projection (h16 out, no residuals): column n = (which, head, d) with
+                             N = 3 * split_heads * split_dim, row m = (b, token) with split_tokens rows per b;
+                             out[(((b*3 + which)*split_heads + head)*split_tokens + token)*split_dim + d]; ldo is ignored */
+    int32_t split_dim;    /* head dim (multiple of 4) */
+    int32_t split_tokens; /* rows per batch element */
 } vv_conv_params;
 int vv_conv_gemm(const vv_conv_params* host_p, int dtype, void* stream);
 
@@ -107,7 +112,7 @@ int vv_layernorm(const float* x, int M, int C, const float* gamma, const float* 
 /* ------------------------------------------------------------------------------------------------------------
  * K3/K4/K5  fused attention: online-softmax flash attention on MFMA with LDS-staged K/V tiles
  * (S^T = K Q^T so every lane owns one query column; V read through ds_read_b64_tr_b16).
- *   element (b, h, i, c) of q lives at q[b*q_bs + h*D + i*q_rs + c]  (same for k, v, o with their strides)
+ *   element (b, h, i, c) of q lives at q[b*q_bs + h*q_hs + i*q_rs + c], q_hs = D when 0  (same for k, v; o: o[b*o_bs + h*D + i*o_rs + c])
  * spatial self-attention : b = frame, i = pixel (rows of the fused QKV GEMM output, row stride 3C)
  * cross-attention        : K/V have Nkv = 77 rows, kv batch stride 0 (one text tensor for all frames)
  * temporal attention     : b = pixel, i = frame  (q_bs = 3C, q_rs = HW*3C): the (f,hw)->(hw,f) gather is fused
@@ -120,6 +125,9 @@ typedef struct {
     int64_t q_rs, k_rs, v_rs, o_rs;   /* row strides (elements) */
     int32_t B, heads, Nq, Nkv, D;     /* D in {32,40,64,80,160,512} */
     float scale;                      /* softmax scale (D^-1/2) */
+    int64_t q_hs, k_hs, v_hs;         /* head strides (elements) of q / k / v; 0 = D (heads side by side inside a row).  The
+                                         head-major QKV layout written by vv_conv_gemm's split_heads store uses
+                                         hs = Nq*D, rs = D: a head's K/V rows are contiguous 2*D-byte records */
 } vv_attn_params;
 int vv_attention(const vv_attn_params* host_p, int dtype, void* stream);
 

@@ -232,6 +232,34 @@ def test_attention_spatial(gpu, dname, td, ulp, B, heads, Nq, Nkv, D):
                       o_bs=Nq * C, q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C, k_off=C, v_off=2 * C)
     got = out.float().cpu().reshape(B, Nq, heads, D)
     assert (got - ref).abs().max().item() <= 4 * ulp * max(1.0, ref.abs().max().item())
+    if not shared_kv:
+        # head-major layout [b][q|k|v][head][token][D] (what vv_conv_gemm's split_heads store writes): same result bit for bit
+        hm = torch.stack([q, k, v], 1).permute(0, 1, 3, 2, 4).contiguous().to(td).to(gpu)      # [B,3,heads,N,D]
+        out2 = torch.empty_like(out)
+        hip.attention(dt, hm, hm, hm, out2, B=B, heads=heads, Nq=Nq, Nkv=Nkv, D=D, q_bs=3 * Nq * C, k_bs=3 * Nq * C, v_bs=3 * Nq * C,
+                      o_bs=Nq * C, q_rs=D, k_rs=D, v_rs=D, o_rs=C, k_off=Nq * C, v_off=2 * Nq * C, q_hs=Nq * D, k_hs=Nq * D, v_hs=Nq * D)
+        assert torch.equal(out2.cpu(), out.cpu())
+
+
+@pytest.mark.parametrize("dname,td,ulp", DT)
+def test_conv_gemm_split_heads(gpu, dname, td, ulp):
+    """fused QKV projection with the head-major store: out[b][which][head][token][d] == linear(x)[b*T+token][which*C + head*D + d]."""
+    from videovanish_amd import hip, packing
+    dt = hip.dtype_id(dname)
+    g = torch.Generator().manual_seed(15)
+    B, T, heads, D = 3, 70, 8, 40
+    C = heads * D
+    x = torch.randn(B * T, C, generator=g)
+    w = torch.randn(3 * C, C, generator=g) / math.sqrt(C)
+    wp = packing.pack_matrix(w, td).to(gpu)
+    plain = hip.conv_gemm(dt, x.to(td).to(gpu), wp, 3 * C, C, F=1, Hin=B * T, Win=1)
+    split = hip.conv_gemm(dt, x.to(td).to(gpu), wp, 3 * C, C, F=1, Hin=B * T, Win=1, split_heads=heads, split_dim=D, split_tokens=T)
+    want = plain.cpu().reshape(B, T, 3, heads, D).permute(0, 2, 3, 1, 4).contiguous()
+    assert torch.equal(split.cpu().reshape(B, 3, heads, T, D), want)
+    ref = F.linear(_r(x, td), _r(w, td))
+    assert (plain.float().cpu() - ref).abs().max().item() <= 2 * ulp * ref.abs().max().item()
+    with pytest.raises(RuntimeError):
+        hip.conv_gemm(dt, x.to(td).to(gpu), wp, 3 * C, C, F=1, Hin=B * T, Win=1, split_heads=heads, split_dim=D, split_tokens=T, out_dtype=torch.float32)
 
 
 @pytest.mark.parametrize("dname,td,ulp", DT)

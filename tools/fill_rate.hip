@@ -118,7 +118,40 @@ void run_shortk() {
                    ms, (double)ntiles * 5 * 36864.0 / ms / 1e9, 2.0 * M * N * K / ms / 1e9);
         }
 }
+// BK = 128 variant of the fill stream: 256 contiguous bytes per row and k tile, 72 KB per tile, 2 blocks per CU
+__global__ __launch_bounds__(256, 2) void fill128(const unsigned char* A, const unsigned char* B, int K, int tilesN, int nk, float* out) {
+    __shared__ __attribute__((aligned(16))) unsigned char sA[128 * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char sB[160 * 256];
+    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tile_n = blockIdx.x % tilesN, tile_m = blockIdx.x / tilesN;
+    const unsigned char* a = A + ((size_t)(tile_m * 128 + (t >> 4)) * K) * 2 + (t & 15) * 16;
+    const unsigned char* b = B + ((size_t)(tile_n * 160 + (t >> 4)) * K) * 2 + (t & 15) * 16;
+    float acc = 0.f;
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) glds16(a + (size_t)(16 * i) * K * 2 + kt * 256, sA + wave * 1024 + i * 4096);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) glds16(b + (size_t)(16 * i) * K * 2 + kt * 256, sB + wave * 1024 + i * 4096);
+        __syncthreads(); acc += *(float*)(sA + t * 4); __syncthreads();
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+void run_fill128() {
+    const int M = 115200, N = 640, K = 5760;
+    unsigned char *A, *B; float* out;
+    hipMalloc(&A, (size_t)(M + 256) * K * 2); hipMalloc(&B, (size_t)(N + 256) * K * 2); hipMalloc(&out, 4);
+    hipMemset(A, 0, (size_t)(M + 256) * K * 2); hipMemset(B, 0, (size_t)(N + 256) * K * 2);
+    const int tilesM = M / 128, tilesN = N / 160, nk = K / 128;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0); fill128<<<tilesM * tilesN, 256>>>(A, B, K, tilesN, nk, out); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("BK=128 DMA + barrier per tile (72 KB tiles, 2 blocks/CU): %.3f ms, %.2f TB/s\n", ms, (double)tilesM * tilesN * nk * 73728.0 / ms / 1e9);
+    }
+    hipFree(A); hipFree(B);
+}
 int main() {
+    run_fill128();
     run_shortk();
     const int M = 115200, N = 640, K = 5760;    // conv3 L1 640->640 as a GEMM
     unsigned char *A, *B; float* out;

@@ -11,7 +11,7 @@ import torch
 BF16, F16, F32, U8 = 0, 1, 2, 3
 EPI_NONE, EPI_GEGLU = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 _DT = {"bf16": BF16, "fp16": F16}
 _TORCH_H16 = {BF16: torch.bfloat16, F16: torch.float16}
 
@@ -51,7 +51,7 @@ class ConvParams(C.Structure):
                 ("Kpad", C.c_int32), ("Npad", C.c_int32), ("bias", C.c_void_p), ("rowvec", C.c_void_p),
                 ("res0", C.c_void_p), ("res1", C.c_void_p), ("res_dtype", C.c_int32), ("out", C.c_void_p),
                 ("out_dtype", C.c_int32), ("ldo", C.c_int32), ("epilogue", C.c_int32), ("out_scale", C.c_float), ("ksize_w", C.c_int32),
-                ("act", C.c_int32)]
+                ("act", C.c_int32), ("split_heads", C.c_int32), ("split_dim", C.c_int32), ("split_tokens", C.c_int32)]
 
 
 class GroupNormParams(C.Structure):
@@ -66,7 +66,7 @@ class AttnParams(C.Structure):
                 ("q_bs", C.c_int64), ("k_bs", C.c_int64), ("v_bs", C.c_int64), ("o_bs", C.c_int64),
                 ("q_rs", C.c_int64), ("k_rs", C.c_int64), ("v_rs", C.c_int64), ("o_rs", C.c_int64),
                 ("B", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nkv", C.c_int32), ("D", C.c_int32),
-                ("scale", C.c_float)]
+                ("scale", C.c_float), ("q_hs", C.c_int64), ("k_hs", C.c_int64), ("v_hs", C.c_int64)]
 
 
 EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name", "vv_conv_gemm", "vv_groupnorm_nsplit",
@@ -133,7 +133,7 @@ def _need_cuda(*ts):
 # ----------------------------------------------------------------------------------------------------------------
 def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, Wv=None, Hout=None, Wout=None, ksize=1,
               stride=1, pad_t=0, pad_l=0, bias=None, rowvec=None, res0=None, res1=None, out=None, out_dtype=None,
-              epilogue=EPI_NONE, out_scale=1.0, C0=None, C1=0, ksize_w=0, act=ACT_NONE, out_col=0):
+              epilogue=EPI_NONE, out_scale=1.0, C0=None, C1=0, ksize_w=0, act=ACT_NONE, out_col=0, split_heads=0, split_dim=0, split_tokens=0):
     """Launch vv_conv_gemm.  x0/x1: NHWC activations ([F,Hin,Win,C] or any shape with C last); weight: [Npad,Kpad] h16."""
     _need_cuda(x0, x1, weight, bias, rowvec, res0, res1, out)      # out_col: write into columns [out_col, out_col+N) of `out`
     Hv = Hin if Hv is None else Hv
@@ -155,7 +155,8 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
                    res0=res0.data_ptr() if res0 is not None else 0, res1=res1.data_ptr() if res1 is not None else 0,
                    res_dtype=dt_of(res0) if res0 is not None else F32, out=out.data_ptr() + out_col * out.element_size(), out_dtype=dt_of(out),
                    ldo=out.shape[-1],
-                   epilogue=epilogue, out_scale=out_scale, ksize_w=ksize_w, act=act)
+                   epilogue=epilogue, out_scale=out_scale, ksize_w=ksize_w, act=act, split_heads=split_heads, split_dim=split_dim,
+                   split_tokens=split_tokens)
     if PROFILE is not None:
         Npad = weight.shape[0]
         tile = "128x128" if epilogue == EPI_GEGLU else ("128x160" if Npad % 160 == 0 else ("128x128" if Npad % 128 == 0 else "128x16"))
@@ -197,13 +198,14 @@ def layernorm(dtype, x, gamma, beta, pe=None, rows_per_frame=1):
     return out
 
 
-def attention(dtype, q, k, v, out, *, B, heads, Nq, Nkv, D, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, q_off=0, k_off=0, v_off=0):
+def attention(dtype, q, k, v, out, *, B, heads, Nq, Nkv, D, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, q_off=0, k_off=0, v_off=0,
+              q_hs=0, k_hs=0, v_hs=0):
     """q/k/v/out: h16 tensors (any shape); element offsets *_off select a column block inside a fused QKV buffer."""
     _need_cuda(q, k, v, out)
     es = 2
     p = AttnParams(q=q.data_ptr() + q_off * es, k=k.data_ptr() + k_off * es, v=v.data_ptr() + v_off * es, o=out.data_ptr(),
                    q_bs=q_bs, k_bs=k_bs, v_bs=v_bs, o_bs=o_bs, q_rs=q_rs, k_rs=k_rs, v_rs=v_rs, o_rs=o_rs, B=B, heads=heads, Nq=Nq,
-                   Nkv=Nkv, D=D, scale=float(D) ** -0.5)
+                   Nkv=Nkv, D=D, scale=float(D) ** -0.5, q_hs=q_hs, k_hs=k_hs, v_hs=v_hs)
     kind = "temporal" if (Nq <= 32 and Nkv <= 32) else ("cross" if Nkv < 128 and Nq != Nkv else "spatial")
     if os.environ.get("VV_PROFILE_SHAPES"):
         kind = f"B{B},N{Nq}|" + kind

@@ -75,10 +75,12 @@ class Linear:
         self.w = ctx.dev(packing.pack_matrix(weight, ctx.h16, geglu=geglu))
         self.b = ctx.dev(bias_t.float()) if bias_t is not None else None
 
-    def __call__(self, x, res0=None, res1=None, out_dtype=torch.float32, rows_per_frame=None, out=None):
+    def __call__(self, x, res0=None, res1=None, out_dtype=torch.float32, rows_per_frame=None, out=None, split=None):
+        """split = (heads, head_dim, tokens_per_batch): head-major store of a fused QKV projection (hip.conv_gemm split_heads)."""
         M = x.shape[0]
+        kw = dict(split_heads=split[0], split_dim=split[1], split_tokens=split[2]) if split else {}
         return hip.conv_gemm(self.ctx.dt, x, self.w, self.cout, self.K, F=1, Hin=M, Win=1, bias=self.b, res0=res0, res1=res1,
-                             out_dtype=out_dtype, out=out, epilogue=hip.EPI_GEGLU if self.geglu else hip.EPI_NONE)
+                             out_dtype=out_dtype, out=out, epilogue=hip.EPI_GEGLU if self.geglu else hip.EPI_NONE, **kw)
 
 
 class GroupNorm:
@@ -143,11 +145,14 @@ class SelfAttention:
         self.out = Linear(ctx, name + ".to_out.0", C, C)
 
     def spatial(self, n, res, B, N):
-        C, dt = self.C, self.ctx.dt
-        qkv = self.qkv(n, out_dtype=self.ctx.h16)
+        C, dt, D = self.C, self.ctx.dt, self.C // self.heads
+        # head-major QKV ([frame][q|k|v][head][token][D]): a head's K/V rows are contiguous 2*D-byte records, so the K/V tile
+        # DMA of the attention kernel reads whole cache lines (the [token][3C] layout over-fetched 2.6x at D = 40)
+        qkv = self.qkv(n, out_dtype=self.ctx.h16, split=(self.heads, D, N))
         o = torch.empty((B * N, C), dtype=self.ctx.h16, device=n.device)
-        hip.attention(dt, qkv, qkv, qkv, o, B=B, heads=self.heads, Nq=N, Nkv=N, D=C // self.heads, q_bs=N * 3 * C, k_bs=N * 3 * C,
-                      v_bs=N * 3 * C, o_bs=N * C, q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C, k_off=C, v_off=2 * C)
+        hip.attention(dt, qkv, qkv, qkv, o, B=B, heads=self.heads, Nq=N, Nkv=N, D=D, q_bs=N * 3 * C, k_bs=N * 3 * C,
+                      v_bs=N * 3 * C, o_bs=N * C, q_rs=D, k_rs=D, v_rs=D, o_rs=C, k_off=N * C, v_off=2 * N * C,
+                      q_hs=N * D, k_hs=N * D, v_hs=N * D)
         return self.out(o, res0=res)
 
     def temporal(self, n, res, Fr, HW, res1=None):
