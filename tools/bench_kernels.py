@@ -29,9 +29,14 @@ def gemm_cases():
     M = F * h * w
     cases = [
         ("qkv  L0 K320 N960", dict(F=F, H=h, W=w, cin=320, cout=960, k=1)),
+        ("qkv  L0 K320 N960 head-major store", dict(F=F, H=h, W=w, cin=320, cout=960, k=1, split=(8, 40, h * w))),
         ("out  L0 K320 N320 +res f32", dict(F=F, H=h, W=w, cin=320, cout=320, k=1, res=True)),
         ("geglu L0 K320 N2560", dict(F=F, H=h, W=w, cin=320, cout=2560, k=1, geglu=True)),
         ("ffout L0 K1280 N320 +res", dict(F=F, H=h, W=w, cin=1280, cout=320, k=1, res=True)),
+        ("qkv  L1 K640 N1920", dict(F=F, H=45, W=80, cin=640, cout=1920, k=1)),
+        ("out  L1 K640 N640 +res f32", dict(F=F, H=45, W=80, cin=640, cout=640, k=1, res=True)),
+        ("ffout L1 K2560 N640 +res", dict(F=F, H=45, W=80, cin=2560, cout=640, k=1, res=True)),
+        ("out  L2 K1280 N1280 +res f32", dict(F=F, H=23, W=40, cin=1280, cout=1280, k=1, res=True)),
         ("conv3 L0 320->320 +res", dict(F=F, H=h, W=w, cin=320, cout=320, k=3, res=True)),
         ("conv3 L0 640->320 (cat) f32out", dict(F=F, H=h, W=w, cin=640, cout=320, k=3)),
         ("conv3 L1 640->640", dict(F=F, H=45, W=80, cin=640, cout=640, k=3)),
@@ -66,8 +71,10 @@ def gemm_cases():
         res = torch.randn(M, cout, device=dev) if c.get("res") else None
         od = torch.float32 if (c.get("res") or "f32out" in name) else td
         out = torch.empty(M, cout // 2 if geglu else cout, dtype=od, device=dev)
+        sp = c.get("split")
+        skw = dict(split_heads=sp[0], split_dim=sp[1], split_tokens=sp[2]) if sp else {}
         fn = lambda: hip.conv_gemm(DT, xin, wp, cout, K, F=Fr, Hin=H, Win=W, ksize=k, pad_t=k // 2, pad_l=k // 2, bias=bias, res0=res, out=out,
-                                   epilogue=hip.EPI_GEGLU if geglu else hip.EPI_NONE)
+                                   epilogue=hip.EPI_GEGLU if geglu else hip.EPI_NONE, **skw)
         t = timeit(fn)
         fl = 2.0 * M * cout * K
         by = xin.numel() * xin.element_size() + out.numel() * out.element_size() + (res.numel() * 4 if res is not None else 0)

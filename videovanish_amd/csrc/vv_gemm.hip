@@ -35,8 +35,8 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gp_t)gptr, (lp_t)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int WR, int WC, int MT, int NT, int MODE, int SPLIT, int BKT>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const vv_conv_params p, const int M, const int tilesM, const int tilesN) {
+template <typename T, int WR, int WC, int MT, int NT, int MODE, int SPLIT, int BKT, int OCCW = 2>
+__global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_params p, const int M, const int tilesM, const int tilesN) {
     constexpr int BM = WR * MT * 16, BN = WC * NT * 16;
     constexpr int CH = BKT / 8;                 // 16-byte chunks per tile row (8 for a 64-wide k tile, 4 for 32)
     constexpr int SH = CH == 8 ? 3 : 2;         // log2(CH)
@@ -335,7 +335,11 @@ int launch_cfg(const vv_conv_params& p, int M, hipStream_t st) {
     if constexpr (MODE == MODE_HALO) tilesM = p.F * ((p.Hin + 7) / 8) * ((p.Win + 15) / 16);
     static int split = -1;
     if (split < 0) { const char* e = getenv("VV_GEMM_SPLIT"); split = e ? atoi(e) : 2; }
-    if constexpr (MODE == MODE_FAST32 || MODE == MODE_HALO) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
+    // 128x128 tiles: 130 VGPRs uncapped; capping at 128 (4 spilled) lets a 4th block share the CU (LDS 4 x 32-40 KB)
+    static const bool occ4 = getenv("VV_GEMM_NO_OCC4") == nullptr;
+    constexpr bool CAN4 = WR * MT * WC * NT == 64 && (MODE == MODE_FAST || MODE == MODE_HALO);
+    if (CAN4 && occ4 && (MODE == MODE_HALO || split == 2)) { if constexpr (CAN4) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2, 64, 4>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN); }
+    else if constexpr (MODE == MODE_FAST32 || MODE == MODE_HALO) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     else if (split == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 1, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     else if (split == 3 && MODE == MODE_FAST) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 1, 32>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     else if (split == 0) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 0, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
@@ -348,6 +352,10 @@ template <typename T, int MODE>
 int launch_t(const vv_conv_params& p, int M, hipStream_t st) {
     // tile choice: GEGLU needs an even number of N tiles per wave; N % 160 == 0 -> 128x160; tiny N -> 128x16
     if (p.epilogue == VV_EPI_GEGLU) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, M, st);
+    // N a multiple of both: the 128x128 tile runs 4 blocks per CU (128 VGPRs) against 3 for 128x160 -> +2..8 % on the LDS-DMA
+    // loaders when there are enough row tiles (profiles/r1_gemm_ab.txt, eighth A/B)
+    static const bool pref128 = getenv("VV_GEMM_NO_PREF128") == nullptr && getenv("VV_GEMM_NO_OCC4") == nullptr;
+    if (pref128 && p.Npad % 128 == 0 && (MODE == MODE_FAST || MODE == MODE_HALO) && M >= 16384) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, M, st);
     if (p.Npad % 160 == 0) return launch_cfg<T, 2, 2, 4, 5, MODE>(p, M, st);   // (a 256x160 4-wave tile measured the same: profiles/r1_gemm_ab.txt)
     if (p.Npad % 128 == 0) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, M, st);
     if (p.Npad % 16 == 0 && p.Npad <= 64) return launch_cfg<T, 4, 1, 2, 1, MODE>(p, M, st);
@@ -392,7 +400,8 @@ extern "C" int vv_conv_gemm(const vv_conv_params* pp, int dtype, void* stream) {
     if ((p.res0 || p.res1) && p.res_dtype != VV_F32 && p.res_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_conv_gemm: res_dtype mismatch");
     if (p.epilogue == VV_EPI_GEGLU && (p.N % 32 || p.rowvec || p.res0 || p.res1 || (p.ldo & 3))) VV_FAIL(VV_E_ARG, "vv_conv_gemm: GEGLU needs N%%32==0, ldo%%4==0 and no residual/rowvec");
     if (p.split_heads > 0 && (p.split_dim <= 0 || (p.split_dim & 3) || p.split_tokens <= 0 || p.N != 3 * p.split_heads * p.split_dim || p.out_dtype == VV_F32 ||
-                              p.res0 || p.res1 || p.epilogue == VV_EPI_GEGLU || ((int64_t)p.F * p.Hout * p.Wout) % p.split_tokens))
+                              p.res0 || p.res1 || p.epilogue == VV_EPI_GEGLU || ((int64_t)p.F * p.Hout * p.Wout) % p.split_tokens ||
+                              (int64_t)p.N * p.split_tokens > 0x7fffffff))
         VV_FAIL(VV_E_ARG, "vv_conv_gemm: split_heads needs N = 3*heads*dim, dim %% 4 == 0, h16 output, no residual / GEGLU, M %% split_tokens == 0");
     if (p.F <= 0 || p.Hout <= 0 || p.Wout <= 0 || p.Hin <= 0 || p.Win <= 0 || p.Hv <= 0 || p.Wv <= 0) VV_FAIL(VV_E_ARG, "vv_conv_gemm: bad geometry");
     const int64_t M64 = (int64_t)p.F * p.Hout * p.Wout;

@@ -46,10 +46,17 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
     }
     if (vec) {
         float4 b4[NT];
+        int colpart[NT];          // split_heads store: the column's (which, head, d) part of the output index (< 3*C*tokens)
+        const bool split = p.split_heads > 0;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int n = ncol0 + j * 16 + 4 * lq;
             b4[j] = (p.bias && n < N) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            colpart[j] = 0;
+            if (split) {
+                const int wh = n / p.split_dim;                       // which * heads + head
+                colpart[j] = wh * p.split_tokens * p.split_dim + (n - wh * p.split_dim);
+            }
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -67,6 +74,8 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
             }
             if (!mok) continue;
             const float* rowv = p.rowvec ? p.rowvec + (int64_t)(m / HWo) * N : nullptr;
+            int64_t rowpart = 0;
+            if (split) { const int b = m / p.split_tokens; rowpart = ((int64_t)b * 3 * p.split_heads * p.split_tokens + (m - b * p.split_tokens)) * p.split_dim; }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = ncol0 + j * 16 + 4 * lq;
@@ -83,13 +92,8 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
                     else { const uint2 r2 = *(const uint2*)((const unsigned short*)p.res1 + rbase + n); v[0] += T::to_f32(r2.x & 0xffff); v[1] += T::to_f32(r2.x >> 16); v[2] += T::to_f32(r2.y & 0xffff); v[3] += T::to_f32(r2.y >> 16); }
                 }
                 if (p.act == VV_ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                int64_t oc = (int64_t)m * p.ldo + n;
-                if (p.split_heads > 0) {       // head-major QKV store: (b, which, head, token, d)
-                    const int hd = p.split_heads * p.split_dim;
-                    const int which = n / hd, nh = n - which * hd, head = nh / p.split_dim, d = nh - head * p.split_dim;
-                    const int b = m / p.split_tokens, tok = m - b * p.split_tokens;
-                    oc = ((((int64_t)b * 3 + which) * p.split_heads + head) * p.split_tokens + tok) * p.split_dim + d;
-                }
+                // head-major QKV store: out[b][which][head][token][d] = row part + column part
+                const int64_t oc = split ? rowpart + colpart[j] : (int64_t)m * p.ldo + n;
                 if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + oc) = make_float4(v[0], v[1], v[2], v[3]);
                 else *(uint2*)((unsigned short*)p.out + oc) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
             }

@@ -159,7 +159,10 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
                    split_tokens=split_tokens)
     if PROFILE is not None:
         Npad = weight.shape[0]
-        tile = "128x128" if epilogue == EPI_GEGLU else ("128x160" if Npad % 160 == 0 else ("128x128" if Npad % 128 == 0 else "128x16"))
+        # mirror of launch_t() in vv_gemm.hip (label only): LDS-DMA loaders prefer the 128x128 tile (4 blocks per CU) when N allows
+        dma = x0.dtype != torch.float32 and C0 % 64 == 0 and C1 % 64 == 0 and weight.shape[1] == K
+        tile = "128x128" if (epilogue == EPI_GEGLU or (Npad % 128 == 0 and dma and M >= 16384)) else (
+            "128x160" if Npad % 160 == 0 else ("128x128" if Npad % 128 == 0 else "128x16"))
         if os.environ.get("VV_PROFILE_SHAPES"):
             tile = f"M{M},N{N},K{K}|" + tile
         key = f"conv_gemm[{tile},{'f32in' if x0.dtype == torch.float32 else 'h16in'},k{ksize}{'x%d' % ksize_w if ksize_w and ksize_w != ksize else ''}]"
