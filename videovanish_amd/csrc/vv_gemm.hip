@@ -24,7 +24,7 @@ extern "C" int vv_conv3_halo_try(const vv_conv_params* pp, int dtype, void* stre
 namespace {
 
 constexpr int BK = 64;
-enum { MODE_H16 = 0, MODE_F32 = 1, MODE_FAST = 2, MODE_FAST32 = 3, MODE_HALO = 4 };
+enum { MODE_H16 = 0, MODE_F32 = 1, MODE_FAST = 2, MODE_FAST32 = 3, MODE_HALO = 4, MODE_LIN = 5 };
 constexpr int HALO_PX = 184;   // (8+2) x (16+2) = 180 halo pixels of an 8x16 output patch, padded to whole 1 KB DMA blocks
 
 __device__ __attribute__((aligned(64))) const unsigned int g_zero_page[16] = {0};
@@ -47,7 +47,10 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
     constexpr int KS = BKT / 32;                // MFMA k steps per tile
     // HALO (3x3, stride 1, h16): the M tile is an 8 x 16 pixel patch of one frame; per 64-channel chunk its 10 x 18 halo is
     // DMA'd ONCE and the 9 taps read their A operands out of it (L2->LDS bytes per 9 k tiles: 23 + 9*20 KB instead of 9*36)
-    constexpr bool AF32 = MODE == MODE_F32, A32 = MODE == MODE_FAST32, HALO = MODE == MODE_HALO, FAST = MODE == MODE_FAST || A32 || HALO;
+    // LIN (plain linear layer / 1x1 stride-1 conv, one h16 source): rows of A are consecutive, no gather state at all -> the kernel
+    // fits 128 VGPRs and a 4th block shares the CU
+    constexpr bool AF32 = MODE == MODE_F32, A32 = MODE == MODE_FAST32, HALO = MODE == MODE_HALO, LIN = MODE == MODE_LIN;
+    constexpr bool FAST = MODE == MODE_FAST || A32 || HALO || LIN;
     static_assert(!HALO || (WR * MT == 8 && SPLIT == 2 && BKT == 64), "HALO: 128-row tile, single buffer");
     constexpr int HP = HALO ? (HALO_PX * 8 + 255) / 256 : 1;    // halo DMA passes
     // FAST32: the fp32 A tile is DMA'd as fp32 (256-byte rows, 16 chunks) and rounded to h16 when the operand is read
@@ -102,8 +105,18 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
     // per-row gather state
     int rpix[ARA], ryb[ARA], rxb[ARA], rfr[ARA];
     bool rv[ARA];
+    // LIN: byte pointer of (row m0 + (t >> 3), chunk swizzled); rows past M are clamped to M-1 (never stored by the epilogue)
+    const unsigned char* linA[LIN ? ARA : 1];
+    if constexpr (LIN) {
 #pragma unroll
-    for (int i = 0; i < ARA; ++i) {
+        for (int i = 0; i < ARA; ++i) {
+            int m = m0 + (t >> SHA) + RPBA * i;
+            m = m < M ? m : M - 1;
+            linA[i] = (const unsigned char*)p.in0 + ((int64_t)m * p.C0 + ((c8 ^ rsw) << 3)) * 2;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (LIN ? 0 : ARA); ++i) {
         const int m = m0 + (t >> SHA) + RPBA * i;
         rv[i] = m < M;
         const int mm = rv[i] ? m : 0;
@@ -135,6 +148,18 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
 
     // ---- FAST: LDS-DMA fill of k tile kt (lies inside one tap and one source) into the given buffers
     auto dma_tile = [&](int kt, unsigned char* bufA, unsigned char* bufB) {
+        if constexpr (LIN) {
+            unsigned char* a = bufA + wave * 1024;
+#pragma unroll
+            for (int i = 0; i < ARA; ++i) glds16(linA[i] + kt * (BKT * 2), a + i * RPBA * RPA);
+            unsigned char* b = bufB + wave * 1024;
+            const unsigned short* wrow = wbase + (int64_t)(n0 + (t >> SH)) * p.Kpad + kt * BKT + ((c8 ^ rsw) << 3);
+#pragma unroll
+            for (int i = 0; i < BCH; ++i) {
+                if (BN % RPB == 0 || (t >> SH) + RPB * i < BN) glds16(wrow + (int64_t)(RPB * i) * p.Kpad, b + i * RPB * RP);
+            }
+            return;
+        }
         const int k0 = kt * BKT;
         const int tap = k0 / Cin;
         int cc = k0 - tap * Cin;
@@ -337,7 +362,7 @@ int launch_cfg(const vv_conv_params& p, int M, hipStream_t st) {
     if (split < 0) { const char* e = getenv("VV_GEMM_SPLIT"); split = e ? atoi(e) : 2; }
     // 128x128 tiles: 130 VGPRs uncapped; capping at 128 (4 spilled) lets a 4th block share the CU (LDS 4 x 32-40 KB)
     static const bool occ4 = getenv("VV_GEMM_NO_OCC4") == nullptr;
-    constexpr bool CAN4 = WR * MT * WC * NT == 64 && (MODE == MODE_FAST || MODE == MODE_HALO);
+    constexpr bool CAN4 = WR * WC == 4 && (MODE == MODE_LIN || (NT == 4 && (MODE == MODE_FAST || MODE == MODE_HALO)));
     if (CAN4 && occ4 && (MODE == MODE_HALO || split == 2)) { if constexpr (CAN4) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2, 64, 4>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN); }
     else if constexpr (MODE == MODE_FAST32 || MODE == MODE_HALO) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     else if (split == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 1, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
@@ -377,6 +402,9 @@ int launch_mode(const vv_conv_params& p, int M, hipStream_t st) {
         const int64_t cover = (int64_t)((p.Hin + 7) / 8) * 8 * ((p.Win + 15) / 16) * 16;
         if (cover * 100 <= (int64_t)p.Hin * p.Win * 115) return launch_t<T, MODE_HALO>(p, M, st);
     }
+    static const bool nolin = getenv("VV_GEMM_NO_LIN") != nullptr;
+    if (fast && !nolin && p.in_dtype != VV_F32 && p.ksize == 1 && p.ksize_w <= 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.C1 == 0 &&
+        p.Hv == p.Hin && p.Wv == p.Win && p.Hout == p.Hin && p.Wout == p.Win) return launch_t<T, MODE_LIN>(p, M, st);
     if (p.in_dtype == VV_F32) return (fast && !no32) ? launch_t<T, MODE_FAST32>(p, M, st) : launch_t<T, MODE_F32>(p, M, st);
     return fast ? launch_t<T, MODE_FAST>(p, M, st) : launch_t<T, MODE_H16>(p, M, st);
 }

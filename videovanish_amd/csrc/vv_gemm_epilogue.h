@@ -45,13 +45,12 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
         return;
     }
     if (vec) {
-        float4 b4[NT];
+        // (the bias is re-read per strip instead of being held in NT float4 registers: it keeps the kernels under 128 VGPRs)
         int colpart[NT];          // split_heads store: the column's (which, head, d) part of the output index (< 3*C*tokens)
         const bool split = p.split_heads > 0;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int n = ncol0 + j * 16 + 4 * lq;
-            b4[j] = (p.bias && n < N) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             colpart[j] = 0;
             if (split) {
                 const int wh = n / p.split_dim;                       // which * heads + head
@@ -80,8 +79,9 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
             for (int j = 0; j < NT; ++j) {
                 const int n = ncol0 + j * 16 + 4 * lq;
                 if (n >= N) continue;
-                float v[4] = {(acc[i][j][0] + b4[j].x) * p.out_scale, (acc[i][j][1] + b4[j].y) * p.out_scale,
-                              (acc[i][j][2] + b4[j].z) * p.out_scale, (acc[i][j][3] + b4[j].w) * p.out_scale};
+                const float4 bj = p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float v[4] = {(acc[i][j][0] + bj.x) * p.out_scale, (acc[i][j][1] + bj.y) * p.out_scale,
+                              (acc[i][j][2] + bj.z) * p.out_scale, (acc[i][j][3] + bj.w) * p.out_scale};
                 if (rowv) { const float4 t4 = *(const float4*)(rowv + n); v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w; }
                 if (p.res0) {
                     if (r0f32) { v[0] += ra4[j].x; v[1] += ra4[j].y; v[2] += ra4[j].z; v[3] += ra4[j].w; }
