@@ -379,7 +379,8 @@ int launch_t(const vv_conv_params& p, int M, hipStream_t st) {
     if (p.epilogue == VV_EPI_GEGLU) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, M, st);
     // N a multiple of both: the 128x128 tile runs 4 blocks per CU (128 VGPRs) against 3 for 128x160 -> +2..8 % on the LDS-DMA
     // loaders when there are enough row tiles (profiles/r1_gemm_ab.txt, eighth A/B)
-    static const bool pref128 = getenv("VV_GEMM_NO_PREF128") == nullptr && getenv("VV_GEMM_NO_OCC4") == nullptr;
+    // (opt-in: in the pipeline the 3x3 convs lose 2-3 % with it, and the linear layers now run 128x160 at 4 blocks through LIN)
+    static const bool pref128 = getenv("VV_GEMM_PREF128") != nullptr && getenv("VV_GEMM_NO_OCC4") == nullptr;
     if (pref128 && p.Npad % 128 == 0 && (MODE == MODE_FAST || MODE == MODE_HALO) && M >= 16384) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, M, st);
     if (p.Npad % 160 == 0) return launch_cfg<T, 2, 2, 4, 5, MODE>(p, M, st);   // (a 256x160 4-wave tile measured the same: profiles/r1_gemm_ab.txt)
     if (p.Npad % 128 == 0) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, M, st);

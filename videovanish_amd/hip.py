@@ -162,7 +162,8 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
         # mirror of launch_t() in vv_gemm.hip (label only): LDS-DMA loaders prefer the 128x128 tile (4 blocks per CU) when N allows
         dma = x0.dtype != torch.float32 and C0 % 64 == 0 and C1 % 64 == 0 and weight.shape[1] == K
         lin = dma and ksize == 1 and stride == 1 and C1 == 0 and Hv == Hin and Wv == Win and Hout == Hin and Wout == Win
-        tile = "128x128" if (epilogue == EPI_GEGLU or (Npad % 128 == 0 and dma and not lin and M >= 16384)) else (
+        pref128 = os.environ.get("VV_GEMM_PREF128") is not None
+        tile = "128x128" if (epilogue == EPI_GEGLU or (pref128 and Npad % 128 == 0 and dma and not lin and M >= 16384)) else (
             "128x160" if Npad % 160 == 0 else ("128x128" if Npad % 128 == 0 else "128x16"))
         if os.environ.get("VV_PROFILE_SHAPES"):
             tile = f"M{M},N{N},K{K}|" + tile
