@@ -81,7 +81,8 @@ typedef struct {
                              N = 3 * split_heads * split_dim, row m = (b, token) with split_tokens rows per b;
                              out[(((b*3 + which)*split_heads + head)*split_tokens + token)*split_dim + d]; ldo is ignored */
     int32_t split_dim;    /* head dim (multiple of 4) */
-    int32_t split_tokens; /* rows per batch element */
+    int32_t split_tokens; /* rows per batch element: row m = b*split_tokens + token; NEGATIVE: -split_tokens tokens per batch element
+                             with token-major rows, m = token*(M/tokens) + b (temporal attention: token = frame, b = pixel) */
 } vv_conv_params;
 int vv_conv_gemm(const vv_conv_params* host_p, int dtype, void* stream);
 

@@ -260,6 +260,10 @@ def test_conv_gemm_split_heads(gpu, dname, td, ulp):
     assert (plain.float().cpu() - ref).abs().max().item() <= 2 * ulp * ref.abs().max().item()
     with pytest.raises(RuntimeError):
         hip.conv_gemm(dt, x.to(td).to(gpu), wp, 3 * C, C, F=1, Hin=B * T, Win=1, split_heads=heads, split_dim=D, split_tokens=T, out_dtype=torch.float32)
+    # token-major rows (temporal attention: row = frame*HW + pixel, batch element = pixel): split_tokens < 0
+    tm = hip.conv_gemm(dt, x.to(td).to(gpu), wp, 3 * C, C, F=1, Hin=B * T, Win=1, split_heads=heads, split_dim=D, split_tokens=-B)
+    want_tm = plain.cpu().reshape(B, T, 3, heads, D).permute(1, 2, 3, 0, 4).contiguous()       # rows = (token=B index, b=T index)
+    assert torch.equal(tm.cpu().reshape(T, 3, heads, B, D), want_tm)
 
 
 @pytest.mark.parametrize("dname,td,ulp", DT)

@@ -428,9 +428,10 @@ extern "C" int vv_conv_gemm(const vv_conv_params* pp, int dtype, void* stream) {
     if (p.out_dtype != VV_F32 && p.out_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_conv_gemm: out_dtype mismatch");
     if ((p.res0 || p.res1) && p.res_dtype != VV_F32 && p.res_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_conv_gemm: res_dtype mismatch");
     if (p.epilogue == VV_EPI_GEGLU && (p.N % 32 || p.rowvec || p.res0 || p.res1 || (p.ldo & 3))) VV_FAIL(VV_E_ARG, "vv_conv_gemm: GEGLU needs N%%32==0, ldo%%4==0 and no residual/rowvec");
-    if (p.split_heads > 0 && (p.split_dim <= 0 || (p.split_dim & 3) || p.split_tokens <= 0 || p.N != 3 * p.split_heads * p.split_dim || p.out_dtype == VV_F32 ||
-                              p.res0 || p.res1 || p.epilogue == VV_EPI_GEGLU || ((int64_t)p.F * p.Hout * p.Wout) % p.split_tokens ||
-                              (int64_t)p.N * p.split_tokens > 0x7fffffff))
+    const int64_t stok_ = p.split_tokens < 0 ? -(int64_t)p.split_tokens : p.split_tokens;
+    if (p.split_heads > 0 && (p.split_dim <= 0 || (p.split_dim & 3) || stok_ <= 0 || p.N != 3 * p.split_heads * p.split_dim || p.out_dtype == VV_F32 ||
+                              p.res0 || p.res1 || p.epilogue == VV_EPI_GEGLU || ((int64_t)p.F * p.Hout * p.Wout) % stok_ ||
+                              (int64_t)p.N * stok_ > 0x7fffffff))
         VV_FAIL(VV_E_ARG, "vv_conv_gemm: split_heads needs N = 3*heads*dim, dim %% 4 == 0, h16 output, no residual / GEGLU, M %% split_tokens == 0");
     if (p.F <= 0 || p.Hout <= 0 || p.Wout <= 0 || p.Hin <= 0 || p.Win <= 0 || p.Hv <= 0 || p.Wv <= 0) VV_FAIL(VV_E_ARG, "vv_conv_gemm: bad geometry");
     const int64_t M64 = (int64_t)p.F * p.Hout * p.Wout;

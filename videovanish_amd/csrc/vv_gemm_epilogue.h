@@ -48,13 +48,15 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
         // (the bias is re-read per strip instead of being held in NT float4 registers: it keeps the kernels under 128 VGPRs)
         int colpart[NT];          // split_heads store: the column's (which, head, d) part of the output index (< 3*C*tokens)
         const bool split = p.split_heads > 0;
+        const int stok = p.split_tokens < 0 ? -p.split_tokens : p.split_tokens;      // tokens per batch element
+        const int snb = p.split_tokens < 0 ? (p.F * HWo) / stok : 0;                 // token-major rows: number of batch elements
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int n = ncol0 + j * 16 + 4 * lq;
             colpart[j] = 0;
             if (split) {
                 const int wh = n / p.split_dim;                       // which * heads + head
-                colpart[j] = wh * p.split_tokens * p.split_dim + (n - wh * p.split_dim);
+                colpart[j] = wh * stok * p.split_dim + (n - wh * p.split_dim);
             }
         }
 #pragma unroll
@@ -74,7 +76,11 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
             if (!mok) continue;
             const float* rowv = p.rowvec ? p.rowvec + (int64_t)(m / HWo) * N : nullptr;
             int64_t rowpart = 0;
-            if (split) { const int b = m / p.split_tokens; rowpart = ((int64_t)b * 3 * p.split_heads * p.split_tokens + (m - b * p.split_tokens)) * p.split_dim; }
+            if (split) {
+                int b, tok;
+                if (snb) { tok = m / snb; b = m - tok * snb; } else { b = m / stok; tok = m - b * stok; }
+                rowpart = ((int64_t)b * 3 * p.split_heads * stok + tok) * p.split_dim;
+            }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = ncol0 + j * 16 + 4 * lq;
