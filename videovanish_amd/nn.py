@@ -157,13 +157,13 @@ class SelfAttention:
 
     def temporal(self, n, res, Fr, HW, res1=None):
         """sequence = frames; rows of the [F*HW, 3C] QKV matrix gathered with stride HW*3C inside the kernel."""
-        C, dt, D = self.C, self.ctx.dt, self.C // self.heads
-        # head-major QKV per pixel ([pixel][q|k|v][head][frame][D], token-major rows -> split_tokens < 0): the F x D block of a
-        # (pixel, head) is one contiguous record instead of F rows HW*3C elements apart
-        qkv = self.qkv(n, out_dtype=self.ctx.h16, split=(self.heads, D, -Fr))
+        C, dt = self.C, self.ctx.dt
+        # (a per-pixel head-major QKV -- split_tokens < 0 -- makes this core 15 % faster but scatters the QKV GEMM's stores over
+        # records 3*C*F elements apart: +9 % on that GEMM, a net loss; measured in profiles/r1_gemm_ab.txt)
+        qkv = self.qkv(n, out_dtype=self.ctx.h16)
         o = torch.empty((Fr * HW, C), dtype=self.ctx.h16, device=n.device)
-        hip.attention(dt, qkv, qkv, qkv, o, B=HW, heads=self.heads, Nq=Fr, Nkv=Fr, D=D, q_bs=3 * Fr * C, k_bs=3 * Fr * C, v_bs=3 * Fr * C,
-                      o_bs=C, q_rs=D, k_rs=D, v_rs=D, o_rs=HW * C, k_off=Fr * C, v_off=2 * Fr * C, q_hs=Fr * D, k_hs=Fr * D, v_hs=Fr * D)
+        hip.attention(dt, qkv, qkv, qkv, o, B=HW, heads=self.heads, Nq=Fr, Nkv=Fr, D=C // self.heads, q_bs=3 * C, k_bs=3 * C, v_bs=3 * C,
+                      o_bs=C, q_rs=HW * 3 * C, k_rs=HW * 3 * C, v_rs=HW * 3 * C, o_rs=HW * C, k_off=C, v_off=2 * C)
         return self.out(o, res0=res, res1=res1)
 
 
