@@ -177,12 +177,12 @@ int vv_corr_lookup(const float* l0, const float* l1, const float* l2, const floa
 /* context encoder output cn [M][256] -> net = tanh(cn[:, :128]) (fp32 + h16), relu(cn[:, 128:]) -> xbuf[:, 0:128] (h16, ld 256) */
 int vv_raft_ctx_split(const float* cn, int64_t M, float* net, void* net16, void* xbuf, int dtype, void* stream);
 /* flow = coords1 - grid -> flow8 (h16 [M][8]) and xbuf[:, 254:256] */
-int vv_raft_flow_prep(const float* coords1, int64_t M, int w, void* flow8, void* xbuf, int dtype, void* stream);
+int vv_raft_flow_prep(const float* coords1, int64_t M, int w, int h, void* flow8, void* xbuf, int dtype, void* stream);   /* M rows = stacked h x w grids (batched pairs) */
 int vv_gru_rh(const float* zr, const float* h, int64_t M, void* rh, int dtype, void* stream);        /* rh = sigmoid(zr[:,128:]) * h */
 int vv_gru_update(const float* zr, const float* q, int64_t M, float* h, void* h16, int dtype, void* stream); /* h = (1-z)h + z tanh(q) */
 int vv_add_flow(float* coords1, const float* dflow, int ld, int64_t M, void* stream);              /* coords1 += dflow[:, 0:2] */
 int vv_add_relu_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
-int vv_convex_upsample(const float* coords1, const float* mask, int h, int w, float* out, void* stream);   /* -> flow [8h][8w][2] */
+int vv_convex_upsample(const float* coords1, const float* mask, int F, int h, int w, float* out, void* stream);   /* F stacked grids -> flow [F][8h][8w][2] */
 int vv_fb_valid(const float* f_ab, const float* f_ba, int H, int W, uint8_t* valid, void* stream);
 /* fill the unknown pixels of frame t (cur_t [H][W][3] fp32, in place) from neighbour nb warped by `flow` (t -> nb) */
 int vv_prop_fill(float* cur_t, const float* cur_nb, uint8_t* known_t, const uint8_t* known_nb, const uint8_t* valid,

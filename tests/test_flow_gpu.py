@@ -175,3 +175,18 @@ def test_prior_end_to_end(gpu):
     frac = float((np.abs(diff) > 2).mean())
     print(f"prior e2e: fraction of pixels differing by >2 levels from the oracle: {frac:.4f}")
     assert frac <= 0.02
+
+
+def test_raft_batched_pairs_match_single(gpu):
+    """the update block over a stack of pairs (one launch per kernel and iteration) gives bit for bit the per-pair flows."""
+    from videovanish_amd.nn import Ctx
+    from videovanish_amd.raft import RAFT
+    H, W = 64, 96
+    frames, _ = _clip(4, H, W, 61)
+    raft = RAFT(Ctx("cuda:0", "fp16", 0))
+    f, c, h, w = raft.features(torch.from_numpy(np.stack(frames)).to(gpu))
+    single = [raft.flow(f[t], f[t + 1], c[t], h, w, iters=3) for t in range(3)]
+    batched = raft.flow_batch(f[0:3], f[1:4], c[0:3], h, w, iters=3)
+    assert batched.shape == (3, H, W, 2)
+    for t in range(3):
+        assert torch.equal(batched[t], single[t])

@@ -79,9 +79,9 @@ __global__ void ctx_split_kernel(const float* cn, int64_t M, float* net, unsigne
 }
 // flow = coords1 - coords0 -> flow8 (h16 [M][8], 2 real channels) and xbuf[:, 254:256]
 template <typename T>
-__global__ void flow_prep_kernel(const float* coords1, int64_t M, int w, unsigned short* flow8, unsigned short* xbuf) {
+__global__ void flow_prep_kernel(const float* coords1, int64_t M, int w, int h, unsigned short* flow8, unsigned short* xbuf) {
     GRID_STRIDE(m, M) {
-        const float fx = coords1[m * 2] - (float)(m % w), fy = coords1[m * 2 + 1] - (float)(m / w);
+        const float fx = coords1[m * 2] - (float)(m % w), fy = coords1[m * 2 + 1] - (float)((m / w) % h);      // rows of stacked h x w grids
         const unsigned pk = pack2<T>(fx, fy);
         *(uint4*)(flow8 + m * 8) = make_uint4(pk, 0, 0, 0);
         *(unsigned*)(xbuf + m * 256 + 254) = pk;
@@ -114,11 +114,12 @@ __global__ void add_relu_kernel(const float* a, const float* b, float* out, int6
     GRID_STRIDE(i, n) out[i] = fmaxf(a[i] + b[i], 0.f);
 }
 // convex 8x upsampling: coords1 [h][w][2] (absolute), mask [h][w][576] (already x0.25) -> flow [8h][8w][2]
-__global__ void convex_upsample_kernel(const float* coords1, const float* mask, int h, int w, float* out) {
-    const int64_t n = (int64_t)h * w * 64;
+__global__ void convex_upsample_kernel(const float* coords1, const float* mask, int F, int h, int w, float* out) {
+    const int64_t n = (int64_t)F * h * w * 64;
     GRID_STRIDE(i, n) {
         const int sub = (int)(i & 63); const int64_t p = i >> 6;
-        const int x = (int)(p % w), y = (int)(p / w), sy = sub >> 3, sx = sub & 7;
+        const int64_t f = p / ((int64_t)h * w), g0 = f * h * w;          // grid f of the stack
+        const int x = (int)(p % w), y = (int)((p / w) % h), sy = sub >> 3, sx = sub & 7;
         const float* mk = mask + p * 576 + sub;           // mask[k*64 + sy*8 + sx], k = 0..8
         float mx = mk[0];
         for (int k = 1; k < 9; ++k) mx = fmaxf(mx, mk[k * 64]);
@@ -129,13 +130,13 @@ __global__ void convex_upsample_kernel(const float* coords1, const float* mask, 
             const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
             float vx = 0.f, vy = 0.f;
             if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
-                const int64_t q = (int64_t)yy * w + xx;
+                const int64_t q = g0 + (int64_t)yy * w + xx;
                 vx = 8.0f * (coords1[q * 2] - (float)xx); vy = 8.0f * (coords1[q * 2 + 1] - (float)yy);
             }
             const float wk = e[k] / den;
             fx += wk * vx; fy += wk * vy;
         }
-        const int64_t o = ((int64_t)(y * 8 + sy) * (w * 8) + (x * 8 + sx)) * 2;
+        const int64_t o = ((f * h * 8 + (int64_t)(y * 8 + sy)) * (w * 8) + (x * 8 + sx)) * 2;
         out[o] = fx; out[o + 1] = fy;
     }
 }
@@ -268,9 +269,9 @@ extern "C" int vv_raft_ctx_split(const float* cn, int64_t M, float* net, void* n
     DT_DISPATCH("vv_raft_ctx_split", ctx_split_kernel, grid_for(M * 128), cn, M, net, (unsigned short*)net16, (unsigned short*)xbuf)
 }
 
-extern "C" int vv_raft_flow_prep(const float* coords1, int64_t M, int w, void* flow8, void* xbuf, int dtype, void* stream) {
-    if (!coords1 || !flow8 || !xbuf || M <= 0 || w <= 0) VV_FAIL(VV_E_ARG, "vv_raft_flow_prep: bad args");
-    DT_DISPATCH("vv_raft_flow_prep", flow_prep_kernel, grid_for(M), coords1, M, w, (unsigned short*)flow8, (unsigned short*)xbuf)
+extern "C" int vv_raft_flow_prep(const float* coords1, int64_t M, int w, int h, void* flow8, void* xbuf, int dtype, void* stream) {
+    if (!coords1 || !flow8 || !xbuf || M <= 0 || w <= 0 || h <= 0 || M % ((int64_t)h * w)) VV_FAIL(VV_E_ARG, "vv_raft_flow_prep: bad args (M must be whole h x w grids)");
+    DT_DISPATCH("vv_raft_flow_prep", flow_prep_kernel, grid_for(M), coords1, M, w, h, (unsigned short*)flow8, (unsigned short*)xbuf)
 }
 
 extern "C" int vv_gru_rh(const float* zr, const float* h, int64_t M, void* rh, int dtype, void* stream) {
@@ -297,9 +298,9 @@ extern "C" int vv_add_relu_f32(const float* a, const float* b, float* out, int64
     return VV_OK;
 }
 
-extern "C" int vv_convex_upsample(const float* coords1, const float* mask, int h, int w, float* out, void* stream) {
-    if (!coords1 || !mask || !out || h <= 0 || w <= 0) VV_FAIL(VV_E_ARG, "vv_convex_upsample: bad args");
-    hipLaunchKernelGGL(convex_upsample_kernel, grid_for((int64_t)h * w * 64), dim3(EB), 0, (hipStream_t)stream, coords1, mask, h, w, out);
+extern "C" int vv_convex_upsample(const float* coords1, const float* mask, int F, int h, int w, float* out, void* stream) {
+    if (!coords1 || !mask || !out || F <= 0 || h <= 0 || w <= 0) VV_FAIL(VV_E_ARG, "vv_convex_upsample: bad args");
+    hipLaunchKernelGGL(convex_upsample_kernel, grid_for((int64_t)F * h * w * 64), dim3(EB), 0, (hipStream_t)stream, coords1, mask, F, h, w, out);
     VV_CHECK_LAUNCH("vv_convex_upsample");
     return VV_OK;
 }

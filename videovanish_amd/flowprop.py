@@ -20,12 +20,20 @@ def _model(device, dtype, weight_seed):
     return _cache[key]
 
 
+PAIRS = 8      # pairs per stacked group
+
+
 def flows_for_clip(raft, frames_u8, iters=ITERS):
     """frames u8 [T,H,W,3] (device, H,W % 8 == 0) -> (fw, bw): lists of fp32 [H,W,2]; fw[t] = flow t->t+1, bw[t] = flow t+1->t."""
     T = frames_u8.shape[0]
     f, c, h, w = raft.features(frames_u8)
-    fw = [raft.flow(f[t], f[t + 1], c[t], h, w, iters) for t in range(T - 1)]
-    bw = [raft.flow(f[t + 1], f[t], c[t + 1], h, w, iters) for t in range(T - 1)]
+    # forward pairs (t -> t+1) and backward pairs (t+1 -> t) go through the update block in stacked groups: one launch per
+    # kernel and iteration for the whole group (the all-pairs pyramid is 1.1 GB of fp32 per pair at 720p -> groups of <= PAIRS)
+    fw, bw = [], []
+    for t0 in range(0, T - 1, PAIRS):
+        t1 = min(t0 + PAIRS, T - 1)
+        fw.extend(raft.flow_batch(f[t0:t1], f[t0 + 1:t1 + 1], c[t0:t1], h, w, iters))
+        bw.extend(raft.flow_batch(f[t0 + 1:t1 + 1], f[t0:t1], c[t0 + 1:t1 + 1], h, w, iters))
     return fw, bw
 
 

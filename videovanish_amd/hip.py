@@ -356,9 +356,9 @@ def raft_ctx_split(dtype, cn, net, net16, xbuf):
     _check(lib().vv_raft_ctx_split(_p(cn), C.c_int64(cn.shape[0]), _p(net), _p(net16), _p(xbuf), dtype, _stream()), "vv_raft_ctx_split")
 
 
-def raft_flow_prep(dtype, coords1, w, flow8, xbuf):
+def raft_flow_prep(dtype, coords1, w, h, flow8, xbuf):
     _need_cuda(coords1, flow8, xbuf)
-    _check(lib().vv_raft_flow_prep(_p(coords1), C.c_int64(coords1.shape[0]), w, _p(flow8), _p(xbuf), dtype, _stream()), "vv_raft_flow_prep")
+    _check(lib().vv_raft_flow_prep(_p(coords1), C.c_int64(coords1.shape[0]), w, h, _p(flow8), _p(xbuf), dtype, _stream()), "vv_raft_flow_prep")
 
 
 def gru_rh(dtype, zr, h, rh):
@@ -383,11 +383,12 @@ def add_relu(a, b):
     return out
 
 
-def convex_upsample(coords1, mask, h, w):
+def convex_upsample(coords1, mask, h, w, F=1):
+    """coords1 [F*h*w, 2], mask [F*h*w, 576] -> flow [8h, 8w, 2] (F = 1) or [F, 8h, 8w, 2]."""
     _need_cuda(coords1, mask)
-    out = torch.empty((8 * h, 8 * w, 2), dtype=torch.float32, device=coords1.device)
-    _check(lib().vv_convex_upsample(_p(coords1), _p(mask), h, w, _p(out), _stream()), "vv_convex_upsample")
-    return out
+    out = torch.empty((F, 8 * h, 8 * w, 2), dtype=torch.float32, device=coords1.device)
+    _check(lib().vv_convex_upsample(_p(coords1), _p(mask), F, h, w, _p(out), _stream()), "vv_convex_upsample")
+    return out[0] if F == 1 else out
 
 
 def fb_valid(f_ab, f_ba):

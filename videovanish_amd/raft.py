@@ -132,12 +132,16 @@ class RAFT:
         return f.view(T, h * w, 256), c.view(T, h * w, 256), h, w
 
     def corr_pyramid(self, f1_16, f2_16, h, w):
+        """all-pairs correlation pyramid of P stacked pairs: f1_16 / f2_16 h16 [P*N, 256] -> 4 fp32 tensors [P*N, h_l, w_l]."""
         N = h * w
+        P = f1_16.shape[0] // N
         npad = packing.npad_for(N)
+        corr = torch.empty((P * N, N), dtype=torch.float32, device=f1_16.device)
         f2p = torch.zeros((npad, 256), dtype=self.ctx.h16, device=f1_16.device)
-        f2p[:N] = f2_16
-        corr = hip.conv_gemm(self.ctx.dt, f1_16, f2p, N, 256, F=1, Hin=N, Win=1, out_dtype=torch.float32, out_scale=1.0 / 16.0)
-        pyr = [corr.view(N, h, w)]
+        for i in range(P):         # one 14400 x 14400 x 256 GEMM per pair (829 MB of fp32 at 720p), written into its slice
+            f2p[:N] = f2_16[i * N: (i + 1) * N]
+            hip.conv_gemm(self.ctx.dt, f1_16[i * N: (i + 1) * N], f2p, N, 256, F=1, Hin=N, Win=1, out=corr[i * N: (i + 1) * N], out_scale=1.0 / 16.0)
+        pyr = [corr.view(P * N, h, w)]
         for _ in range(3):
             pyr.append(hip.avgpool2(pyr[-1]))
         return pyr
@@ -145,8 +149,16 @@ class RAFT:
     def flow(self, f1, f2, cn1, h, w, iters=ITERS, trace=None):
         """f1,f2: fp32 [h*w,256] feature maps of the two frames; cn1: fp32 [h*w,256] context of frame 1.
         Returns flow 1->2, fp32 [8h, 8w, 2]."""
+        return self.flow_batch(f1, f2, cn1, h, w, iters, trace)[0]
+
+    def flow_batch(self, f1, f2, cn1, h, w, iters=ITERS, trace=None):
+        """P stacked pairs: f1, f2, cn1 fp32 [P*h*w, 256] (or [P, h*w, 256]).  Every kernel of the update block runs ONCE per
+        iteration over all pairs (rows = stacked h x w grids, conv F = P).  Returns flows fp32 [P, 8h, 8w, 2]."""
         ctx, dt, dev = self.ctx, self.ctx.dt, f1.device
-        M = h * w
+        N = h * w
+        f1, f2, cn1 = f1.reshape(-1, 256), f2.reshape(-1, 256), cn1.reshape(-1, 256)
+        M = f1.shape[0]
+        P = M // N
         f1_16, f2_16 = hip.pad_channels(dt, f1, 256), hip.pad_channels(dt, f2, 256)      # fp32 -> h16 MFMA operands
         pyr = self.corr_pyramid(f1_16, f2_16, h, w)
         net = torch.empty((M, 128), dtype=torch.float32, device=dev)
@@ -154,7 +166,7 @@ class RAFT:
         xbuf = torch.zeros((M, 256), dtype=ctx.h16, device=dev)            # [inp(128) | motion(126) | flow(2)]
         hip.raft_ctx_split(dt, cn1, net, net16, xbuf)
         ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
-        coords1 = torch.stack([xs, ys], -1).reshape(M, 2).contiguous().to(dev)
+        coords1 = torch.stack([xs, ys], -1).reshape(N, 2).repeat(P, 1).contiguous().to(dev)
         flow8 = torch.empty((M, 8), dtype=ctx.h16, device=dev)
         corflo = torch.empty((M, 256), dtype=ctx.h16, device=dev)           # [cor(192) | flo(64)]
         rh = torch.empty((M, 128), dtype=ctx.h16, device=dev)
@@ -163,25 +175,26 @@ class RAFT:
             trace.update(net0=net.clone(), corr0=pyr[0].clone(), corr3=pyr[3].clone())
         for it in range(iters):
             look = hip.corr_lookup(dt, pyr, coords1)
-            hip.raft_flow_prep(dt, coords1, w, flow8, xbuf)
-            c1, _, _ = self.convc1(look, 1, h, w, relu=True, out_dtype=ctx.h16)
-            self.convc2(c1, 1, h, w, relu=True, out=corflo, out_col=0)
-            fl1, _, _ = self.convf1(flow8, 1, h, w, relu=True, out_dtype=ctx.h16)
-            self.convf2(fl1, 1, h, w, relu=True, out=corflo, out_col=192)
-            self.conv(corflo, 1, h, w, relu=True, out=xbuf, out_col=128)
+            hip.raft_flow_prep(dt, coords1, w, h, flow8, xbuf)
+            c1, _, _ = self.convc1(look, P, h, w, relu=True, out_dtype=ctx.h16)
+            self.convc2(c1, P, h, w, relu=True, out=corflo, out_col=0)
+            fl1, _, _ = self.convf1(flow8, P, h, w, relu=True, out_dtype=ctx.h16)
+            self.convf2(fl1, P, h, w, relu=True, out=corflo, out_col=192)
+            self.conv(corflo, P, h, w, relu=True, out=xbuf, out_col=128)
             for (zr_c, q_c) in self.gru:
-                zr, _, _ = zr_c(net16, 1, h, w, x1=xbuf)
+                zr, _, _ = zr_c(net16, P, h, w, x1=xbuf)
                 hip.gru_rh(dt, zr, net, rh)
-                q, _, _ = q_c(rh, 1, h, w, x1=xbuf)
+                q, _, _ = q_c(rh, P, h, w, x1=xbuf)
                 hip.gru_update(dt, zr, q, net, net16)
-            d1, _, _ = self.fh1(net16, 1, h, w, relu=True, out_dtype=ctx.h16)
-            dflow, _, _ = self.fh2(d1, 1, h, w)
+            d1, _, _ = self.fh1(net16, P, h, w, relu=True, out_dtype=ctx.h16)
+            dflow, _, _ = self.fh2(d1, P, h, w)
             if trace is not None and it == 0:
                 trace.update(lookup0=look.clone(), dflow0=dflow.clone(), net1=net.clone())
             hip.add_flow(coords1, dflow)
             if it == iters - 1:
-                m1, _, _ = self.mk1(net16, 1, h, w, relu=True, out_dtype=ctx.h16)
-                mask, _, _ = self.mk2(m1, 1, h, w, scale=0.25)
+                m1, _, _ = self.mk1(net16, P, h, w, relu=True, out_dtype=ctx.h16)
+                mask, _, _ = self.mk2(m1, P, h, w, scale=0.25)
         if trace is not None:
             trace.update(coords1=coords1.clone())
-        return hip.convex_upsample(coords1, mask, h, w)
+        out = hip.convex_upsample(coords1, mask, h, w, F=P)
+        return out if P > 1 else out[None]
