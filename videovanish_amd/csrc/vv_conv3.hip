@@ -36,7 +36,10 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     else static_assert(N == 0, "unsupported count");
 }
 
-template <typename T, int NT>
+// PIPE: the MFMA operands are double buffered in registers at k-step granularity -- the ds_reads of step n+1 are issued before the
+// MFMAs of step n, and the second half of tile k-1 runs AFTER the barrier of tile k (its operands were read before it), so the LDS
+// burst that follows every barrier (all 8 waves read at once) overlaps matrix work instead of stalling the pipe.
+template <typename T, int NT, bool PIPE>
 __global__ __launch_bounds__(512, 1) void conv3_halo_kernel(const vv_conv_params p, const int tilesM, const int tilesN) {
     constexpr int MT = 4, BN = 2 * NT * 16;
     constexpr int BSLOTS = BN * 8;                       // 16-byte slots per weight tile (1280 for BN = 160, 1024 for 128)
@@ -155,6 +158,29 @@ __global__ __launch_bounds__(512, 1) void conv3_halo_kernel(const vv_conv_params
     dma_b(kofs_of(0), sB0);
     if (nkt > 1) dma_b(kofs_of(1), sB1);
     // ---- one channel chunk = nine k tiles; PAR = chunk parity selects the halo buffer; weight ring index = tap % 3
+    struct Frag { uint4 a[MT]; uint4 b[NT]; };
+    auto read_step = [&](Frag& r, const unsigned char* hA, const unsigned char* sB, int tapofs, const int s) {
+        asm volatile("" : "+v"(tapofs));
+        const unsigned char* b = sB + (wc * NT * 16) * 128;
+        const int ch = s * 4 + lq;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int hp = (wr * MT + i) * 18 + lr + tapofs;
+            r.a[i] = *(const uint4*)(hA + hp * 128 + ((ch ^ (hp & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int row = j * 16 + lr;
+            r.b[j] = *(const uint4*)(b + row * 128 + ((ch ^ (row & 7)) << 4));
+        }
+    };
+    auto mma_step = [&](const Frag& r) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = T::mfma(r.b[j], r.a[i], acc[i][j]);
+    };
+    Frag f0, f1;
     auto chunk = [&](const int c, auto par_tag) {
         constexpr int PAR = decltype(par_tag)::value;
         unsigned char* hcur = PAR ? hA1 : hA0;
@@ -169,9 +195,18 @@ __global__ __launch_bounds__(512, 1) void conv3_halo_kernel(const vv_conv_params
             // have landed; leaving the BPASS newest in flight never under-waits (a halo slice among them only makes the wait
             // cover one DMA of B(kk+1) as well).  A wave whose halo lanes are all out of the image skips that slice entirely.
             if (kk + 1 < nkt) wait_vm<BPASS>(); else wait_vm<0>();
+            if (PIPE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my operand reads of tile kk-1 are done before its buffer is refilled
             __builtin_amdgcn_s_barrier();       // (not __syncthreads(): its fence would drain vmcnt(0))
             if (kk + 2 < nkt) dma_b(kofs_of(kk + 2), bnext2);
-            mma(hcur, bcur, (tap / 3) * 18 + tap % 3);
+            const int tapofs = (tap / 3) * 18 + tap % 3;
+            if constexpr (PIPE) {
+                read_step(f0, hcur, bcur, tapofs, 0);
+                if (kk > 0) mma_step(f1);                 // second k step of tile kk-1 (operands read before the barrier)
+                read_step(f1, hcur, bcur, tapofs, 1);
+                mma_step(f0);
+            } else {
+                mma(hcur, bcur, tapofs);
+            }
             if (tap < HPASS && more_chunks) dma_halo_pass(c + 1, tap, hnext);
         }
     };
@@ -179,6 +214,7 @@ __global__ __launch_bounds__(512, 1) void conv3_halo_kernel(const vv_conv_params
         chunk(c, std::integral_constant<int, 0>{});
         if (c + 1 < nchunks) chunk(c + 1, std::integral_constant<int, 1>{});
     }
+    if constexpr (PIPE) mma_step(f1);                    // second k step of the last tile
     const int HWo = p.Hin * p.Win;
     gemm_epilogue<T, MT, NT>(p, acc, wr * MT * 16, n0 + wc * NT * 16, lr, lq, HWo, row_m);
 }
@@ -186,7 +222,9 @@ __global__ __launch_bounds__(512, 1) void conv3_halo_kernel(const vv_conv_params
 template <typename T, int NT>
 int launch(const vv_conv_params& p, hipStream_t st) {
     const int tilesM = p.F * ((p.Hin + 15) / 16) * ((p.Win + 15) / 16), tilesN = p.Npad / (2 * NT * 16);
-    hipLaunchKernelGGL((conv3_halo_kernel<T, NT>), dim3(tilesM * tilesN), dim3(512), 0, st, p, tilesM, tilesN);
+    const char* e = getenv("VV_CONV3_PIPE");
+    if (e && e[0] == '0') hipLaunchKernelGGL((conv3_halo_kernel<T, NT, false>), dim3(tilesM * tilesN), dim3(512), 0, st, p, tilesM, tilesN);
+    else hipLaunchKernelGGL((conv3_halo_kernel<T, NT, true>), dim3(tilesM * tilesN), dim3(512), 0, st, p, tilesM, tilesN);
     VV_CHECK_LAUNCH("vv_conv3_halo");
     return VV_OK;
 }
