@@ -62,3 +62,29 @@ def test_product_path_has_no_cpu_fallback():
                 assert "import oracle" not in txt and "from oracle" not in txt, f
     txt = open(os.path.join(ROOT, "diffuerase.py")).read() if os.path.isfile(os.path.join(ROOT, "diffuerase.py")) else ""
     assert "oracle" not in txt
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof / offsetof of the three parameter structs as gcc compiles include/vvhip.h == the ctypes mirrors in hip.py."""
+    import subprocess
+    from videovanish_amd import hip
+    probes = {"vv_conv_params": (hip.ConvParams, ["weight", "bias", "out", "ldo", "act", "split_heads", "split_tokens"]),
+              "vv_attn_params": (hip.AttnParams, ["o", "q_rs", "D", "scale", "q_hs", "v_hs"]),
+              "vv_groupnorm_params": (hip.GroupNormParams, ["groups", "eps", "gamma", "stats_ws", "out_dtype"])}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "vvhip.h"', "int main(void) {"]
+    for name, (_, fields) in probes.items():
+        src.append(f'  printf("{name} %zu", sizeof({name}));')
+        for f in fields:
+            src.append(f'  printf(" %zu", offsetof({name}, {f}));')
+        src.append('  printf("\\n");')
+    src += ["  return 0;", "}"]
+    c = tmp_path / "probe.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    for line in out:
+        parts = line.split()
+        cls, fields = probes[parts[0]]
+        want = [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f in fields]
+        assert [int(x) for x in parts[1:]] == want, (parts[0], parts[1:], want)
