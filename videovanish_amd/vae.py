@@ -70,8 +70,11 @@ class VAE:
         """img8: h16 [F*H*W, 8] (3 real channels, [-1,1]) -> scaled latent means fp32 [F, H/f, W/f, 4]."""
         x, _, _ = self.e_in(img8, F, H, W)
         for i, rs in enumerate(self.e_blocks):
-            for r in rs:
-                x = r(x, F, H, W)
+            last = i < len(self.e_blocks) - 1
+            for j, r in enumerate(rs):
+                # the block's last ResBlock feeds only the strided conv: hand over h16 (the conv rounds its input to h16 anyway,
+                # so the values are identical) and the conv runs on the h16 LDS-DMA loader instead of the fp32 one
+                x = r(x, F, H, W, out_dtype=self.ctx.h16 if (last and j == len(rs) - 1) else torch.float32)
             if i < len(self.e_blocks) - 1:
                 # F.pad(x,(0,1,0,1)) + stride-2 conv, pad 0: bottom/right zeros come from the bounds check
                 x, H, W = self.e_down[i](x, F, H, W, stride=2, pad=0, Hout=H // 2, Wout=W // 2)
@@ -91,8 +94,9 @@ class VAE:
         H, W = h, w
         x = self.d_mid(x, F, H, W)
         for i, rs in enumerate(self.d_blocks):
-            for r in rs:
-                x = r(x, F, H, W)
+            last = i < len(self.d_blocks) - 1
+            for j, r in enumerate(rs):
+                x = r(x, F, H, W, out_dtype=self.ctx.h16 if (last and j == len(rs) - 1) else torch.float32)   # feeds only the upsample conv
             if i < len(self.d_blocks) - 1:
                 x, H, W = self.d_up[i](x, F, H, W, Hv=2 * H, Wv=2 * W)      # nearest x2 fused into the conv gather
         hh = self.d_norm(x, F, H * W, silu=True)
