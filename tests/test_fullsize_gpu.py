@@ -172,3 +172,25 @@ def test_image_kernels_full_size_bit_exact(gpu):
     assert np.array_equal(small[1], IC.resize_bilinear_u8(inp[1], 960, 540))
     back = hip.resize_u8(torch.from_numpy(small).to(gpu), Hh, Ww).cpu().numpy()
     assert np.array_equal(back[2], IC.resize_bilinear_u8(small[2], Ww, Hh))
+
+
+def test_bench_contract_line(gpu):
+    """bench.py prints ONE JSON line with the driver's contract fields + roofline (live HIP events) + cpu_baseline (tiny arch, 2 steps)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--arch", "tiny", "--height", "128", "--width", "192", "--denoise-steps", "2",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - 24 * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3      # 24 credited frames per chunk
+    assert "workload" in d["config"] and "model" not in d["config"]
+    ro = d["roofline"]
+    assert ro["bound"] in ("hbm", "mfma") and ro["peak"] > 0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and ro["launches"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
