@@ -24,7 +24,7 @@ extern "C" int vv_conv3_halo_try(const vv_conv_params* pp, int dtype, void* stre
 namespace {
 
 constexpr int BK = 64;
-enum { MODE_H16 = 0, MODE_F32 = 1, MODE_FAST = 2, MODE_FAST32 = 3, MODE_HALO = 4, MODE_LIN = 5 };
+enum { MODE_H16 = 0, MODE_F32 = 1, MODE_FAST = 2, MODE_FAST32 = 3, MODE_HALO = 4, MODE_LIN = 5, MODE_FAST9 = 6 };
 constexpr int HALO_PX = 184;   // (8+2) x (16+2) = 180 halo pixels of an 8x16 output patch, padded to whole 1 KB DMA blocks
 
 __device__ __attribute__((aligned(64))) const unsigned int g_zero_page[16] = {0};
@@ -50,7 +50,10 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
     // LIN (plain linear layer / 1x1 stride-1 conv, one h16 source): rows of A are consecutive, no gather state at all -> the kernel
     // fits 128 VGPRs and a 4th block shares the CU
     constexpr bool AF32 = MODE == MODE_F32, A32 = MODE == MODE_FAST32, HALO = MODE == MODE_HALO, LIN = MODE == MODE_LIN;
-    constexpr bool FAST = MODE == MODE_FAST || A32 || HALO || LIN;
+    // FAST9 (h16 im2col, at most 9 taps, no fused resize): per row only the pixel index of tap (0,0) and a 9-bit tap-validity mask are
+    // kept (two rows per VGPR) instead of coordinates + frame + flags -> the 128x160 kernel fits 128 VGPRs = 4 blocks per CU
+    constexpr bool F9 = MODE == MODE_FAST9;
+    constexpr bool FAST = MODE == MODE_FAST || A32 || HALO || LIN || F9;
     static_assert(!HALO || (WR * MT == 8 && SPLIT == 2 && BKT == 64), "HALO: 128-row tile, single buffer");
     constexpr int HP = HALO ? (HALO_PX * 8 + 255) / 256 : 1;    // halo DMA passes
     // FAST32: the fp32 A tile is DMA'd as fp32 (256-byte rows, 16 chunks) and rounded to h16 when the operand is read
@@ -115,8 +118,30 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
             linA[i] = (const unsigned char*)p.in0 + ((int64_t)m * p.C0 + ((c8 ^ rsw) << 3)) * 2;
         }
     }
+    unsigned okm[F9 ? (ARA + 1) / 2 : 1];       // FAST9: bit (i & 1) * 16 + tap of okm[i >> 1] = tap of row i is inside the image
+    int pix9[F9 ? ARA : 1];
+    if constexpr (F9) {
 #pragma unroll
-    for (int i = 0; i < (LIN ? 0 : ARA); ++i) {
+        for (int i = 0; i < (ARA + 1) / 2; ++i) okm[i] = 0u;
+#pragma unroll
+        for (int i = 0; i < ARA; ++i) {
+            const int m = m0 + (t >> SHA) + RPBA * i;
+            const bool v = m < M;
+            const int mm = v ? m : 0;
+            const int f = mm / HWo, rem = mm - f * HWo;
+            const int y = rem / p.Wout, x = rem - y * p.Wout;
+            const int yb = y * p.stride - p.pad_t, xb = x * p.stride - p.pad_l;
+            pix9[i] = (f * p.Hin + yb) * p.Win + xb;
+            unsigned bits = 0u;
+            for (int tap = 0; tap < p.ksize * KW; ++tap) {
+                const int yv = yb + tap / KW, xv = xb + tap % KW;
+                if (v && yv >= 0 && yv < p.Hin && xv >= 0 && xv < p.Win) bits |= 1u << tap;
+            }
+            okm[i >> 1] |= bits << ((i & 1) * 16);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < ((LIN || F9) ? 0 : ARA); ++i) {
         const int m = m0 + (t >> SHA) + RPBA * i;
         rv[i] = m < M;
         const int mm = rv[i] ? m : 0;
@@ -174,6 +199,14 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
         const int csrc = A32 ? cc + c32 * 8 + (((t & 1) ^ (c32 & 1)) << 2) : cc + ((c8 ^ rsw) << 3);
         constexpr int ES = A32 ? 4 : 2;
         unsigned char* a = bufA + wave * 1024;
+        if constexpr (F9) {
+#pragma unroll
+            for (int i = 0; i < ARA; ++i) {
+                const bool ok = (okm[i >> 1] >> ((i & 1) * 16 + tap)) & 1u;
+                const void* g = ok ? (const void*)(src + ((int64_t)(pix9[i] + dpix) * Cs + csrc) * 2) : (const void*)g_zero_page;
+                glds16(g, a + i * RPBA * RPA);
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < ARA; ++i) {
             const int yv = ryb[i] + ky, xv = rxb[i] + kx;
@@ -182,6 +215,7 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
             if (resize) pix = (rfr[i] * p.Hin + (yv * p.Hin) / p.Hv) * p.Win + (xv * p.Win) / p.Wv;   // fused nearest upsample
             const void* g = ok ? (const void*)(src + ((int64_t)pix * Cs + csrc) * ES) : (const void*)g_zero_page;
             glds16(g, a + i * RPBA * RPA);
+        }
         }
         unsigned char* b = bufB + wave * 1024;
         const unsigned short* wrow = wbase + (int64_t)(n0 + (t >> SH)) * p.Kpad + k0 + ((c8 ^ rsw) << 3);
@@ -362,7 +396,7 @@ int launch_cfg(const vv_conv_params& p, int M, hipStream_t st) {
     if (split < 0) { const char* e = getenv("VV_GEMM_SPLIT"); split = e ? atoi(e) : 2; }
     // 128x128 tiles: 130 VGPRs uncapped; capping at 128 (4 spilled) lets a 4th block share the CU (LDS 4 x 32-40 KB)
     static const bool occ4 = getenv("VV_GEMM_NO_OCC4") == nullptr;
-    constexpr bool CAN4 = WR * WC == 4 && (MODE == MODE_LIN || (NT == 4 && (MODE == MODE_FAST || MODE == MODE_HALO)));
+    constexpr bool CAN4 = WR * WC == 4 && (MODE == MODE_LIN || MODE == MODE_FAST9 || (NT == 4 && (MODE == MODE_FAST || MODE == MODE_HALO)));
     if (CAN4 && occ4 && (MODE == MODE_HALO || split == 2)) { if constexpr (CAN4) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2, 64, 4>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN); }
     else if constexpr (MODE == MODE_FAST32 || MODE == MODE_HALO) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     else if (split == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 1, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
@@ -407,6 +441,8 @@ int launch_mode(const vv_conv_params& p, int M, hipStream_t st) {
     if (fast && !nolin && p.in_dtype != VV_F32 && p.ksize == 1 && p.ksize_w <= 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.C1 == 0 &&
         p.Hv == p.Hin && p.Wv == p.Win && p.Hout == p.Hin && p.Wout == p.Win) return launch_t<T, MODE_LIN>(p, M, st);
     if (p.in_dtype == VV_F32) return (fast && !no32) ? launch_t<T, MODE_FAST32>(p, M, st) : launch_t<T, MODE_F32>(p, M, st);
+    static const bool no9 = getenv("VV_GEMM_NO_FAST9") != nullptr;
+    if (fast && !no9 && p.Hv == p.Hin && p.Wv == p.Win && p.ksize * (p.ksize_w > 0 ? p.ksize_w : p.ksize) <= 9) return launch_t<T, MODE_FAST9>(p, M, st);
     return fast ? launch_t<T, MODE_FAST>(p, M, st) : launch_t<T, MODE_H16>(p, M, st);
 }
 
