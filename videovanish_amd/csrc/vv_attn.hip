@@ -362,6 +362,7 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
             if (var == 9) return attn_launch<T, D, 2, 64, 4, false, 3, true>(p, st);   // DMA, capped at 168 VGPRs (3 waves/SIMD)
             if (var == 10) return attn_launch<T, D, 2, 64, 4, false, 1, true>(p, st);   // DMA, uncapped registers (2 waves/SIMD)
             if (var == 13) return attn_launch<T, D, 2, 32, 4, false, 4, true>(p, st);   // DMA, 32-key tiles, capped at 128 VGPRs (4 waves/SIMD)
+            if (var == 14) return attn_launch<T, D, 2, 64, 4, true, 3>(p, st);          // register staged, capped at 168 VGPRs (3 waves/SIMD)
             // default for d <= 64: K/V by LDS-DMA, double buffered, 3 waves/SIMD (d = 80 would spill: stays register staged)
             if (D <= 64) return attn_launch<T, D, 2, 64, 4, false, 3, true>(p, st);
         }
