@@ -333,8 +333,10 @@ def ddim_step(x, eps, t, steps, ac):
 
 
 def tcd_timesteps(steps):
-    """trailing spacing: 2 steps -> [999, 499]."""
-    return [int(round(1000 - i * 1000 / steps)) - 1 for i in range(steps)]
+    """diffusers TCDScheduler.set_timesteps restated (original_inference_steps = 50, strength 1): the 50 origin timesteps
+    20*k - 1, reversed, picked at floor(linspace(0, 50, steps, endpoint=False)): 2 -> [999, 499], 4 -> [999, 759, 499, 259]."""
+    origin = [20 * k - 1 for k in range(1, 51)][::-1]
+    return [origin[int(math.floor(i * 50.0 / steps))] for i in range(steps)]
 
 
 def tcd_step(x, eps, t, t_prev, ac, z, gamma=0.3):

@@ -84,6 +84,8 @@ def denoise_chunk(P, img, m, prior, noise, steps, ucfg, vcfg, scheduler="ddim", 
         else:
             lat = M.tcd_step(lat, eps, t, ts[i + 1] if i + 1 < len(ts) else None, ac,
                              tcd_noise[i] if (tcd_noise is not None and i < len(tcd_noise)) else torch.zeros_like(lat))
+        if trace is not None:
+            trace.setdefault("lat_steps", []).append(lat.clone())
     if trace is not None:
         trace.update(lat_final=lat.clone())
     dec = M.vae_decode(P, lat, vcfg)

@@ -88,3 +88,25 @@ def test_struct_layouts_match_header(tmp_path):
         cls, fields = probes[parts[0]]
         want = [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f in fields]
         assert [int(x) for x in parts[1:]] == want, (parts[0], parts[1:], want)
+
+
+def test_tcd_timesteps_match_diffusers_schedule():
+    """diffusers TCDScheduler.set_timesteps (original_inference_steps 50): floor(linspace(0, 50, n, endpoint=False)) into [999, 979, ...]."""
+    from oracle import model_ref as M
+    from videovanish_amd.pipeline import ddim_timesteps, tcd_timesteps
+    assert tcd_timesteps(2) == [999, 499] and tcd_timesteps(4) == [999, 759, 499, 259] and tcd_timesteps(3) == [999, 679, 339]
+    assert tcd_timesteps(1) == [999] and tcd_timesteps(50) == [20 * k - 1 for k in range(50, 0, -1)]
+    for n in (1, 2, 3, 4, 5, 8, 10, 25, 50):
+        assert tcd_timesteps(n) == M.tcd_timesteps(n) and ddim_timesteps(n) == M.ddim_timesteps(n)
+
+
+def test_normalize_device():
+    """str / torch.device / int are all accepted and keep their index (one process per GPU passes cuda:<LOCAL_RANK>)."""
+    import pytest
+    import torch
+    from videovanish_amd.nn import normalize_device
+    assert normalize_device("cuda:3") == torch.device("cuda", 3)
+    assert normalize_device(torch.device("cuda", 5)) == torch.device("cuda", 5)
+    assert normalize_device(2) == torch.device("cuda", 2)
+    with pytest.raises(RuntimeError):
+        normalize_device("cpu")

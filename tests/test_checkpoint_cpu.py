@@ -85,3 +85,19 @@ def test_merge_lora_formats():
         merge_lora({k: v.clone() for k, v in base.items()}, {"unet." + q[:-7] + ".lora_A.weight": dq})
     with pytest.raises(KeyError):
         merge_lora({k: v.clone() for k, v in base.items()}, {"something.else": dq})
+
+
+def test_vae_legacy_attention_names():
+    """sd-vae-ft-mse as published uses query/key/value/proj_attn (some exports as [C,C,1,1]); vae.py asks for to_q/.../to_out.0."""
+    g = torch.Generator().manual_seed(9)
+    sd = {}
+    for old in ("query", "key", "value", "proj_attn"):
+        sd[f"decoder.mid_block.attentions.0.{old}.weight"] = torch.randn(8, 8, 1, 1, generator=g)
+        sd[f"decoder.mid_block.attentions.0.{old}.bias"] = torch.randn(8, generator=g)
+    ck = CheckpointWeights({"vae": sd})
+    for new, old in (("to_q", "query"), ("to_k", "key"), ("to_v", "value"), ("to_out.0", "proj_attn")):
+        w, b = ck.linear(f"vae.decoder.mid_block.attentions.0.{new}", 8, 8)
+        assert w.shape == (8, 8) and torch.equal(w, sd[f"decoder.mid_block.attentions.0.{old}.weight"].reshape(8, 8))
+        assert torch.equal(b, sd[f"decoder.mid_block.attentions.0.{old}.bias"])
+    with pytest.raises(KeyError):
+        ck.linear("vae.encoder.mid_block.attentions.0.to_q", 8, 8)

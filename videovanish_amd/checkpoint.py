@@ -26,6 +26,9 @@ def map_name(name):
     return comp, key
 
 
+_VAE_LEGACY_ATTN = (("to_q", "query"), ("to_k", "key"), ("to_v", "value"), ("to_out.0", "proj_attn"))
+
+
 class CheckpointWeights:
     """Drop-in for SyntheticWeights backed by real tensors.  `components`: {"unet": state_dict, "brushnet": ..., "vae": ...,
     "raft": ...}; `text_states`: the [1,77,768] CLIP encoding of the empty prompt (the reference's prompt is "")."""
@@ -45,12 +48,24 @@ class CheckpointWeights:
             raise KeyError(f"no checkpoint loaded for component {comp!r} (needed by {name})")
         full = key + suffix
         sd = self.components[comp]
+        if full not in sd and comp == "vae":
+            # the published sd-vae-ft-mse file predates diffusers' attention refactor: query/key/value/proj_attn, stored as
+            # [C, C, 1, 1] convolutions in some exports (diffusers renames them on load; a raw safetensors read does not)
+            for new, old in _VAE_LEGACY_ATTN:
+                if ("." + new + ".") in ("." + full):
+                    alt = full.replace(new + ".", old + ".")
+                    if alt in sd:
+                        full = alt
+                        break
         if full not in sd:
             raise KeyError(f"checkpoint of {comp!r} has no tensor {full!r} (internal name {name}{suffix})")
         t = sd[full].to(torch.float32)
         if shape is not None and tuple(t.shape) != tuple(shape):
-            if t.numel() == int(torch.tensor(shape).prod()) and len(shape) == 4 and t.dim() == 2:
-                t = t.reshape(shape)          # linear-projection checkpoints of 1x1 convs
+            n_need = 1
+            for d in shape:
+                n_need *= int(d)
+            if t.numel() == n_need and ((len(shape) == 4 and t.dim() == 2) or (len(shape) == 2 and t.dim() == 4 and t.shape[2:] == (1, 1))):
+                t = t.reshape(shape)          # linear-projection checkpoints of 1x1 convs, and 1x1-conv exports of linear projections
             else:
                 raise ValueError(f"{comp}:{full} has shape {tuple(t.shape)}, the architecture needs {tuple(shape)}")
         return t.contiguous()

@@ -3,6 +3,7 @@
 import numpy as np
 
 from .config import RunConfig
+from .nn import normalize_device
 from .pipeline import DiffuEraserHIP
 
 
@@ -15,8 +16,7 @@ class DiffuEraser:
         self.ckpt = ckpt
         self.run = run or RunConfig()
         self.dist = dist
-        dev = device if isinstance(device, str) and device.startswith("cuda") else "cuda:0"
-        self.model = DiffuEraserHIP(self.run, dev, weights=weights)
+        self.model = DiffuEraserHIP(self.run, normalize_device(device), weights=weights)
 
     def forward(self, frames, masks, priori, max_img_size=960, mask_dilation_iter=0, guidance_scale=None, progress=None,
                 num_inference_steps=None, scheduler=None):

@@ -6,16 +6,16 @@ import numpy as np
 import torch
 
 from . import hip
-from .nn import Ctx
+from .nn import Ctx, normalize_device
 from .raft import ITERS, RAFT
 
 _cache = {}
 
 
 def _model(device, dtype, weight_seed):
-    key = (str(device), dtype, weight_seed)
+    key = (str(device) if device is not None else "cuda:%d" % torch.cuda.current_device(), dtype, weight_seed)
     if key not in _cache:
-        ctx = Ctx(str(device) if device is not None else "cuda:0", dtype, weight_seed)
+        ctx = Ctx(normalize_device(device), dtype, weight_seed)
         _cache[key] = (ctx, RAFT(ctx))
     return _cache[key]
 

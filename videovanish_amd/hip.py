@@ -123,11 +123,20 @@ def dtype_id(name):
 
 
 def _need_cuda(*ts):
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("videovanish_amd.hip: tensors must live on the GPU (no CPU fallback)")
-        if t is not None and not t.is_contiguous():
+        if not t.is_contiguous():
             raise RuntimeError("videovanish_amd.hip: tensors must be contiguous")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            # kernels are launched on the CURRENT device's stream: a tensor on another GPU would be a cross-device pointer
+            raise RuntimeError(f"videovanish_amd.hip: tensor on {t.device} but the current device is cuda:{cur} "
+                               "(one process per GPU: torch.cuda.set_device(LOCAL_RANK) before building the model)")
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -145,6 +154,9 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
         C1 = x1.shape[-1]
     M = F * Hout * Wout
     nout = N // 2 if epilogue == EPI_GEGLU else N
+    if res0 is not None and res1 is not None and res0.dtype != res1.dtype:
+        raise RuntimeError(f"vv_conv_gemm: res0 ({res0.dtype}) and res1 ({res1.dtype}) must share one dtype (one res_dtype field covers both)")
+    res_dt = dt_of(res0) if res0 is not None else (dt_of(res1) if res1 is not None else F32)
     if out is None:
         od = h16(dtype) if out_dtype is None else out_dtype
         out = torch.empty((M, nout), dtype=od, device=x0.device)
@@ -153,7 +165,7 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
                    weight=weight.data_ptr(), N=N, K=K, Kpad=weight.shape[1], Npad=weight.shape[0],
                    bias=bias.data_ptr() if bias is not None else 0, rowvec=rowvec.data_ptr() if rowvec is not None else 0,
                    res0=res0.data_ptr() if res0 is not None else 0, res1=res1.data_ptr() if res1 is not None else 0,
-                   res_dtype=dt_of(res0) if res0 is not None else F32, out=out.data_ptr() + out_col * out.element_size(), out_dtype=dt_of(out),
+                   res_dtype=res_dt, out=out.data_ptr() + out_col * out.element_size(), out_dtype=dt_of(out),
                    ldo=out.shape[-1],
                    epilogue=epilogue, out_scale=out_scale, ksize_w=ksize_w, act=act, split_heads=split_heads, split_dim=split_dim,
                    split_tokens=split_tokens)

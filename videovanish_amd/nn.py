@@ -10,6 +10,21 @@ from . import hip, packing
 from .weights import SyntheticWeights
 
 
+def normalize_device(device):
+    """str ("cuda", "cuda:1"), torch.device or int -> torch.device("cuda", index).  A bare "cuda" means the CURRENT device
+    (one process per GPU sets it with torch.cuda.set_device(LOCAL_RANK)); anything that is not a HIP device is refused."""
+    if device is None:
+        device = "cuda"
+    if isinstance(device, int):
+        device = torch.device("cuda", device)
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError(f"videovanish_amd: device {device} is not a HIP device (there is no CPU fallback)")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 class Ctx:
     """Per-process model context: device, MFMA operand dtype, weight source."""
 
@@ -17,7 +32,9 @@ class Ctx:
         hip.lib()  # fail loudly before anything else if the extension is missing
         if not torch.cuda.is_available():
             raise RuntimeError("videovanish_amd: no HIP device visible (there is no CPU fallback)")
-        self.device = torch.device(device)
+        self.device = normalize_device(device)
+        if torch.cuda.current_device() != self.device.index:
+            torch.cuda.set_device(self.device)      # one process per GPU: every launch goes to the current device's stream
         self.dt = hip.dtype_id(dtype)
         self.h16 = hip.h16(self.dt)
         self.src = weights if weights is not None else SyntheticWeights(weight_seed)

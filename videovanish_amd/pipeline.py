@@ -84,7 +84,10 @@ def ddim_timesteps(steps):
 
 
 def tcd_timesteps(steps):
-    return [int(round(1000 - i * 1000 / steps)) - 1 for i in range(steps)]
+    """diffusers TCDScheduler.set_timesteps restated (original_inference_steps = 50, strength 1): the 50 origin timesteps
+    20*k - 1, reversed, picked at floor(linspace(0, 50, steps, endpoint=False)): 2 -> [999, 499], 4 -> [999, 759, 499, 259]."""
+    origin = [20 * k - 1 for k in range(1, 51)][::-1]
+    return [origin[int(math.floor(i * 50.0 / steps))] for i in range(steps)]
 
 
 def alphas_cumprod():
@@ -210,6 +213,8 @@ class DiffuEraserHIP:
                     z = tcd_noise[i] if tcd_noise is not None else torch.zeros_like(lat)
                     lat = hip.sched_step(lat, eps, z, a_t ** 0.5, (1 - a_t) ** 0.5, (r ** 0.5) * a_s ** 0.5, (r ** 0.5) * (1 - a_s) ** 0.5,
                                          (1 - r) ** 0.5)
+            if trace is not None:
+                trace.setdefault("lat_steps", []).append(lat.clone())
             if progress is not None:
                 progress(i + 1, len(ts))
         if trace is not None:
@@ -243,7 +248,11 @@ class DiffuEraserHIP:
             base, fr, pr, mk = 0, None, None, None
         res = self.forward_device(fr, pr, mk, T, base, steps=steps, scheduler=scheduler, progress=progress, dist=dist, return_float=return_float)
         if return_float:
+            # per-rank return: the blended fp32 pixels of the frames THIS rank owns (no gather); a rank that owns no
+            # frame (world > number of chunks) gets an empty array and (0, 0)
             out, (lo, hi) = res
+            if out is None:
+                return np.zeros((0, H, W, 3), np.float32), (0, 0)
             return out.cpu().numpy(), (lo, hi)
         out, (lo, hi) = res
         out_frames = {}
