@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VV_ABI_VERSION 3
+#define VV_ABI_VERSION 4
 
 enum { VV_BF16 = 0, VV_F16 = 1, VV_F32 = 2, VV_U8 = 3 };
 enum { VV_OK = 0, VV_E_ARG = -1, VV_E_UNSUPPORTED = -2, VV_E_LAUNCH = -3 };
@@ -83,6 +83,8 @@ typedef struct {
     int32_t split_dim;    /* head dim (multiple of 4) */
     int32_t split_tokens; /* rows per batch element: row m = b*split_tokens + token; NEGATIVE: -split_tokens tokens per batch element
                              with token-major rows, m = token*(M/tokens) + b (temporal attention: token = frame, b = pixel) */
+    int32_t tile_hint;    /* 0 = automatic tiling; 1 = 128-row tiles only; 2 = the 256-row tile kernel whenever the shape is eligible
+                             (h16 sources with channel counts % 64 == 0, <= 9 taps, no fused resize, Npad % 320 or % 256 == 0) */
 } vv_conv_params;
 int vv_conv_gemm(const vv_conv_params* host_p, int dtype, void* stream);
 
@@ -204,6 +206,11 @@ int vv_brushnet_input(const float* lat, const float* cond, const uint8_t* mask2d
                       void* out16, int dtype, void* stream);
 /* fp32 NHWC [..][cin] -> h16 [..][cpad] (zero padded channels), used for conv_in of latents */
 int vv_pad_channels(const float* x, int64_t rows, int cin, int cpad, float scale, void* out, int dtype, void* stream);
+/* same, fp32 output (input of a split-precision layer) */
+int vv_pad_channels_f32(const float* x, int64_t rows, int cin, int cpad, float scale, float* out, void* stream);
+/* split precision operands for the 3-pass "precise" convolutions (VAE decoder): hi = h16(x), lo = h16((x - hi) * lo_scale);
+ * x*w ~= hi*wh + (lo*wh)/lo_scale + hi*wl/w_scale, each product one vv_conv_gemm launch accumulated through res0/out_scale */
+int vv_split_f32(const float* x, int64_t n, float lo_scale, void* hi16, void* lo16, int dtype, void* stream);
 /* decoded [T][H][W][ld] fp32 (first 3 channels) -> pix01 = clamp(x/2+0.5,0,1) blended into acc:
  * acc = acc*(1-w[t]) + pix*w[t]  (separately rounded fp32 products, no FMA contraction) */
 int vv_decode_blend(const float* dec, int ld, const float* w, int T, int64_t HW, float* acc, void* stream);

@@ -388,3 +388,49 @@ def test_image_kernels_bit_exact(gpu):
                            imageops.gaussian_taps_21()).cpu().numpy()
     ref = np.stack([I.blur_compose(pix[t], orig[t], m[t]) for t in range(2)])
     assert (got == ref).all()
+
+
+@pytest.mark.parametrize("dname,tol", [("fp16", 3e-6), ("bf16", 1.5e-4)])
+def test_precise_split_conv_and_linear(gpu, dname, tol):
+    """Split-precision layers (nn._precise_gemm: hi*wh + lo*wh + hi*wl in three MFMA launches) against an fp64 reference on
+    UN-rounded fp32 operands: the error must sit orders of magnitude below the one-pass h16 layer (5e-4 fp16 / 4e-3 bf16)."""
+    from videovanish_amd import nn as vnn
+    g = torch.Generator().manual_seed(31)
+    Fr, H, W, cin, cout = 2, 12, 20, 64, 128
+
+    class Src:
+        def conv(self, name, ci, co, k, gain=1.0):
+            return torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k), torch.randn(co, generator=g)
+
+        def linear(self, name, ci, co, gain=1.0, bias=True):
+            return torch.randn(co, ci, generator=g) / math.sqrt(ci), torch.randn(co, generator=g)
+
+    ctx = vnn.Ctx("cuda:0", dname, 0, weights=Src())
+    x = torch.randn(Fr, cin, H, W, generator=g)
+    res = torch.randn(Fr, cout, H, W, generator=g)
+    for precise in (False, True):
+        g.manual_seed(32)
+        conv = vnn.Conv(ctx, "c", cin, cout, k=3, precise=precise)
+        g.manual_seed(32)
+        w, b = Src().conv("c", cin, cout, 3)
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + res.double()
+        xin = _nhwc(x).reshape(-1, cin).to(gpu)
+        if not precise:
+            xin = xin.to(ctx.h16)
+        out, _, _ = conv(xin, Fr, H, W, res0=_nhwc(res).reshape(-1, cout).to(gpu))
+        got = out.cpu().reshape(Fr, H, W, cout).permute(0, 3, 1, 2).double()
+        err = ((got - ref).abs().max() / ref.abs().max()).item()
+        print(f"conv3 {dname} precise={precise}: rel max err {err:.2e}")
+        assert err <= (tol if precise else 1e-2)
+        if precise:
+            assert err <= tol
+    g.manual_seed(33)
+    lin = vnn.Linear(ctx, "l", cin, cout, precise=True)
+    g.manual_seed(33)
+    w, b = Src().linear("l", cin, cout)
+    xm = torch.randn(300, cin, generator=g)
+    ref = xm.double() @ w.double().t() + b.double()
+    got = lin(xm.to(gpu)).cpu().double()
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    print(f"linear {dname} precise: rel max err {err:.2e}")
+    assert err <= tol

@@ -12,13 +12,18 @@ compile() {   # compile <src> <obj> [extra flags]
     pids+=($!)
   fi
 }
-for f in vv_api vv_gemm vv_conv3 vv_norm vv_elem vv_image vv_flow; do
-  [ -f $f.hip ] && compile $f $f
+# VV_AB=1 ./build.sh builds the lab variant: environment-selected A/B kernels + the opt-in vv_conv3 kernel
+AB=""
+SRCS="vv_api vv_gemm vv_gemm256 vv_norm vv_elem vv_image vv_flow"
+if [ -n "$VV_AB" ]; then AB="-DVV_AB"; SRCS="$SRCS vv_conv3"; else rm -f build/vv_conv3.o; fi
+if [ "$(cat build/.ab 2>/dev/null)" != "$AB" ]; then rm -f build/*.o; echo "$AB" > build/.ab; fi
+for f in $SRCS; do
+  [ -f $f.hip ] && compile $f $f $AB
 done
 # attention, small head dims: MFMA results feed VALU code (softmax) every tile -> keep accumulators in arch VGPRs
 # (no v_accvgpr_read/write traffic); large head dims need the AGPR half of the register file
-compile vv_attn vv_attn_small -DVV_ATTN_PART=0 -mllvm -amdgpu-mfma-vgpr-form
-compile vv_attn vv_attn_large -DVV_ATTN_PART=1
+compile vv_attn vv_attn_small -DVV_ATTN_PART=0 -mllvm -amdgpu-mfma-vgpr-form $AB
+compile vv_attn vv_attn_large -DVV_ATTN_PART=1 $AB
 for p in "${pids[@]}"; do wait $p; done
 rm -f build/vv_attn.o
 hipcc --offload-arch=gfx950 -shared -fPIC -o libvvhip.so build/*.o

@@ -349,6 +349,7 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
         // short sequences (temporal attention over <=32 frames, tiny test shapes): one wave per block, 32-key tiles
         if (p.Nq <= 32 && p.Nkv <= 32) return attn_launch<T, D, 2, 32, 1, true>(p, st);
         if constexpr (D <= 80) {
+#ifdef VV_AB      // lab build only: environment-selected A/B variants (profiles/r1_attn_pmc.txt)
             static int var = -1;
             if (var < 0) { const char* e = getenv("VV_ATTN_VARIANT"); var = e ? atoi(e) : 0; }
             if (var == 1) return attn_launch<T, D, 2, 64, 4, false, 1>(p, st);     // no register prefetch
@@ -363,6 +364,7 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
             if (var == 10) return attn_launch<T, D, 2, 64, 4, false, 1, true>(p, st);   // DMA, uncapped registers (2 waves/SIMD)
             if (var == 13) return attn_launch<T, D, 2, 32, 4, false, 4, true>(p, st);   // DMA, 32-key tiles, capped at 128 VGPRs (4 waves/SIMD)
             if (var == 14) return attn_launch<T, D, 2, 64, 4, true, 3>(p, st);          // register staged, capped at 168 VGPRs (3 waves/SIMD)
+#endif
             // default for d <= 64: K/V by LDS-DMA, double buffered, 3 waves/SIMD (d = 80 would spill: stays register staged)
             if (D <= 64) return attn_launch<T, D, 2, 64, 4, false, 3, true>(p, st);
         }

@@ -155,6 +155,47 @@ extern "C" int vv_brushnet_input(const float* lat, const float* cond, const uint
     return VV_OK;
 }
 
+__global__ void pad_channels_f32_kernel(const float* x, int64_t rows, int cin, int cpad, float scale, float* out) {
+    const int64_t n = rows * cpad;
+    for (int64_t i = blockIdx.x * (int64_t)EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) {
+        const int c = (int)(i % cpad);
+        out[i] = c < cin ? x[(i / cpad) * cin + c] * scale : 0.f;
+    }
+}
+
+extern "C" int vv_pad_channels_f32(const float* x, int64_t rows, int cin, int cpad, float scale, float* out, void* stream) {
+    if (!x || !out || rows <= 0 || cin <= 0 || cpad < cin) VV_FAIL(VV_E_ARG, "vv_pad_channels_f32: bad args");
+    hipLaunchKernelGGL(pad_channels_f32_kernel, grid_for(rows * cpad), dim3(EB), 0, (hipStream_t)stream, x, rows, cin, cpad, scale, out);
+    VV_CHECK_LAUNCH("vv_pad_channels_f32");
+    return VV_OK;
+}
+
+// split precision (hi + lo): hi = h16(x), lo = h16((x - f32(hi)) * lo_scale).  x ~= hi + lo / lo_scale to ~2^-19 (fp16) relative.
+template <typename T>
+__global__ void split_f32_kernel(const float* x, int64_t n4, float lo_scale, unsigned short* hi, unsigned short* lo) {
+    for (int64_t i = blockIdx.x * (int64_t)EB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EB) {
+        const float4 v = ((const float4*)x)[i];
+        const float a[4] = {v.x, v.y, v.z, v.w};
+        unsigned short h[4], l[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            h[c] = T::from_f32(a[c]);
+            l[c] = T::from_f32((a[c] - T::to_f32(h[c])) * lo_scale);
+        }
+        ((uint2*)hi)[i] = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+        ((uint2*)lo)[i] = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+    }
+}
+
+extern "C" int vv_split_f32(const float* x, int64_t n, float lo_scale, void* hi, void* lo, int dtype, void* stream) {
+    if (!x || !hi || !lo || n <= 0 || (n & 3)) VV_FAIL(VV_E_ARG, "vv_split_f32: bad args (n must be a positive multiple of 4)");
+    if (dtype == VV_BF16) hipLaunchKernelGGL(split_f32_kernel<BF16>, grid_for(n / 4), dim3(EB), 0, (hipStream_t)stream, x, n / 4, lo_scale, (unsigned short*)hi, (unsigned short*)lo);
+    else if (dtype == VV_F16) hipLaunchKernelGGL(split_f32_kernel<F16>, grid_for(n / 4), dim3(EB), 0, (hipStream_t)stream, x, n / 4, lo_scale, (unsigned short*)hi, (unsigned short*)lo);
+    else VV_FAIL(VV_E_ARG, "vv_split_f32: bad dtype");
+    VV_CHECK_LAUNCH("vv_split_f32");
+    return VV_OK;
+}
+
 extern "C" int vv_pad_channels(const float* x, int64_t rows, int cin, int cpad, float scale, void* out, int dtype, void* stream) {
     if (!x || !out || rows <= 0 || cin <= 0 || cpad < cin) VV_FAIL(VV_E_ARG, "vv_pad_channels: bad args");
     const int64_t n = rows * cpad;

@@ -19,7 +19,18 @@
 #include "vv_common.h"
 #include "vv_gemm_epilogue.h"
 
+extern "C" int vv_gemm256_try(const vv_conv_params* pp, int dtype, int force, void* stream);
+
+// A/B switches of the lab build (-DVV_AB: environment variables read once per process).  The product build takes the measured
+// defaults (profiles/r1_gemm_ab.txt) with no getenv in any launch path.
+#ifdef VV_AB
+#define VV_AB_ENV(name) (getenv(name) != nullptr)
+#define VV_AB_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
 extern "C" int vv_conv3_halo_try(const vv_conv_params* pp, int dtype, void* stream);
+#else
+#define VV_AB_ENV(name) false
+#define VV_AB_INT(name, dflt) (dflt)
+#endif
 
 namespace {
 
@@ -392,16 +403,17 @@ int launch_cfg(const vv_conv_params& p, int M, hipStream_t st) {
     int tilesM = (M + BM - 1) / BM;
     const int tilesN = p.Npad / BN;
     if constexpr (MODE == MODE_HALO) tilesM = p.F * ((p.Hin + 7) / 8) * ((p.Win + 15) / 16);
-    static int split = -1;
-    if (split < 0) { const char* e = getenv("VV_GEMM_SPLIT"); split = e ? atoi(e) : 2; }
+    static const int split = VV_AB_INT("VV_GEMM_SPLIT", 2);
     // 128x128 tiles: 130 VGPRs uncapped; capping at 128 (4 spilled) lets a 4th block share the CU (LDS 4 x 32-40 KB)
-    static const bool occ4 = getenv("VV_GEMM_NO_OCC4") == nullptr;
+    static const bool occ4 = !VV_AB_ENV("VV_GEMM_NO_OCC4");
     constexpr bool CAN4 = WR * WC == 4 && (MODE == MODE_LIN || MODE == MODE_FAST9 || (NT == 4 && (MODE == MODE_FAST || MODE == MODE_HALO)));
     if (CAN4 && occ4 && (MODE == MODE_HALO || split == 2)) { if constexpr (CAN4) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2, 64, 4>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN); }
     else if constexpr (MODE == MODE_FAST32 || MODE == MODE_HALO) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
+#ifdef VV_AB
     else if (split == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 1, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     else if (split == 3 && MODE == MODE_FAST) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 1, 32>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     else if (split == 0) hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 0, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
+#endif
     else hipLaunchKernelGGL((conv_gemm_kernel<T, WR, WC, MT, NT, MODE, 2, 64>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);
     VV_CHECK_LAUNCH("vv_conv_gemm");
     return VV_OK;
@@ -414,7 +426,7 @@ int launch_t(const vv_conv_params& p, int M, hipStream_t st) {
     // N a multiple of both: the 128x128 tile runs 4 blocks per CU (128 VGPRs) against 3 for 128x160 -> +2..8 % on the LDS-DMA
     // loaders when there are enough row tiles (profiles/r1_gemm_ab.txt, eighth A/B)
     // (opt-in: in the pipeline the 3x3 convs lose 2-3 % with it, and the linear layers now run 128x160 at 4 blocks through LIN)
-    static const bool pref128 = getenv("VV_GEMM_PREF128") != nullptr && getenv("VV_GEMM_NO_OCC4") == nullptr;
+    static const bool pref128 = VV_AB_ENV("VV_GEMM_PREF128") && !VV_AB_ENV("VV_GEMM_NO_OCC4");
     if (pref128 && p.Npad % 128 == 0 && (MODE == MODE_FAST || MODE == MODE_HALO) && M >= 16384) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, M, st);
     if (p.Npad % 160 == 0) return launch_cfg<T, 2, 2, 4, 5, MODE>(p, M, st);   // (a 256x160 4-wave tile measured the same: profiles/r1_gemm_ab.txt)
     if (p.Npad % 128 == 0) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, M, st);
@@ -425,23 +437,30 @@ int launch_t(const vv_conv_params& p, int M, hipStream_t st) {
 template <typename T>
 int launch_mode(const vv_conv_params& p, int M, hipStream_t st) {
     const bool fast = (p.C0 % 64 == 0) && (p.C1 % 64 == 0) && p.Kpad == p.K;
-    static const bool no32 = getenv("VV_GEMM_NO_FAST32") != nullptr;
-    {   // large 3x3 feature maps: the 256-pixel halo kernel (vv_conv3.hip) when the shape is eligible
-        const int r = vv_conv3_halo_try(&p, std::is_same<T, BF16>::value ? VV_BF16 : VV_F16, (void*)st);
+    static const bool no32 = VV_AB_ENV("VV_GEMM_NO_FAST32");
+    constexpr int dt = std::is_same<T, BF16>::value ? VV_BF16 : VV_F16;
+    if (p.tile_hint != 1) {   // compute-bound shapes: the 256-row tile kernel (vv_gemm256.hip)
+        const int r = vv_gemm256_try(&p, dt, p.tile_hint == 2, (void*)st);
         if (r > -1000) return r;
     }
-    static const bool nohalo = getenv("VV_GEMM_NO_HALO") != nullptr;
+#ifdef VV_AB
+    {   // opt-in 256-pixel halo kernel (vv_conv3.hip; measured slower than the 128-row halo tile)
+        const int r = vv_conv3_halo_try(&p, dt, (void*)st);
+        if (r > -1000) return r;
+    }
+#endif
+    static const bool nohalo = VV_AB_ENV("VV_GEMM_NO_HALO");
     if (fast && !nohalo && p.in_dtype != VV_F32 && p.ksize == 3 && (p.ksize_w == 0 || p.ksize_w == 3) && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 &&
         p.Hv == p.Hin && p.Wv == p.Win && p.Hout == p.Hin && p.Wout == p.Win && p.epilogue != VV_EPI_GEGLU && (p.Npad % 160 == 0 || p.Npad % 128 == 0)) {
         // patch grid waste <= 15 % (the halo tile is worth 17-25 %)
         const int64_t cover = (int64_t)((p.Hin + 7) / 8) * 8 * ((p.Win + 15) / 16) * 16;
         if (cover * 100 <= (int64_t)p.Hin * p.Win * 115) return launch_t<T, MODE_HALO>(p, M, st);
     }
-    static const bool nolin = getenv("VV_GEMM_NO_LIN") != nullptr;
+    static const bool nolin = VV_AB_ENV("VV_GEMM_NO_LIN");
     if (fast && !nolin && p.in_dtype != VV_F32 && p.ksize == 1 && p.ksize_w <= 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.C1 == 0 &&
         p.Hv == p.Hin && p.Wv == p.Win && p.Hout == p.Hin && p.Wout == p.Win) return launch_t<T, MODE_LIN>(p, M, st);
     if (p.in_dtype == VV_F32) return (fast && !no32) ? launch_t<T, MODE_FAST32>(p, M, st) : launch_t<T, MODE_F32>(p, M, st);
-    static const bool no9 = getenv("VV_GEMM_NO_FAST9") != nullptr;
+    static const bool no9 = VV_AB_ENV("VV_GEMM_NO_FAST9");
     if (fast && !no9 && p.Hv == p.Hin && p.Wv == p.Win && p.ksize * (p.ksize_w > 0 ? p.ksize_w : p.ksize) <= 9) return launch_t<T, MODE_FAST9>(p, M, st);
     return fast ? launch_t<T, MODE_FAST>(p, M, st) : launch_t<T, MODE_H16>(p, M, st);
 }

@@ -1,0 +1,212 @@
+// K1/K6 (large-tile form): implicit-GEMM convolution / linear layer on 256 x {320,256} x 64 tiles for the compute-bound
+// shapes of the UNet / BrushNet / VAE (same contract as vv_conv_gemm; dispatched from vv_gemm.hip, see include/vvhip.h).
+//
+// Why a second tiling: the 128 x 160 kernel (vv_gemm.hip) moves 36 KB of L2->LDS bytes per 5.2 MFLOP k tile and the LDS-DMA
+// stream tops out at ~27 B/clk/CU (tools/fill_rate.hip), which caps it near half of the MFMA peak however many blocks share a
+// CU.  A 256 x 320 tile moves 72 KB per 21 MFLOP: twice the reuse per byte.  One 512-thread block (8 waves, 2 per SIMD, <= 256
+// VGPRs) owns a CU, so nothing overlaps between blocks any more: the k loop is software pipelined inside the block instead --
+// two LDS stages in DISTINCT __shared__ arrays (so hipcc does not order the ds_reads of stage k behind the LDS-DMA of stage
+// k+1), the DMA of tile k+1 issued before the MFMAs of tile k, one vmcnt(0)+barrier per k tile (cdna_hip_programming.md 5,
+// "minimum 2-phase" form of the 256^2 template).
+//
+// Waves: 2 (M) x 4 (N); a wave owns 128 rows x NT*16 columns = MT(8) x NT accumulator tiles of v_mfma_f32_16x16x32 with
+// swapped operands (lane owns 4 consecutive output channels of one row -> shared 16-byte epilogue, vv_gemm_epilogue.h).
+// LDS image: [row][64 k] h16, 128-byte rows, 16-byte chunk c of row r stored at chunk c ^ (r & 7); filled by
+// global_load_lds_dwordx4 with the swizzle applied on the per-lane SOURCE address (the LDS side of the DMA is lane-linear).
+//   LIN  : plain [M][K] h16 matrix (linear layers, 1x1 stride-1 convs)
+//   CONV : im2col gather, <= 9 taps, stride 1/2, zero padding, two-source channel concat, no fused resize; per row only the
+//          pixel index of tap (0,0) and a tap-validity bit mask are kept (out-of-image taps read a zero page)
+#include "vv_common.h"
+#include "vv_gemm_epilogue.h"
+
+namespace {
+
+enum { G256_LIN = 0, G256_CONV = 1 };
+
+__device__ __attribute__((aligned(64))) const unsigned int g256_zero_page[16] = {0};
+
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+    typedef const void __attribute__((address_space(1))) * gp_t;
+    typedef void __attribute__((address_space(3))) * lp_t;
+    __builtin_amdgcn_global_load_lds((gp_t)gptr, (lp_t)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int NT, int MODE>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const vv_conv_params p, const int M, const int tilesM, const int tilesN) {
+    constexpr int BM = 256, BN = 4 * NT * 16, MT = 8;
+    constexpr int AP = BM / 64;        // 1 KB pieces (8 rows x 128 B) of the A tile per wave: 4
+    constexpr int BP = BN / 64;        // ... of the B tile per wave: 5 (BN = 320) or 4 (BN = 256)
+    __shared__ __attribute__((aligned(1024))) unsigned char sA0[BM * 128];
+    __shared__ __attribute__((aligned(1024))) unsigned char sA1[BM * 128];
+    __shared__ __attribute__((aligned(1024))) unsigned char sB0[BN * 128];
+    __shared__ __attribute__((aligned(1024))) unsigned char sB1[BN * 128];
+
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    // XCD-aware bijective remap: blocks b and b+8 share an XCD -> every XCD walks a contiguous range of tiles (column tiles of
+    // one row panel fastest), so a row panel of A and the weight matrix stay in ONE L2
+    const int nblk = tilesM * tilesN;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % tilesN, tile_m = bid / tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-thread DMA state.  Piece i of this wave = tile rows (wave + 8 i) * 8 .. + 7; lane -> row (lane >> 3), physical
+    // chunk (lane & 7) which holds logical chunk (lane & 7) ^ (row & 7) = (lane & 7) ^ (lane >> 3)
+    const int prow = lane >> 3;
+    const int lchunk = (lane & 7) ^ prow;
+    const int HWo = p.Hout * p.Wout;
+    const int Cin = p.C0 + p.C1;
+    const int KW = p.ksize_w > 0 ? p.ksize_w : p.ksize;
+    const unsigned char* aptr[MODE == G256_LIN ? AP : 1];
+    int pix9[MODE == G256_CONV ? AP : 1];
+    unsigned okm[MODE == G256_CONV ? (AP + 1) / 2 : 1];      // bit (i & 1) * 16 + tap: tap of piece-row i lies inside the image
+    if constexpr (MODE == G256_LIN) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            int m = m0 + (wave + 8 * i) * 8 + prow;
+            m = m < M ? m : M - 1;                            // rows past M are clamped (never stored by the epilogue)
+            aptr[i] = (const unsigned char*)p.in0 + ((int64_t)m * p.C0 + lchunk * 8) * 2;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < (AP + 1) / 2; ++i) okm[i] = 0u;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int m = m0 + (wave + 8 * i) * 8 + prow;
+            const bool v = m < M;
+            const int mm = v ? m : 0;
+            const int f = mm / HWo, rem = mm - f * HWo;
+            const int y = rem / p.Wout, x = rem - y * p.Wout;
+            const int yb = y * p.stride - p.pad_t, xb = x * p.stride - p.pad_l;
+            pix9[i] = (f * p.Hin + yb) * p.Win + xb;
+            unsigned bits = 0u;
+            for (int tap = 0; tap < p.ksize * KW; ++tap) {
+                const int yv = yb + tap / KW, xv = xb + tap % KW;
+                if (v && yv >= 0 && yv < p.Hin && xv >= 0 && xv < p.Win) bits |= 1u << tap;
+            }
+            okm[i >> 1] |= bits << ((i & 1) * 16);
+        }
+    }
+    const unsigned char* wptr = (const unsigned char*)p.weight + ((int64_t)(n0 + wave * 8 + prow) * p.Kpad + lchunk * 8) * 2;
+    const int64_t wstep = (int64_t)64 * p.Kpad * 2;           // 8 pieces = 64 weight rows further
+
+    auto dma_tile = [&](const int kt, unsigned char* bufA, unsigned char* bufB) {
+        if constexpr (MODE == G256_LIN) {
+#pragma unroll
+            for (int i = 0; i < AP; ++i) glds16(aptr[i] + kt * 128, bufA + (wave + 8 * i) * 1024);
+        } else {
+            const int k0 = kt * 64;
+            const int tap = k0 / Cin;
+            int cc = k0 - tap * Cin;
+            const int ky = tap / KW, kx = tap - ky * KW;
+            const unsigned char* src = (const unsigned char*)p.in0;
+            int Cs = p.C0;
+            if (cc >= p.C0) { src = (const unsigned char*)p.in1; cc -= p.C0; Cs = p.C1; }
+            const int dpix = ky * p.Win + kx;
+            const int csrc = cc + lchunk * 8;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                const bool ok = (okm[i >> 1] >> ((i & 1) * 16 + tap)) & 1u;
+                const void* g = ok ? (const void*)(src + ((int64_t)(pix9[i] + dpix) * Cs + csrc) * 2) : (const void*)g256_zero_page;
+                glds16(g, bufA + (wave + 8 * i) * 1024);
+            }
+        }
+        const unsigned char* w = wptr + kt * 128;
+#pragma unroll
+        for (int i = 0; i < BP; ++i) glds16(w + i * wstep, bufB + (wave + 8 * i) * 1024);
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](const unsigned char* cA, const unsigned char* cB) {
+        const unsigned char* a = cA + (wr * 128 + lr) * 128;
+        const unsigned char* b = cB + (wc * NT * 16 + lr) * 128;
+        const int sw = lr & 7;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int off = ((s * 4 + lq) ^ sw) << 4;
+            uint4 bf[NT], af[MT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = *(const uint4*)(b + j * 2048 + off);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *(const uint4*)(a + i * 2048 + off);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = T::mfma(bf[j], af[i], acc[i][j]);
+        }
+    };
+
+    const int nk = p.Kpad / 64;
+    dma_tile(0, sA0, sB0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 1 < nk) dma_tile(kt + 1, sA1, sB1);
+        compute(sA0, sB0);
+        __syncthreads();          // vmcnt(0): tile kt+1 has landed; barrier: everybody is done reading stage 0
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) dma_tile(kt + 2, sA0, sB0);
+            compute(sA1, sB1);
+            __syncthreads();
+        }
+    }
+
+    auto row_m = [&](int row, bool& ok) -> int { ok = m0 + row < M; return m0 + row; };
+    gemm_epilogue<T, MT, NT>(p, acc, wr * 128, n0 + wc * NT * 16, lr, lq, HWo, row_m);
+}
+
+template <typename T, int NT, int MODE>
+int launch256(const vv_conv_params& p, int M, hipStream_t st) {
+    constexpr int BN = 4 * NT * 16;
+    const int tilesM = (M + 255) / 256, tilesN = p.Npad / BN;
+    hipLaunchKernelGGL((gemm256_kernel<T, NT, MODE>), dim3(tilesM * tilesN), dim3(512), 0, st, p, M, tilesM, tilesN);
+    VV_CHECK_LAUNCH("vv_conv_gemm(256-row tile)");
+    return VV_OK;
+}
+
+template <typename T>
+int launch256_t(const vv_conv_params& p, int M, bool lin, hipStream_t st) {
+    const bool n5 = p.Npad % 320 == 0 && p.epilogue != VV_EPI_GEGLU;     // GEGLU pairs value/gate tiles: needs an even NT
+    if (n5) return lin ? launch256<T, 5, G256_LIN>(p, M, st) : launch256<T, 5, G256_CONV>(p, M, st);
+    return lin ? launch256<T, 4, G256_LIN>(p, M, st) : launch256<T, 4, G256_CONV>(p, M, st);
+}
+
+}  // namespace
+
+// Eligibility + launch.  Returns VV_OK / an error after launching, or -1000 when the shape is not eligible (caller falls back
+// to the 128-row kernels).  `force`: launch whenever the shape is ELIGIBLE; otherwise only when the heuristic expects a win.
+extern "C" int vv_gemm256_try(const vv_conv_params* pp, int dtype, int force, void* stream) {
+    const vv_conv_params& p = *pp;
+    const int kw = p.ksize_w > 0 ? p.ksize_w : p.ksize;
+    if (p.in_dtype == VV_F32 || p.Kpad != p.K || (p.C0 & 63) || (p.C1 & 63)) return -1000;
+    if (p.Hv != p.Hin || p.Wv != p.Win || p.ksize * kw > 9) return -1000;
+    if (!(p.Npad % 320 == 0 && p.epilogue != VV_EPI_GEGLU) && p.Npad % 256 != 0) return -1000;
+    const int64_t M64 = (int64_t)p.F * p.Hout * p.Wout;
+    const int M = (int)M64;
+    const bool lin = p.ksize == 1 && kw == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.C1 == 0 && p.Hout == p.Hin && p.Wout == p.Win;
+    if (!force) {
+        // One block per CU: nothing overlaps the (fp32 residual) epilogue, and the grid is quantised to whole rounds of 256 blocks.
+        // Measured A/B against the 128-row kernels on the shapes of a 720p step (tools/bench_gemm256.py, profiles/r2_gemm256_ab.txt):
+        // it wins (x1.05 .. x1.33) where the k loop is long or the tile count small -- GEGLU projections with K >= 640, K >= 5120
+        // linears, 3x3 convs with K >= 5760 (single source, or any at the low-resolution levels) -- and loses on short-K layers.
+        const int BN = (p.Npad % 320 == 0 && p.epilogue != VV_EPI_GEGLU) ? 320 : 256;
+        const int64_t tiles = ((M64 + 255) / 256) * (p.Npad / BN);
+        if (tiles < 400) return -1000;
+        bool win;
+        if (lin) win = (p.epilogue == VV_EPI_GEGLU && p.K >= 640) || p.K >= 5120;
+        else win = p.ksize == 3 && p.stride == 1 && p.K >= 5760 && (p.C1 == 0 || M64 <= 65536);
+        if (!win) return -1000;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == VV_BF16 ? launch256_t<BF16>(p, M, lin, st) : launch256_t<F16>(p, M, lin, st);
+}

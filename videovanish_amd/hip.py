@@ -11,7 +11,7 @@ import torch
 BF16, F16, F32, U8 = 0, 1, 2, 3
 EPI_NONE, EPI_GEGLU = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 _DT = {"bf16": BF16, "fp16": F16}
 _TORCH_H16 = {BF16: torch.bfloat16, F16: torch.float16}
 
@@ -51,7 +51,8 @@ class ConvParams(C.Structure):
                 ("Kpad", C.c_int32), ("Npad", C.c_int32), ("bias", C.c_void_p), ("rowvec", C.c_void_p),
                 ("res0", C.c_void_p), ("res1", C.c_void_p), ("res_dtype", C.c_int32), ("out", C.c_void_p),
                 ("out_dtype", C.c_int32), ("ldo", C.c_int32), ("epilogue", C.c_int32), ("out_scale", C.c_float), ("ksize_w", C.c_int32),
-                ("act", C.c_int32), ("split_heads", C.c_int32), ("split_dim", C.c_int32), ("split_tokens", C.c_int32)]
+                ("act", C.c_int32), ("split_heads", C.c_int32), ("split_dim", C.c_int32), ("split_tokens", C.c_int32),
+                ("tile_hint", C.c_int32)]
 
 
 class GroupNormParams(C.Structure):
@@ -75,7 +76,7 @@ EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name
            "vv_preprocess", "vv_brushnet_input", "vv_pad_channels", "vv_decode_blend", "vv_blur_compose",
            "vv_avgpool2_f32", "vv_corr_lookup", "vv_raft_ctx_split", "vv_raft_flow_prep", "vv_gru_rh", "vv_gru_update", "vv_add_flow",
            "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32", "vv_u8_is_zero",
-           "vv_raft_prep"]
+           "vv_raft_prep", "vv_split_f32", "vv_pad_channels_f32"]
 
 
 def lib():
@@ -142,7 +143,7 @@ def _need_cuda(*ts):
 # ----------------------------------------------------------------------------------------------------------------
 def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, Wv=None, Hout=None, Wout=None, ksize=1,
               stride=1, pad_t=0, pad_l=0, bias=None, rowvec=None, res0=None, res1=None, out=None, out_dtype=None,
-              epilogue=EPI_NONE, out_scale=1.0, C0=None, C1=0, ksize_w=0, act=ACT_NONE, out_col=0, split_heads=0, split_dim=0, split_tokens=0):
+              epilogue=EPI_NONE, out_scale=1.0, C0=None, C1=0, ksize_w=0, act=ACT_NONE, out_col=0, split_heads=0, split_dim=0, split_tokens=0, tile_hint=0):
     """Launch vv_conv_gemm.  x0/x1: NHWC activations ([F,Hin,Win,C] or any shape with C last); weight: [Npad,Kpad] h16."""
     _need_cuda(x0, x1, weight, bias, rowvec, res0, res1, out)      # out_col: write into columns [out_col, out_col+N) of `out`
     Hv = Hin if Hv is None else Hv
@@ -168,7 +169,7 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
                    res_dtype=res_dt, out=out.data_ptr() + out_col * out.element_size(), out_dtype=dt_of(out),
                    ldo=out.shape[-1],
                    epilogue=epilogue, out_scale=out_scale, ksize_w=ksize_w, act=act, split_heads=split_heads, split_dim=split_dim,
-                   split_tokens=split_tokens)
+                   split_tokens=split_tokens, tile_hint=tile_hint)
     if PROFILE is not None:
         Npad = weight.shape[0]
         # mirror of launch_t() in vv_gemm.hip (label only): LDS-DMA loaders prefer the 128x128 tile (4 blocks per CU) when N allows
@@ -323,6 +324,25 @@ def pad_channels(dtype, x, cpad, scale=1.0):
     out = torch.empty(x.shape[:-1] + (cpad,), dtype=h16(dtype), device=x.device)
     _check(lib().vv_pad_channels(_p(x), C.c_int64(rows), cin, cpad, C.c_float(scale), _p(out), dtype, _stream()), "vv_pad_channels")
     return out
+
+
+def pad_channels_f32(x, cpad, scale=1.0):
+    _need_cuda(x)
+    cin = x.shape[-1]
+    rows = x.numel() // cin
+    out = torch.empty(x.shape[:-1] + (cpad,), dtype=torch.float32, device=x.device)
+    _check(lib().vv_pad_channels_f32(_p(x), C.c_int64(rows), cin, cpad, C.c_float(scale), _p(out), _stream()), "vv_pad_channels_f32")
+    return out
+
+
+def split_f32(dtype, x, lo_scale):
+    """fp32 tensor -> (hi, lo) h16 tensors of the same shape: hi = h16(x), lo = h16((x - hi) * lo_scale)."""
+    _need_cuda(x)
+    assert x.dtype == torch.float32
+    hi = torch.empty(x.shape, dtype=h16(dtype), device=x.device)
+    lo = torch.empty(x.shape, dtype=h16(dtype), device=x.device)
+    _check(lib().vv_split_f32(_p(x), C.c_int64(x.numel()), C.c_float(lo_scale), _p(hi), _p(lo), dtype, _stream()), "vv_split_f32")
+    return hi, lo
 
 
 def decode_blend(dec, w, acc):

@@ -43,11 +43,42 @@ class Ctx:
         return t.to(dtype if dtype is not None else t.dtype).contiguous().to(self.device)
 
 
+# ---- split precision ("precise" layers: the VAE decoder, RunConfig.precise_decoder) --------------------------------------
+# A 16-bit operand keeps 11 (fp16) / 8 (bf16) significant bits; x = hi + lo / LO_SCALE and w = wh + wl / W_SCALE keep ~2x that.
+# x*w ~= hi*wh + (lo*wh) / LO_SCALE + (hi*wl) / W_SCALE: three launches of the SAME MFMA kernel, accumulated in fp32 through
+# the epilogue (out_scale, res0); the dropped lo*wl term is ~2^-22 relative.  The power-of-two scales keep lo / wl out of the
+# fp16 subnormal range.  Cost: 3x the layer's FLOPs -- used only where the emulation (tools/parity_emulate.py) shows the error
+# budget is spent: the VAE decoder (its rounding errors go straight to the pixels).
+LO_SCALE = 256.0
+W_SCALE = 1024.0
+
+
+def _precise_gemm(ctx, launch, x0, x1, w_hi, w_lo, bias, res0, res1, scale, out):
+    """launch(x0, x1, weight, bias, res0, res1, out_scale, out) runs one vv_conv_gemm with the layer's geometry (fp32 `out`)."""
+    def halves(x):
+        if x is None:
+            return None, None
+        if x.dtype == torch.float32:
+            return hip.split_f32(ctx.dt, x, LO_SCALE)
+        return x, None                      # already h16: exactly representable, no lo part
+    h0, l0 = halves(x0)
+    h1, l1 = halves(x1)
+    y = launch(h0, h1, w_hi, bias, res0, res1, scale, out)
+    if l0 is not None or l1 is not None:
+        if x1 is not None and (l0 is None or l1 is None):
+            raise RuntimeError("precise conv: both concat sources must be fp32 (or both h16)")
+        launch(l0, l1, w_hi, None, y, None, scale / LO_SCALE, y)
+    launch(h0, h1, w_lo, None, y, None, scale / W_SCALE, y)
+    return y
+
+
 class Conv:
     """conv2d / linear as implicit GEMM.  `in_pad`: activations carry zero-padded channels (conv_in layers)."""
 
-    def __init__(self, ctx, name, cin, cout, k=3, gain=1.0, cin_pad=None, bias=True, weight=None, bias_t=None, rows=None, geglu=False):
+    def __init__(self, ctx, name, cin, cout, k=3, gain=1.0, cin_pad=None, bias=True, weight=None, bias_t=None, rows=None, geglu=False,
+                 precise=False):
         self.ctx, self.k, self.cout = ctx, k, cout
+        self.precise = precise
         if weight is None:
             weight, b = ctx.src.conv(name, cin, cout, k, gain)
             bias_t = b if bias else None
@@ -58,6 +89,11 @@ class Conv:
             wp, self.K = packing.pack_matrix(w2, ctx.h16, geglu=True), w2.shape[1]
         else:
             wp, self.K = packing.pack_conv(weight, ctx.h16, cin_pad)
+            if precise:
+                wl = (weight.float() - weight.to(ctx.h16).float()) * W_SCALE
+                self.w_lo = ctx.dev(packing.pack_conv(wl, ctx.h16, cin_pad)[0])
+        if precise and geglu:
+            raise RuntimeError("precise GEGLU layers are not supported")
         self.geglu = geglu
         self.w = ctx.dev(wp)
         self.b = ctx.dev(bias_t.float()) if bias_t is not None else None
@@ -72,6 +108,13 @@ class Conv:
             Hout = (Hv + 2 * pad - k) // stride + 1
             Wout = (Wv + 2 * pad - k) // stride + 1
         b = bias_override if bias_override is not None else (self.b if bias else None)
+        if self.precise:
+            if rowvec is not None or out_dtype != torch.float32:
+                raise RuntimeError("precise conv: fp32 output, no rowvec")
+            def launch(a0, a1, w, bb, r0, r1, sc, o):
+                return hip.conv_gemm(self.ctx.dt, a0, w, self.cout, self.K, x1=a1, F=F, Hin=H, Win=W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout, ksize=k,
+                                     stride=stride, pad_t=pad, pad_l=pad, bias=bb, res0=r0, res1=r1, out=o, out_dtype=torch.float32, out_scale=sc)
+            return _precise_gemm(self.ctx, launch, x0, x1, self.w, self.w_lo, b, res0, res1, scale, out), Hout, Wout
         return hip.conv_gemm(self.ctx.dt, x0, self.w, self.cout, self.K, x1=x1, F=F, Hin=H, Win=W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout,
                              ksize=k, stride=stride, pad_t=pad, pad_l=pad, bias=b, rowvec=rowvec, res0=res0, res1=res1, out=out,
                              out_dtype=out_dtype, epilogue=hip.EPI_GEGLU if self.geglu else hip.EPI_NONE, out_scale=scale), Hout, Wout
@@ -80,34 +123,48 @@ class Conv:
 class Linear:
     """y = x W^T + b on a [M, K] matrix (fp32 or h16 input)."""
 
-    def __init__(self, ctx, name=None, cin=None, cout=None, bias=True, gain=1.0, weight=None, bias_t=None, geglu=False):
+    def __init__(self, ctx, name=None, cin=None, cout=None, bias=True, gain=1.0, weight=None, bias_t=None, geglu=False, precise=False):
         self.ctx = ctx
         if weight is None:
             weight, bias_t = ctx.src.linear(name, cin, cout, gain, bias)
         self.cout = weight.shape[0]
         self.geglu = geglu
+        self.precise = precise
         if geglu:
             weight, bias_t = packing.geglu_interleave(weight, bias_t)
         self.K = weight.shape[1]
         self.w = ctx.dev(packing.pack_matrix(weight, ctx.h16, geglu=geglu))
+        if precise:
+            if geglu:
+                raise RuntimeError("precise GEGLU layers are not supported")
+            self.w_lo = ctx.dev(packing.pack_matrix((weight.float() - weight.to(ctx.h16).float()) * W_SCALE, ctx.h16))
         self.b = ctx.dev(bias_t.float()) if bias_t is not None else None
 
     def __call__(self, x, res0=None, res1=None, out_dtype=torch.float32, rows_per_frame=None, out=None, split=None):
         """split = (heads, head_dim, tokens_per_batch): head-major store of a fused QKV projection (hip.conv_gemm split_heads)."""
         M = x.shape[0]
         kw = dict(split_heads=split[0], split_dim=split[1], split_tokens=split[2]) if split else {}
+        if self.precise:
+            if split or out_dtype != torch.float32:
+                raise RuntimeError("precise linear: fp32 row-major output only")
+            def launch(a0, a1, w, bb, r0, r1, sc, o):
+                return hip.conv_gemm(self.ctx.dt, a0, w, self.cout, self.K, F=1, Hin=M, Win=1, bias=bb, res0=r0, res1=r1, out=o,
+                                     out_dtype=torch.float32, out_scale=sc)
+            return _precise_gemm(self.ctx, launch, x, None, self.w, self.w_lo, self.b, res0, res1, 1.0, out)
         return hip.conv_gemm(self.ctx.dt, x, self.w, self.cout, self.K, F=1, Hin=M, Win=1, bias=self.b, res0=res0, res1=res1,
                              out_dtype=out_dtype, out=out, epilogue=hip.EPI_GEGLU if self.geglu else hip.EPI_NONE, **kw)
 
 
 class GroupNorm:
-    def __init__(self, ctx, name, C, groups, eps):
+    def __init__(self, ctx, name, C, groups, eps, precise=False):
         self.ctx, self.groups, self.eps = ctx, groups, eps
+        self.out_dtype = torch.float32 if precise else None      # precise consumers split the fp32 result into hi + lo themselves
         g, b = ctx.src.norm(name, C)
         self.g, self.b = ctx.dev(g), ctx.dev(b)
 
     def __call__(self, x0, F, HW, x1=None, silu=False, pool_frames=False):
-        return hip.groupnorm(self.ctx.dt, x0, self.g, self.b, self.groups, self.eps, x1=x1, F=F, HW=HW, silu=silu, pool_frames=pool_frames)
+        return hip.groupnorm(self.ctx.dt, x0, self.g, self.b, self.groups, self.eps, x1=x1, F=F, HW=HW, silu=silu, pool_frames=pool_frames,
+                             out_dtype=self.out_dtype)
 
 
 class LayerNorm:
@@ -123,14 +180,14 @@ class LayerNorm:
 class ResBlock:
     """ResnetBlock2D: GN+SiLU -> conv3 (+temb) -> GN+SiLU -> conv3 -> + shortcut(x)."""
 
-    def __init__(self, ctx, name, cin, cout, groups, eps, temb_dim=None):
+    def __init__(self, ctx, name, cin, cout, groups, eps, temb_dim=None, precise=False):
         self.ctx, self.cin, self.cout = ctx, cin, cout
-        self.norm1 = GroupNorm(ctx, name + ".norm1", cin, groups, eps)
-        self.conv1 = Conv(ctx, name + ".conv1", cin, cout)
+        self.norm1 = GroupNorm(ctx, name + ".norm1", cin, groups, eps, precise=precise)
+        self.conv1 = Conv(ctx, name + ".conv1", cin, cout, precise=precise)
         self.temb = Linear(ctx, name + ".time_emb_proj", temb_dim, cout) if temb_dim else None
-        self.norm2 = GroupNorm(ctx, name + ".norm2", cout, groups, eps)
-        self.conv2 = Conv(ctx, name + ".conv2", cout, cout)
-        self.short = Conv(ctx, name + ".conv_shortcut", cin, cout, k=1) if cin != cout else None
+        self.norm2 = GroupNorm(ctx, name + ".norm2", cout, groups, eps, precise=precise)
+        self.conv2 = Conv(ctx, name + ".conv2", cout, cout, precise=precise)
+        self.short = Conv(ctx, name + ".conv_shortcut", cin, cout, k=1, precise=precise) if cin != cout else None
 
     def __call__(self, x0, F, H, W, x1=None, silu_temb=None, res1=None, out_dtype=torch.float32):
         HW = H * W
@@ -152,17 +209,26 @@ class ResBlock:
 class SelfAttention:
     """attn with fused QKV projection (no bias) + output projection (bias) + residual."""
 
-    def __init__(self, ctx, name, C, heads, qkv_bias=False):
-        self.ctx, self.C, self.heads = ctx, C, heads
+    def __init__(self, ctx, name, C, heads, qkv_bias=False, precise=False):
+        self.ctx, self.C, self.heads, self.precise = ctx, C, heads, precise
         ws, bs = [], []
         for n in ("to_q", "to_k", "to_v"):
             w, b = ctx.src.linear(f"{name}.{n}", C, C, 1.0, qkv_bias)
             ws.append(w); bs.append(b)
-        self.qkv = Linear(ctx, weight=torch.cat(ws, 0), bias_t=torch.cat(bs, 0) if qkv_bias else None)
-        self.out = Linear(ctx, name + ".to_out.0", C, C)
+        self.qkv = Linear(ctx, weight=torch.cat(ws, 0), bias_t=torch.cat(bs, 0) if qkv_bias else None, precise=precise)
+        self.out = Linear(ctx, name + ".to_out.0", C, C, precise=precise)
 
     def spatial(self, n, res, B, N):
         C, dt, D = self.C, self.ctx.dt, self.C // self.heads
+        if self.precise:
+            # split-precision projections around the (h16-operand) attention core: fp32 [M, 3C] QKV, rounded once to h16
+            qkv32 = self.qkv(n)
+            qkv, _ = hip.split_f32(dt, qkv32, 1.0)
+            del qkv32
+            o = torch.empty((B * N, C), dtype=self.ctx.h16, device=n.device)
+            hip.attention(dt, qkv, qkv, qkv, o, B=B, heads=self.heads, Nq=N, Nkv=N, D=D, q_bs=N * 3 * C, k_bs=N * 3 * C, v_bs=N * 3 * C,
+                          o_bs=N * C, q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C, k_off=C, v_off=2 * C)
+            return self.out(o, res0=res)
         # head-major QKV ([frame][q|k|v][head][token][D]): a head's K/V rows are contiguous 2*D-byte records, so the K/V tile
         # DMA of the attention kernel reads whole cache lines (the [token][3C] layout over-fetched 2.6x at D = 40)
         qkv = self.qkv(n, out_dtype=self.ctx.h16, split=(self.heads, D, N))

@@ -148,7 +148,7 @@ class DiffuEraserHIP:
         self.ctx = Ctx(device, self.run.dtype, self.run.weight_seed, weights=weights)
         text = self.ctx.src.normal("text_states", (1, self.run.unet.text_len, self.run.unet.cross_dim))
         self.denoiser = Denoiser(self.ctx, self.run.unet, text)
-        self.vae = VAE(self.ctx, self.run.vae)
+        self.vae = VAE(self.ctx, self.run.vae, precise_decoder=self.run.precise_decoder)
         self.ac = alphas_cumprod()
         self.taps = imageops.gaussian_taps_21()
         self.vae_batch = 4
