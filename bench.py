@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=50)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--arch", default="full", choices=["full", "small", "tiny"])
+    ap.add_argument("--precise-decoder", action="store_true", help="VAE decoder in split precision (3 MFMA passes per GEMM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -118,7 +119,8 @@ def main():
     from videovanish_amd.config import SMALL_UNET, SMALL_VAE, TINY_UNET, TINY_VAE, RunConfig, UNetConfig, VAEConfig
     from videovanish_amd.pipeline import DiffuEraserHIP, chunk_plan, shard_chunks
     ucfg, vcfg = {"full": (UNetConfig(), VAEConfig()), "small": (SMALL_UNET, SMALL_VAE), "tiny": (TINY_UNET, TINY_VAE)}[args.arch]
-    run = RunConfig(steps=args.denoise_steps, chunk=args.chunk, overlap=args.overlap, seed=42, weight_seed=0, dtype=args.dtype, unet=ucfg, vae=vcfg)
+    run = RunConfig(steps=args.denoise_steps, chunk=args.chunk, overlap=args.overlap, seed=42, weight_seed=0, dtype=args.dtype, unet=ucfg, vae=vcfg,
+                    precise_decoder=args.precise_decoder)
     t_build = time.time()
     model = DiffuEraserHIP(run, f"cuda:{local_rank}")
     torch.cuda.synchronize()

@@ -83,8 +83,9 @@ typedef struct {
     int32_t split_dim;    /* head dim (multiple of 4) */
     int32_t split_tokens; /* rows per batch element: row m = b*split_tokens + token; NEGATIVE: -split_tokens tokens per batch element
                              with token-major rows, m = token*(M/tokens) + b (temporal attention: token = frame, b = pixel) */
-    int32_t tile_hint;    /* 0 = automatic tiling; 1 = 128-row tiles only; 2 = the 256-row tile kernel whenever the shape is eligible
-                             (h16 sources with channel counts % 64 == 0, <= 9 taps, no fused resize, Npad % 320 or % 256 == 0) */
+    int32_t tile_hint;    /* 0 = automatic tiling; 1 = 128-row tiles only; 2 / 3 = the 256-row tile kernel (2-phase / 8-phase form) whenever
+                             the shape is eligible (h16 sources with channel counts % 64 == 0, <= 9 taps, no fused resize,
+                             Npad % 320 or % 256 == 0; 8-phase: Npad % 256 == 0) */
 } vv_conv_params;
 int vv_conv_gemm(const vv_conv_params* host_p, int dtype, void* stream);
 

@@ -57,6 +57,8 @@ CASES = [   # name, F, H, W, cin (or (c0,c1)), cout, k, stride, flags, calls per
     ("vae conv3 512->512 180x320 x4f", 4, 180, 320, 512, 512, 3, 1, "res", 0),
     ("vae conv3 256->256 360x640 x4f", 4, 360, 640, 256, 256, 3, 1, "res", 0),
     ("vae conv3 512->512 90x160 x4f", 4, 90, 160, 512, 512, 3, 1, "res", 0),
+    ("big   K4096 N4096 M8192", 1, 8192, 1, 4096, 4096, 1, 1, "", 0),
+    ("big   K8192 N8192 M8192", 1, 8192, 1, 8192, 8192, 1, 1, "", 0),
 ]
 
 
@@ -90,21 +92,23 @@ def main():
             D = 80 if flags == "split80" else 40
             skw = dict(split_heads=cout // 3 // D, split_dim=D, split_tokens=Ho * Wo)
         outs, times = {}, {}
-        for hint in (1, 2):
+        hints = (1, 2, 3, 4) if (cout % 256 == 0) else (1, 2)
+        for hint in hints:
             out = torch.zeros(M, cout // 2 if geglu else cout, dtype=od, device=dev)
             fn = lambda: hip.conv_gemm(DT, x0, wp, cout, K, x1=x1, F=Fr, Hin=H, Win=W, Hout=Ho, Wout=Wo, ksize=k, stride=stride, pad_t=k // 2,
                                        pad_l=k // 2, bias=bias, res0=res, out=out, epilogue=hip.EPI_GEGLU if geglu else hip.EPI_NONE,
                                        tile_hint=hint, **skw)
             times[hint] = timeit(fn)
             outs[hint] = out.float()
-        diff = (outs[1] - outs[2]).abs().max().item()
+        diff = max((outs[1] - outs[h]).abs().max().item() for h in hints)
         scale = outs[1].abs().max().item()
         fl = 2.0 * M * cout * K
         t1, t2 = times[1], times[2]
         for h in (1, 2):
             tot[h] += times[h] * calls
-        tot["best"] += min(t1, t2) * calls
-        print(f"{name:34s} M={M:7d} 128-row {t1*1e3:7.3f} ms {fl/t1/1e12:7.1f} TF/s | 256-row {t2*1e3:7.3f} ms {fl/t2/1e12:7.1f} TF/s | x{t1/t2:5.2f} | "
+        tot["best"] += min(times.values()) * calls
+        extra = "".join(f" | hint{h} {times[h]*1e3:7.3f} ms {fl/times[h]/1e12:7.1f} TF/s x{t1/times[h]:4.2f}" for h in hints if h > 2)
+        print(f"{name:34s} M={M:7d} 128-row {t1*1e3:7.3f} ms {fl/t1/1e12:7.1f} TF/s | 256-row {t2*1e3:7.3f} ms {fl/t2/1e12:7.1f} TF/s | x{t1/t2:5.2f}{extra} | "
               f"maxdiff {diff:.2e} (|out| {scale:.1f})", flush=True)
     print(f"per denoise step (calls-weighted): 128-row {tot[1]*1e3:.1f} ms, 256-row {tot[2]*1e3:.1f} ms, best-of {tot['best']*1e3:.1f} ms")
 

@@ -440,7 +440,7 @@ int launch_mode(const vv_conv_params& p, int M, hipStream_t st) {
     static const bool no32 = VV_AB_ENV("VV_GEMM_NO_FAST32");
     constexpr int dt = std::is_same<T, BF16>::value ? VV_BF16 : VV_F16;
     if (p.tile_hint != 1) {   // compute-bound shapes: the 256-row tile kernel (vv_gemm256.hip)
-        const int r = vv_gemm256_try(&p, dt, p.tile_hint == 2, (void*)st);
+        const int r = vv_gemm256_try(&p, dt, p.tile_hint >= 2 ? p.tile_hint - 1 : 0, (void*)st);
         if (r > -1000) return r;
     }
 #ifdef VV_AB
