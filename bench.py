@@ -29,6 +29,92 @@ MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/fp16 MFMA peak, /opt/skills/guides/MI
 HBM_PEAK_GBS = 8000.0
 
 
+def synth_frame(t, H, W, seed=1234):
+    """One frame of the SURVEY 8d synthetic clip, seeded by its index (so a rank can build just the frames it needs)."""
+    rng = np.random.default_rng(seed * 1000003 + t)
+    frame = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    mask = np.zeros((H, W), np.uint8)
+    rh, rw = H // 4, W // 4
+    x0 = (W // 8 + 2 * t) % (W - rw)
+    mask[H // 3: H // 3 + rh, x0: x0 + rw] = 255
+    prior = frame.copy()
+    prior[mask > 0] = frame.reshape(-1, 3).mean(0).astype(np.uint8)
+    return frame, mask, prior
+
+
+def strong_scaling(args, model, dist, rank, world, H, W, ucfg, vcfg):
+    """--frames T: ONE fixed T-frame clip (c3: 256 x 720p, c4: 1024 x 1080p) sharded over the ranks, timed host memory ->
+    host memory: upload of this rank's frames, VAE + denoise of its chunks, overlap exchange + blend over RCCL,
+    compose, collection of all uint8 frames in rank 0's host memory."""
+    from videovanish_amd import flops
+    from videovanish_amd.pipeline import chunk_plan, shard_chunks
+    T = args.frames
+    plan = chunk_plan(T, args.chunk, args.overlap)
+    mine = shard_chunks(len(plan), world)[rank]
+    need = set([0])
+    if mine:
+        need |= set(range(plan[mine[0]][0], plan[mine[-1]][1]))
+    frames, masks, prior = [None] * T, [None] * T, [None] * T
+    for t in sorted(need):
+        frames[t], masks[t], prior[t] = synth_frame(t, H, W)
+    dev = model.ctx.device
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as td
+            td.barrier()
+            torch.cuda.synchronize()
+
+    if args.warmup > 0:      # one chunk, untimed: kernels loaded, allocator warm (and one RCCL round trip)
+        fr = torch.from_numpy(np.stack([frames[0]] * args.chunk)).to(dev)
+        mk = torch.from_numpy(np.stack([masks[0]] * args.chunk)).to(dev)
+        model.forward_device(fr, fr, mk, args.chunk, 0, steps=min(2, args.denoise_steps), scheduler="ddim")
+        del fr, mk
+        if world > 1:
+            import torch.distributed as td
+            x = torch.zeros(1, device=dev)
+            td.all_reduce(x)
+    reps = max(1, args.steps)
+    tms = []
+    barrier()
+    t0 = time.time()
+    for _ in range(reps):
+        tm = {}
+        out = model.forward(frames, masks, prior, max_img_size=max(H, W), steps=args.denoise_steps, scheduler="ddim", dist=dist,
+                            gather="rank0", timings=tm)
+        tms.append(tm)
+    barrier()
+    dt = time.time() - t0
+    per_rank = [tms[-1]]
+    backend = "none"
+    if world > 1:
+        import torch.distributed as td
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = float(tt.item())
+        per_rank = [None] * world
+        td.all_gather_object(per_rank, tms[-1])      # a few floats of control-plane data (the frames travelled as tensors)
+        backend = td.get_backend()
+    if rank != 0:
+        return None
+    assert all(o is not None and o.shape == (H, W, 3) and o.dtype == np.uint8 for o in out)
+    fl = flops.per_output_frame(H, W, args.chunk, args.denoise_steps, ucfg, vcfg) * args.chunk * len(plan) * reps
+    ideal = len(plan) / max(len(s) for s in shard_chunks(len(plan), world))
+    return {
+        "metric": "inpainted frames/sec at 720p, 50 denoise steps", "value": round(T * reps / dt, 5), "unit": "frames/s", "n_gpus": world,
+        "steps": reps, "warmup": args.warmup, "ms_per_step": round(dt / reps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{ {720: 'c3', 1080: 'c4', 480: 'c2'}.get(H, 'custom') }: fixed {T}-frame {W}x{H} clip, {args.denoise_steps} DDIM steps, "
+                               f"{args.chunk}/{args.overlap} chunk/overlap = {len(plan)} chunks sharded {[len(s) for s in shard_chunks(len(plan), world)]}, "
+                               f"timed host memory -> host memory (rank 0 collects every frame), {args.arch} width, random-init weights",
+                   "frames": T, "chunks": len(plan), "parallelism": f"chunk-dp{world}", "ideal_speedup_from_chunk_quantisation": round(ideal, 3),
+                   "precise_decoder": bool(args.precise_decoder)},
+        "job_tflops": round(fl / dt / 1e12, 1), "collective_backend": backend,
+        "per_rank_seconds": per_rank,
+    }
+
+
 def synth_clip(T, H, W, seed=1234, t0=0):
     """SURVEY 8d synthetic inputs: uniform random frames, one 25% x 25% rectangle drifting +2 px/frame, prior = frame with
     the masked pixels replaced by the per-frame mean colour (bypasses ProPainter exactly as diffuerase.py:47 allows)."""
@@ -97,6 +183,8 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=50)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--arch", default="full", choices=["full", "small", "tiny"])
+    ap.add_argument("--frames", type=int, default=0, help="strong-scaling mode: one fixed clip of this many frames sharded over the ranks, "
+                    "timed host memory -> host memory (c3: --frames 256; c4: --frames 1024 --height 1080 --width 1920)")
     ap.add_argument("--precise-decoder", action="store_true", help="VAE decoder in split precision (3 MFMA passes per GEMM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -128,6 +216,15 @@ def main():
     H, W = args.height, args.width
     stride = args.chunk - args.overlap
     dev = model.ctx.device
+    if args.frames > 0:
+        res = strong_scaling(args, model, dist, rank, world, H, W, ucfg, vcfg)
+        if rank == 0:
+            res["config"]["model_build_s"] = round(t_build, 1)
+            print(json.dumps(res))
+        if world > 1:
+            import torch.distributed as td
+            td.destroy_process_group()
+        return
 
     def resident_inputs(n_chunks_per_rank):
         """This rank's slice of a (world * n) -chunk synthetic video, uploaded BEFORE the timed region."""

@@ -23,12 +23,15 @@ video_inpainting_sd = None
 propainter = None
 _run_config = None      # set through configure(); None = full SD-1.5 / sd-vae-ft-mse shapes
 _dist = None
+_gather = "all"
 
 
-def configure(run: RunConfig = None, dist=None):
-    """Select architecture / chunking / dtype for subsequently constructed models (tests use small configs)."""
-    global _run_config, _dist, last_ckpt
-    _run_config, _dist, last_ckpt = run, dist, None
+def configure(run: RunConfig = None, dist=None, gather="all"):
+    """Select architecture / chunking / dtype for subsequently constructed models (tests use small configs).
+    dist = (rank, world) with torch.distributed initialised, one process per GPU (torchrun); gather = "all": every rank returns
+    every frame; "rank0": only rank 0 does (the other ranks get None for frames they do not own and should not write a file)."""
+    global _run_config, _dist, _gather, last_ckpt
+    _run_config, _dist, _gather, last_ckpt = run, dist, gather, None
 
 
 def run_infill_on_frames(frames_rgb, mask_frames, mask_dilation_iter=8, ckpt="2-Step",
@@ -50,7 +53,7 @@ def run_infill_on_frames(frames_rgb, mask_frames, mask_dilation_iter=8, ckpt="2-
         ckpt = "2-Step"
         last_ckpt = ckpt
         video_inpainting_sd = DiffuEraser(device, "stable-diffusion-v1-5/stable-diffusion-v1-5", "stabilityai/sd-vae-ft-mse",
-                                          "lixiaowen/diffuEraser", ckpt=ckpt, run=_run_config, dist=_dist)
+                                          "lixiaowen/diffuEraser", ckpt=ckpt, run=_run_config, dist=_dist, gather=_gather)
 
     if propainer_frames is None:                                                # reference :47-57
         if propainter is None:
@@ -69,16 +72,19 @@ def run_infill_on_frames(frames_rgb, mask_frames, mask_dilation_iter=8, ckpt="2-
     # reference :69-112.  The reference returns from inside its loop (:114) so only frame 0 is post-processed; the
     # evident intent (all frames) is the default here, compat_reference_early_return=True reproduces the quirk.
     n_post = 1 if compat_reference_early_return else len(inpainted_frames)
-    Hm, Wm = inpainted_frames[0].shape[:2]
-    out = torch.from_numpy(np.stack(inpainted_frames[:n_post])).to(dev)
+    idx = [i for i in range(n_post) if inpainted_frames[i] is not None]        # multi-GPU "rank0" gather: other ranks hold only their own frames
+    if not idx:
+        return inpainted_frames
+    Hm, Wm = inpainted_frames[idx[0]].shape[:2]
+    out = torch.from_numpy(np.stack([inpainted_frames[i] for i in idx])).to(dev)
     if (Hm, Wm) != (H0, W0):
         out = hip.resize_u8(out.contiguous(), H0, W0, mode="bilinear")          # cv2.resize(f,(W0,H0)), :73
     if keep_unmasked_original:
-        orig = torch.from_numpy(np.stack(frames_rgb[:n_post])).to(dev)
-        out = hip.feather_composite(out.contiguous(), orig.contiguous(), dil_t[:n_post].contiguous(), float(feather_px))   # :77-112
+        orig = torch.from_numpy(np.stack([frames_rgb[i] for i in idx])).to(dev)
+        out = hip.feather_composite(out.contiguous(), orig.contiguous(), dil_t[idx].contiguous(), float(feather_px))   # :77-112
     out = out.cpu().numpy()
-    for i in range(n_post):
-        inpainted_frames[i] = out[i]
+    for j, i in enumerate(idx):
+        inpainted_frames[i] = out[j]
     return inpainted_frames
 
 

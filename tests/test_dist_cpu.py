@@ -42,7 +42,18 @@ def _worker(rank, world, port, T, chunk, overlap, H, W, q):
     td.init_process_group("gloo", rank=rank, world_size=world)
     try:
         acc, lo, hi = _run_rank(rank, world, T, chunk, overlap, H, W)
-        q.put((rank, lo, hi, None if acc is None else acc.numpy()))
+        # collection step of DiffuEraserHIP.forward: u8 frames to rank 0 (send/recv) and to every rank (broadcasts), no pickling
+        plan = PL.chunk_plan(T, chunk, overlap)
+        owner, _ = PL.frame_owner(plan, PL.shard_chunks(len(plan), world))
+        ranges = PL.owned_ranges(owner, world)
+        assert ranges[rank] == (lo, hi)
+        u8 = None if acc is None else (acc.clamp(0, 1) * 255).round().to(torch.uint8)
+        g0 = PL.gather_frames(u8, ranges, rank, world, T, (H, W, 3), torch.uint8, torch.device("cpu"), to="rank0")
+        ga = PL.gather_frames(u8, ranges, rank, world, T, (H, W, 3), torch.uint8, torch.device("cpu"), to="all")
+        assert (g0 is not None) == (rank == 0) and ga.shape == (T, H, W, 3)
+        if rank == 0:
+            assert torch.equal(g0, ga)
+        q.put((rank, lo, hi, None if acc is None else acc.numpy(), ga.numpy()))
         td.barrier()
     finally:
         td.destroy_process_group()
@@ -56,7 +67,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,T", [(2, 60), (2, 104), (3, 60), (2, 33)])
+@pytest.mark.parametrize("world,T", [(2, 60), (2, 104), (3, 60), (2, 33), (3, 40)])
 def test_sharded_blend_equals_single_process(world, T):
     chunk, overlap, H, W = 32, 8, 6, 5
     ref, lo, hi = _run_rank(0, 1, T, chunk, overlap, H, W)
@@ -73,13 +84,16 @@ def test_sharded_blend_equals_single_process(world, T):
         assert p.exitcode == 0
     out = np.zeros_like(ref.numpy())
     seen = np.zeros(T, bool)
-    for rank, lo, hi, acc in res:
+    for rank, lo, hi, acc, ga in res:
         if acc is not None:
             assert not seen[lo:hi].any()
             out[lo:hi] = acc
             seen[lo:hi] = True
     assert seen.all()
     assert np.array_equal(out, ref.numpy())          # bit for bit, independent of world size
+    ref_u8 = (ref.clamp(0, 1) * 255).round().to(torch.uint8).numpy()
+    for rank, lo, hi, acc, ga in res:
+        assert np.array_equal(ga, ref_u8)            # every rank holds all frames after the "all" gather
 
 
 def test_plan_and_ownership_properties():

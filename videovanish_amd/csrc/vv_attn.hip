@@ -29,7 +29,9 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
 
 // DMA = true: K/V tiles go global -> LDS by LDS-DMA into two static buffers (tile k+1 in flight during the MFMAs and the
 // softmax of tile k, ONE barrier per tile, no staging registers); DMA = false: register staged through dynamic LDS.
-template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false>
+// KIND only names the instantiation (0 spatial self-attention, 1 cross-attention to the text tokens; temporal attention has its own
+// tile shape): profilers then report the launches of each use separately (profiles/*_kernel_stats.csv).
+template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params p, const int nqt) {
     constexpr int DK = (D + 31) / 32 * 32, DKC = DK / 8, KS = DK / 32;
     constexpr int DV = (D + 15) / 16 * 16, DVC = DV / 8, NDT = DV / 16;
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
     }
 }
 
-template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false>
+template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0>
 int attn_launch(const vv_attn_params& p, hipStream_t st) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
     constexpr int PK = DK * 2 + 32, PV = DV * 2 + ((DV * 2) % 64 == 0 ? 32 : 0);   // conflict-free ds_read_b128 / ds_read_b64_tr_b16 (bank model: tools/lds_bank_model.py)
@@ -329,7 +331,7 @@ int attn_launch(const vv_attn_params& p, hipStream_t st) {
     const int nqt = (p.Nq + BQ - 1) / BQ;
     const int64_t nblk = (int64_t)p.B * p.heads * nqt;
     if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_attention: grid too large");
-    auto kern = attn_kernel<T, D, QT, KVT, NW, PREFETCH, OCC, DMA>;
+    auto kern = attn_kernel<T, D, QT, KVT, NW, PREFETCH, OCC, DMA, KIND>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -366,7 +368,9 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
             if (var == 14) return attn_launch<T, D, 2, 64, 4, true, 3>(p, st);          // register staged, capped at 168 VGPRs (3 waves/SIMD)
 #endif
             // default for d <= 64: K/V by LDS-DMA, double buffered, 3 waves/SIMD (d = 80 would spill: stays register staged)
-            if (D <= 64) return attn_launch<T, D, 2, 64, 4, false, 3, true>(p, st);
+            const bool cross = p.Nkv < 128 && p.Nq != p.Nkv;
+            if (D <= 64) return cross ? attn_launch<T, D, 2, 64, 4, false, 3, true, 1>(p, st) : attn_launch<T, D, 2, 64, 4, false, 3, true, 0>(p, st);
+            return cross ? attn_launch<T, D, 2, 64, 4, true, 1, false, 1>(p, st) : attn_launch<T, D, 2, 64, 4, true, 1, false, 0>(p, st);
         }
         return attn_launch<T, D, 2, 64, 4, true>(p, st);
     }

@@ -9,13 +9,14 @@ from .pipeline import DiffuEraserHIP
 
 class DiffuEraser:
     def __init__(self, device, base_model_path="stable-diffusion-v1-5/stable-diffusion-v1-5", vae_path="stabilityai/sd-vae-ft-mse",
-                 diffueraser_path="lixiaowen/diffuEraser", ckpt="2-Step", run: RunConfig = None, dist=None, weights=None):
+                 diffueraser_path="lixiaowen/diffuEraser", ckpt="2-Step", run: RunConfig = None, dist=None, weights=None, gather="all"):
         # model ids are accepted for signature compatibility; weights are seeded random-init of the same
         # architecture (no network on the build/bench machines; real-weight loading is row n2 of SURVEY 8f)
         self.ids = (base_model_path, vae_path, diffueraser_path)
         self.ckpt = ckpt
         self.run = run or RunConfig()
         self.dist = dist
+        self.gather = gather      # multi-GPU: "all" = every rank returns all frames, "rank0" = only rank 0 does (pipeline.gather_frames)
         self.model = DiffuEraserHIP(self.run, normalize_device(device), weights=weights)
 
     def forward(self, frames, masks, priori, max_img_size=960, mask_dilation_iter=0, guidance_scale=None, progress=None,
@@ -36,4 +37,4 @@ class DiffuEraser:
         if progress is not None:
             cb = lambda i, n: progress(50 + int(40 * i / max(n, 1)), "running DiffuEraser")
         return self.model.forward(frames, masks2d, priori, max_img_size=max_img_size, steps=num_inference_steps, scheduler=scheduler,
-                                  progress=cb, dist=self.dist)
+                                  progress=cb, dist=self.dist, gather=self.gather)

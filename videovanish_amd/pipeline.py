@@ -140,6 +140,45 @@ def exchange_and_blend(plan, wts, owner, chunk_rank, rank, world, pending, hw, d
     return accT, (lo, hi)
 
 
+def owned_ranges(owner, world):
+    """[(lo, hi)] per rank from the frame-owner array (ownership is contiguous and monotone; (0, 0) = owns nothing)."""
+    out = []
+    for r in range(world):
+        idx = np.nonzero(owner == r)[0]
+        out.append((int(idx[0]), int(idx[-1]) + 1) if len(idx) else (0, 0))
+    return out
+
+
+def gather_frames(own, ranges, rank, world, T, tail_shape, dtype, device, to="all"):
+    """Assemble the T output frames from the per-rank owned slices WITHOUT pickling or host staging.
+    own: [hi-lo, *tail_shape] tensor of the frames this rank owns (device tensor over RCCL, CPU tensor over gloo) or None;
+    ranges: owned_ranges().  to = "rank0": point-to-point sends to rank 0 (returns the full [T, ...] tensor on rank 0, None
+    elsewhere); "all": one broadcast per owning rank into a full tensor on every rank."""
+    if world == 1:
+        return own
+    import torch.distributed as td
+    if to not in ("all", "rank0"):
+        raise ValueError(f"gather_frames: to={to!r}")
+    lo, hi = ranges[rank]
+    if to == "rank0" and rank != 0:
+        if hi > lo:
+            td.send(own.contiguous(), 0)
+        return None
+    full = torch.empty((T,) + tuple(tail_shape), dtype=dtype, device=device)
+    if hi > lo:
+        full[lo:hi] = own
+    for r in range(world):
+        rlo, rhi = ranges[r]
+        if rhi <= rlo:
+            continue
+        if to == "rank0":
+            if r != 0:
+                td.recv(full[rlo:rhi], r)
+        else:
+            td.broadcast(full[rlo:rhi], src=r)
+    return full
+
+
 # ---- the model ---------------------------------------------------------------------------------------------------
 class DiffuEraserHIP:
     def __init__(self, run: RunConfig = None, device="cuda:0", weights=None):
@@ -223,10 +262,15 @@ class DiffuEraserHIP:
 
     # -- whole video ----------------------------------------------------------------------------------------------
     def forward(self, frames, masks2d, priori, max_img_size=960, steps=None, scheduler="ddim", progress=None, return_float=False,
-                dist=None):
+                dist=None, gather="all", timings=None):
         """frames / priori: list of (H0,W0,3) uint8; masks2d: list of (H0,W0) uint8 (non-zero = masked).
         Returns list of uint8 RGB frames at the inference size (like the third-party DiffuEraser.forward).
-        dist: None, or (rank, world) with torch.distributed initialised (one process per GPU)."""
+        dist: None, or (rank, world) with torch.distributed initialised (one process per GPU).
+        gather (multi-GPU): "all" = every rank returns all T frames (one RCCL broadcast per owning rank); "rank0" = rank 0 returns all
+        frames, the other ranks a list holding only the frames they own (None elsewhere); "none" = no collection at all.
+        timings: optional dict filled with upload / compute+exchange / gather+download seconds (host clock, device synchronised)."""
+        import time
+        t_0 = time.time()
         run, dev = self.run, self.ctx.device
         T = len(frames)
         H0, W0 = frames[0].shape[:2]
@@ -246,7 +290,16 @@ class DiffuEraserHIP:
             fr, pr, mk = prep(frames, base, end), prep(priori, base, end), prep(masks2d, base, end, mask=True)
         else:
             base, fr, pr, mk = 0, None, None, None
-        res = self.forward_device(fr, pr, mk, T, base, steps=steps, scheduler=scheduler, progress=progress, dist=dist, return_float=return_float)
+        if timings is not None:
+            torch.cuda.synchronize()
+            timings["upload_s"] = time.time() - t_0
+            t_0 = time.time()
+        res = self.forward_device(fr, pr, mk, T, base, steps=steps, scheduler=scheduler, progress=progress, dist=dist, return_float=return_float,
+                                  timings=timings)
+        if timings is not None:
+            torch.cuda.synchronize()
+            timings["compute_s"] = time.time() - t_0
+            t_0 = time.time()
         if return_float:
             # per-rank return: the blended fp32 pixels of the frames THIS rank owns (no gather); a rank that owns no
             # frame (world > number of chunks) gets an empty array and (0, 0)
@@ -255,21 +308,21 @@ class DiffuEraserHIP:
                 return np.zeros((0, H, W, 3), np.float32), (0, 0)
             return out.cpu().numpy(), (lo, hi)
         out, (lo, hi) = res
-        out_frames = {}
+        if world > 1 and gather in ("all", "rank0"):
+            owner, _ = frame_owner(plan, shard_chunks(len(plan), world))
+            full = gather_frames(out, owned_ranges(owner, world), rank, world, T, (H, W, 3), torch.uint8, dev, to=gather)
+            if full is not None:
+                out, (lo, hi) = full, (0, T)
+        result = [None] * T
         if out is not None:
             o = out.cpu().numpy()
             for j in range(hi - lo):
-                out_frames[lo + j] = o[j]
-        if world > 1:
-            import torch.distributed as td
-            gathered = [None] * world
-            td.all_gather_object(gathered, out_frames)
-            out_frames = {}
-            for g in gathered:
-                out_frames.update(g)
-        return [out_frames[i] for i in range(T)]
+                result[lo + j] = o[j]
+        if timings is not None:
+            timings["gather_download_s"] = time.time() - t_0
+        return result
 
-    def forward_device(self, fr, pr, mk, T, base, steps=None, scheduler="ddim", progress=None, dist=None, return_float=False):
+    def forward_device(self, fr, pr, mk, T, base, steps=None, scheduler="ddim", progress=None, dist=None, return_float=False, timings=None):
         """Device-resident core.  fr/pr: u8 [n,H,W,3], mk: u8 [n,H,W] hold frames [base, base+n) of a T-frame video at
         the inference size: exactly the frames covered by this rank's chunks.  Returns (u8 [hi-lo,H,W,3] device tensor of
         the frames this rank OWNS, (lo, hi)); with return_float the blended fp32 pixels instead of the composed u8."""
@@ -297,7 +350,14 @@ class DiffuEraserHIP:
                              for i in range(nst - 1)]
             pending[ci] = self.denoise_chunk(fr[s - base:e - base], pr[s - base:e - base], mk[s - base:e - base], noise, steps=steps,
                                              scheduler=scheduler, tcd_noise=tcd_noise, progress=cb)
+        if timings is not None:
+            import time
+            torch.cuda.synchronize()
+            t_x = time.time()
         accT, (lo, hi) = exchange_and_blend(plan, wts, owner, chunk_rank, rank, world, pending, (H, W), dev)
+        if timings is not None:
+            torch.cuda.synchronize()
+            timings["exchange_blend_s"] = time.time() - t_x
         if accT is None:
             return None, (0, 0)
         if return_float:
