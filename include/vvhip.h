@@ -207,6 +207,8 @@ int vv_brushnet_input(const float* lat, const float* cond, const uint8_t* mask2d
                       void* out16, int dtype, void* stream);
 /* fp32 NHWC [..][cin] -> h16 [..][cpad] (zero padded channels), used for conv_in of latents */
 int vv_pad_channels(const float* x, int64_t rows, int cin, int cpad, float scale, void* out, int dtype, void* stream);
+/* reference temporal windowing: out[f][..] = value[f][..] / count[f], count = windows that covered frame f */
+int vv_window_average(const float* value, const float* count, int frames, int64_t per_frame, float* out, void* stream);
 /* same, fp32 output (input of a split-precision layer) */
 int vv_pad_channels_f32(const float* x, int64_t rows, int cin, int cpad, float scale, float* out, void* stream);
 /* split precision operands for the 3-pass "precise" convolutions (VAE decoder): hi = h16(x), lo = h16((x - hi) * lo_scale);

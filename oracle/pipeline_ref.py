@@ -146,3 +146,84 @@ def run_infill_on_frames(frames_rgb, mask_frames, mask_dilation_iter=8, propaine
         if compat_reference_early_return:                                       # :114 (return inside the loop)
             break
     return out
+
+
+# ---- reference temporal windowing ([UNVERIFIED-3P]: restated from the public DiffuEraser pipeline) -------
+def reference_contexts(n, nframes=22, overlap=4):
+    """get_frames_context_swap restated: (contexts, contexts_swap) as [a, b) ranges; even steps use the first list, odd the second."""
+    npc = min(nframes, n)
+    if n <= npc:
+        return [(0, n)], [(0, n)]
+    ctx, swap = [], []
+    k = 0
+    for k in range(0, n - npc, npc - overlap):
+        ctx.append((k, k + npc))
+    if k + npc < n:
+        ctx.append((n - npc, n))
+    swap.append((0, npc))
+    for k in range(npc // 2, n - npc, npc - overlap):
+        swap.append((k, k + npc))
+    if k + npc < n:
+        swap.append((n - npc, n))
+    return ctx, swap
+
+
+def _denoise_windows(P, lat, cond, m_lat, steps, ucfg, nframes, overlap):
+    ac = M.alphas_cumprod()
+    text = M.text_states(P, ucfg)
+    n = lat.shape[0]
+    ctxs, swap = reference_contexts(n, nframes, overlap)
+    for i, t in enumerate(M.ddim_timesteps(steps)):
+        value, count = torch.zeros_like(lat), torch.zeros(n, 1, 1, 1)
+        for (a, b) in (ctxs if i % 2 == 0 else swap):
+            brush = M.brushnet_forward(P, torch.cat([lat[a:b], cond[a:b], m_lat[a:b]], 1), t, text, ucfg)
+            value[a:b] += M.unet_forward(P, lat[a:b], t, text, ucfg, brush)
+            count[a:b] += 1
+        lat = M.ddim_step(lat, value / count, t, steps, ac)
+    return lat
+
+
+def diffueraser_forward_reference_windows(frames, masks2d, priori, max_img_size=960, steps=50, seed=42, weight_seed=0, ucfg=None, vcfg=None,
+                                          nframes=22, overlap=4, P=None, return_float=False):
+    """DiffuEraser.forward with the third-party pipeline's own temporal scheme: windows of `nframes` shifted by half a window on
+    odd steps, noise prediction averaged over the covering windows, key-frame pre-inference when T > 2 * nframes."""
+    from videovanish_amd.config import UNetConfig, VAEConfig
+    ucfg = ucfg or UNetConfig()
+    vcfg = vcfg or VAEConfig()
+    P = P or M.Params(weight_seed)
+    T = len(frames)
+    H0, W0 = frames[0].shape[:2]
+    H, W = model_size(H0, W0, max_img_size)
+    fr = [I.resize_bilinear_u8(f, W, H) for f in frames]
+    pr = [I.resize_bilinear_u8(f, W, H) for f in priori]
+    mk = [I.resize_nearest_u8(np.where(m > 0, 255, 0).astype(np.uint8), W, H) for m in masks2d]
+    fr_orig, mk_orig = list(fr), list(mk)
+    f = 2 ** (len(vcfg.block_out) - 1)
+    h, w = H // f, W // f
+    ac = M.alphas_cumprod()
+    t0 = M.ddim_timesteps(steps)[0]
+    with torch.no_grad():
+        mt = lambda lst: torch.from_numpy(np.stack(lst) > 0).float()[:, None]
+        prior_lat = M.vae_encode(P, to_model_tensor(pr), vcfg)
+        cond_lat = M.vae_encode(P, to_model_tensor(fr) * (1.0 - mt(mk)), vcfg)
+        noise_pre = chunk_noise(seed, 0, (nframes, 4, h, w))
+        if T > 2 * nframes:
+            step = T / nframes
+            idx = [int(i * step) for i in range(nframes)][:nframes]
+            m_lat = torch.nn.functional.interpolate(mt([mk[i] for i in idx]), size=(h, w), mode="nearest")
+            lat_pre = M.add_noise(prior_lat[idx], noise_pre, t0, ac)
+            out_pre = _denoise_windows(P, lat_pre, cond_lat[idx], m_lat, steps, ucfg, nframes, overlap)
+            pix = (M.vae_decode(P, out_pre, vcfg) / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
+            for j, i in enumerate(idx):
+                key = I.blur_compose(pix[j], fr[i], np.full((H, W), 255, np.uint8))
+                fr[i], mk[i] = key, np.zeros((H, W), np.uint8)
+                prior_lat[i] = out_pre[j]
+                cond_lat[i] = M.vae_encode(P, to_model_tensor([key]), vcfg)[0]
+        reps = (T + nframes - 1) // nframes
+        noise = noise_pre.repeat(reps, 1, 1, 1)[:T]
+        m_lat = torch.nn.functional.interpolate(mt(mk), size=(h, w), mode="nearest")
+        lat = _denoise_windows(P, M.add_noise(prior_lat, noise, t0, ac), cond_lat, m_lat, steps, ucfg, nframes, overlap)
+        pix = (M.vae_decode(P, lat, vcfg) / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).contiguous().numpy()
+    if return_float:
+        return pix
+    return [I.blur_compose(pix[t], fr_orig[t], mk_orig[t]) for t in range(T)]

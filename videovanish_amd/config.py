@@ -53,5 +53,9 @@ class RunConfig:
     # dtype="bf16", precise_decoder=False is ~5 % faster at 1e-2.
     dtype: str = "fp16"           # MFMA operand type: "bf16" | "fp16"
     precise_decoder: bool = True  # VAE decoder GEMMs as 3 split-precision passes (hi/lo operands): +3 % time at 50 steps, halves the pixel error
+    # temporal scheme: "chunks" = independent `chunk`-frame clips + overlap cross-fade (build-defined, shards over GPUs);
+    # "reference" = the third-party pipeline's own scheme (22-frame windows shifted on odd steps, value/count averaging, key-frame
+    # pre-inference) -- single GPU only
+    windowing: str = "chunks"
     unet: UNetConfig = field(default_factory=UNetConfig)
     vae: VAEConfig = field(default_factory=VAEConfig)

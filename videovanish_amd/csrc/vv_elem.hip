@@ -155,6 +155,19 @@ extern "C" int vv_brushnet_input(const float* lat, const float* cond, const uint
     return VV_OK;
 }
 
+// reference windowing (third-party DiffuEraser pipeline: per step noise_pred = value / count over the overlapping temporal windows)
+__global__ void window_average_kernel(const float* value, const float* count, int64_t per_frame, int64_t n, float* out) {
+    for (int64_t i = blockIdx.x * (int64_t)EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) out[i] = value[i] / count[i / per_frame];
+}
+
+extern "C" int vv_window_average(const float* value, const float* count, int frames, int64_t per_frame, float* out, void* stream) {
+    if (!value || !count || !out || frames <= 0 || per_frame <= 0) VV_FAIL(VV_E_ARG, "vv_window_average: bad args");
+    const int64_t n = (int64_t)frames * per_frame;
+    hipLaunchKernelGGL(window_average_kernel, grid_for(n), dim3(EB), 0, (hipStream_t)stream, value, count, per_frame, n, out);
+    VV_CHECK_LAUNCH("vv_window_average");
+    return VV_OK;
+}
+
 __global__ void pad_channels_f32_kernel(const float* x, int64_t rows, int cin, int cpad, float scale, float* out) {
     const int64_t n = rows * cpad;
     for (int64_t i = blockIdx.x * (int64_t)EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) {

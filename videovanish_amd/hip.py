@@ -76,7 +76,7 @@ EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name
            "vv_preprocess", "vv_brushnet_input", "vv_pad_channels", "vv_decode_blend", "vv_blur_compose",
            "vv_avgpool2_f32", "vv_corr_lookup", "vv_raft_ctx_split", "vv_raft_flow_prep", "vv_gru_rh", "vv_gru_update", "vv_add_flow",
            "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32", "vv_u8_is_zero",
-           "vv_raft_prep", "vv_split_f32", "vv_pad_channels_f32"]
+           "vv_raft_prep", "vv_split_f32", "vv_pad_channels_f32", "vv_window_average"]
 
 
 def lib():
@@ -323,6 +323,15 @@ def pad_channels(dtype, x, cpad, scale=1.0):
     rows = x.numel() // cin
     out = torch.empty(x.shape[:-1] + (cpad,), dtype=h16(dtype), device=x.device)
     _check(lib().vv_pad_channels(_p(x), C.c_int64(rows), cin, cpad, C.c_float(scale), _p(out), dtype, _stream()), "vv_pad_channels")
+    return out
+
+
+def window_average(value, count):
+    """value fp32 [T, ...], count fp32 [T] -> value / count per frame."""
+    _need_cuda(value, count)
+    T = value.shape[0]
+    out = torch.empty_like(value)
+    _check(lib().vv_window_average(_p(value), _p(count), T, C.c_int64(value.numel() // T), _p(out), _stream()), "vv_window_average")
     return out
 
 

@@ -140,6 +140,35 @@ def exchange_and_blend(plan, wts, owner, chunk_rank, rank, world, pending, hw, d
     return accT, (lo, hi)
 
 
+def reference_contexts(n, nframes=22, overlap=4):
+    """Temporal windows of the third-party DiffuEraser pipeline ([UNVERIFIED-3P]: restated from the public
+    `get_frames_context_swap`): (contexts, contexts_swap) as lists of [a, b) frame ranges.  Even denoise steps use `contexts`
+    (windows of `nframes` every nframes - overlap frames + a last window flush with the end), odd steps `contexts_swap` (the same
+    grid shifted by half a window, plus the first and the last window), and the per-step noise prediction is averaged over the
+    windows that cover a frame."""
+    npc = min(nframes, n)
+    if n <= npc:
+        return [(0, n)], [(0, n)]
+    ctx, swap = [], []
+    k = 0
+    for k in range(0, n - npc, npc - overlap):
+        ctx.append((k, k + npc))
+    if k + npc < n:
+        ctx.append((n - npc, n))
+    swap.append((0, npc))
+    for k in range(npc // 2, n - npc, npc - overlap):      # (an empty range leaves k at its last value above, as upstream does)
+        swap.append((k, k + npc))
+    if k + npc < n:
+        swap.append((n - npc, n))
+    return ctx, swap
+
+
+def key_frame_indices(T, nframes=22):
+    """Uniformly sampled key frames of the reference's pre-inference pass (run when T > 2 * nframes)."""
+    step = T / nframes
+    return [int(i * step) for i in range(nframes)][:nframes]
+
+
 def owned_ranges(owner, world):
     """[(lo, hi)] per rank from the frame-owner array (ownership is contiguous and monotone; (0, 0) = owns nothing)."""
     out = []
@@ -271,6 +300,12 @@ class DiffuEraserHIP:
         timings: optional dict filled with upload / compute+exchange / gather+download seconds (host clock, device synchronised)."""
         import time
         t_0 = time.time()
+        if self.run.windowing == "reference":
+            if dist is not None and dist[1] > 1:
+                raise RuntimeError('windowing="reference" couples every frame at every step and does not shard: run it on one GPU')
+            if scheduler != "ddim":
+                raise RuntimeError('windowing="reference" is implemented for the DDIM scheduler')
+            return self.forward_reference_windows(frames, masks2d, priori, max_img_size=max_img_size, steps=steps, return_float=return_float)
         run, dev = self.run, self.ctx.device
         T = len(frames)
         H0, W0 = frames[0].shape[:2]
@@ -321,6 +356,82 @@ class DiffuEraserHIP:
         if timings is not None:
             timings["gather_download_s"] = time.time() - t_0
         return result
+
+    # -- reference temporal windowing: windows of 22 frames shifted by half a window on odd steps, value/count
+    #    averaging of the noise prediction, key-frame pre-inference for long clips.  Single GPU ("replicas only": the windows couple
+    #    all frames at every step, so this mode does not shard); the default chunked mode is the multi-GPU path.
+    def _denoise_windows(self, lat, cond, mask_u8, ts, steps, H, W, nframes, overlap):
+        n, h, w, _ = lat.shape
+        ctxs, swap = reference_contexts(n, nframes, overlap)
+        for i, t in enumerate(ts):
+            value = torch.zeros_like(lat)
+            count = np.zeros(n, np.float32)
+            for (a, b) in (ctxs if i % 2 == 0 else swap):
+                eps = self.denoiser(lat[a:b].contiguous(), cond[a:b].contiguous(), mask_u8[a:b].contiguous(), t, b - a, h, w, H, W)
+                hip.add_inplace(self.ctx.dt, value[a:b], eps.contiguous())
+                count[a:b] += 1.0
+            if (count == 0).any():
+                raise RuntimeError("reference windowing left a frame uncovered")
+            eps_all = hip.window_average(value, torch.from_numpy(count).to(lat.device))
+            a_t = float(self.ac[t])
+            prev = t - 1000 // steps
+            a_p = float(self.ac[prev]) if prev >= 0 else float(self.ac[0])
+            lat = hip.sched_step(lat, eps_all, None, a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5)
+        return lat
+
+    def _to_pix01(self, dec):
+        F, H, W, _ = dec.shape
+        acc = torch.zeros((F, H, W, 3), dtype=torch.float32, device=dec.device)
+        return hip.decode_blend(dec.contiguous(), torch.ones(F, dtype=torch.float32, device=dec.device), acc)
+
+    def forward_reference_windows(self, frames, masks2d, priori, max_img_size=960, steps=None, nframes=22, overlap=4, return_float=False):
+        """The third-party pipeline's own temporal scheme instead of independent chunks (DDIM; one GPU).  Same I/O as forward()."""
+        run, dev = self.run, self.ctx.device
+        steps = steps or run.steps
+        T = len(frames)
+        H0, W0 = frames[0].shape[:2]
+        H, W = model_size(H0, W0, max_img_size)
+        f = self.vae.factor
+        h, w = H // f, W // f
+
+        def prep(lst, mask=False):
+            t = torch.from_numpy(np.stack(lst)).to(dev)
+            if (H, W) != (H0, W0):
+                t = hip.resize_u8(t.contiguous(), H, W, mode="nearest" if mask else "bilinear")
+            return t.contiguous()
+
+        fr, pr, mk = prep(frames), prep(priori), prep(masks2d, mask=True)
+        mk_orig, fr_orig = mk.clone(), fr.clone()
+        ts = ddim_timesteps(steps)
+        a0 = float(self.ac[ts[0]])
+
+        def enc(img_u8, mask_u8, masked):
+            img8, m8 = hip.preprocess(self.ctx.dt, img_u8.contiguous(), mask_u8.contiguous() if masked else None, want_img=not masked, want_masked=masked)
+            return self.encode(m8 if masked else img8, img_u8.shape[0], H, W)
+
+        prior_lat = enc(pr, None, False)
+        cond_lat = enc(fr, mk, True)
+        noise_pre = chunk_noise(run.seed, 0, (nframes, 4, h, w)).permute(0, 2, 3, 1).contiguous().to(dev)
+        if T > 2 * nframes:                                   # key-frame pre-inference: 22 uniformly sampled frames in ONE window
+            idx = torch.tensor(key_frame_indices(T, nframes), device=dev)
+            lat_pre = hip.axpby(prior_lat[idx].contiguous(), noise_pre, a0 ** 0.5, (1 - a0) ** 0.5)
+            out_pre = self._denoise_windows(lat_pre, cond_lat[idx].contiguous(), mk[idx].contiguous(), ts, steps, H, W, nframes, overlap)
+            pix = self._to_pix01(self.decode(out_pre, nframes, h, w))
+            ones = torch.full((nframes, H, W), 255, dtype=torch.uint8, device=dev)
+            key_u8 = hip.blur_compose(pix, fr[idx].contiguous(), ones, self.taps)     # all-ones mask: the quantised generated frame
+            fr[idx] = key_u8                                  # key frames become known content: image replaced, mask cleared,
+            mk[idx] = 0                                       # prior latents = their denoised latents
+            prior_lat[idx] = out_pre
+            cond_lat[idx] = enc(key_u8, None, False)
+        reps = (T + nframes - 1) // nframes
+        noise = noise_pre.repeat(reps, 1, 1, 1)[:T].contiguous()
+        lat = hip.axpby(prior_lat.contiguous(), noise, a0 ** 0.5, (1 - a0) ** 0.5)
+        lat = self._denoise_windows(lat, cond_lat.contiguous(), mk, ts, steps, H, W, nframes, overlap)
+        pix = self._to_pix01(self.decode(lat, T, h, w))
+        if return_float:
+            return pix.cpu().numpy()
+        out = hip.blur_compose(pix, fr_orig, mk_orig, self.taps)
+        return list(out.cpu().numpy())
 
     def forward_device(self, fr, pr, mk, T, base, steps=None, scheduler="ddim", progress=None, dist=None, return_float=False, timings=None):
         """Device-resident core.  fr/pr: u8 [n,H,W,3], mk: u8 [n,H,W] hold frames [base, base+n) of a T-frame video at
