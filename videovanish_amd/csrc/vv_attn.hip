@@ -322,6 +322,300 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Software-pipelined form for small head dims (d <= 64): per KV tile the wave issues, in ONE barrier interval,
+//     S_next = K(it+1) Q^T   (16 MFMAs)   |   O^T += V(it-1)^T P(it-1)^T   (12 MFMAs)   |   softmax of S(it) on the VALU
+// -- none of the 28 MFMAs depends on the softmax running beside them, so the matrix pipe could work under the (issue-bound) exponent
+// math of the SAME wave instead of waiting for it (cdna_hip_programming.md T15).
+// LAB VARIANT (VV_AB builds, VV_ATTN_VARIANT=20..22), NOT the product path: measured 403 TFLOP/s against 585 for the default kernel
+// on the d = 40 / N = 14400 shape (profiles/r2_attn_pipe_ab.txt) -- hipcc keeps the MFMAs of a step clustered ahead of the softmax
+// (sched_group_barrier pipelines are not honoured across the LDS-read dependencies) and the second S tile + deferred P push the
+// kernel to 256 VGPRs with spills, i.e. 2 waves per SIMD without the intra-wave overlap that was to pay for the lost wave.  K tiles are DMA'd two tiles ahead and V tiles
+// one ahead into 3-slot rings; the LDS-DMA is issued from inline asm (hipcc then orders no ds_read behind it) and every wait is
+// the hand-placed vmcnt(0) + s_barrier at the end of a step.  2 waves per SIMD (the second S tile and the deferred P cost 48 VGPRs).
+__device__ __forceinline__ void glds16_asm(const void* gptr, void* lds_wave_base) {
+    typedef void __attribute__((address_space(3))) * lp_t;
+    const unsigned dst = (unsigned)(size_t)(lp_t)lds_wave_base;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gptr), "s"(dst) : "memory");
+}
+
+template <typename T, int D, int OCC, int KIND, int HINT = 0>
+__global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(const vv_attn_params p, const int nqt) {
+    constexpr int QT = 2, KVT = 64, NW = 4, NT = 256;
+    constexpr int DK = (D + 31) / 32 * 32, KS = DK / 32;
+    constexpr int DV = (D + 15) / 16 * 16, NDT = DV / 16;
+    constexpr int KT = KVT / 16, US = KVT / 32;
+    constexpr int PK = DK * 2 + 32, PV = DV * 2 + ((DV * 2) % 64 == 0 ? 32 : 0);
+    constexpr int BQ = NW * QT * 16;
+    constexpr bool ONES = DV > D;
+    constexpr int NSK = KVT * PK / 16, NSV = KVT * PV / 16;
+    constexpr int KP = (NSK + NT - 1) / NT, VP = (NSV + NT - 1) / NT;
+    constexpr int KBYTES = KVT * PK, VBYTES = KVT * PV;
+    constexpr int VALU_PER_MFMA = HINT;
+    static_assert(NSK % 64 == 0 && NSV % 64 == 0, "K/V tile must be whole 1 KB wave blocks");
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[3 * KBYTES + 3 * VBYTES];
+    unsigned char* const rK = ring;
+    unsigned char* const rV = ring + 3 * KBYTES;
+
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    int qt, h, b;
+    {
+        const int nbh = p.B * p.heads;
+        const int full = (nbh / 8) * 8;
+        const int bid = blockIdx.x;
+        int bh;
+        if (bid < full * nqt) { const int xcd = bid & 7, idx = bid >> 3; bh = (idx / nqt) * 8 + xcd; qt = idx % nqt; }
+        else { const int r = bid - full * nqt; bh = full + r / nqt; qt = r % nqt; }
+        h = bh % p.heads; b = bh / p.heads;
+    }
+    const unsigned short* Q = (const unsigned short*)p.q + (int64_t)b * p.q_bs + (int64_t)h * (p.q_hs ? p.q_hs : D);
+    const unsigned short* Kp = (const unsigned short*)p.k + (int64_t)b * p.k_bs + (int64_t)h * (p.k_hs ? p.k_hs : D);
+    const unsigned short* Vp = (const unsigned short*)p.v + (int64_t)b * p.v_bs + (int64_t)h * (p.v_hs ? p.v_hs : D);
+    unsigned short* O = (unsigned short*)p.o + (int64_t)b * p.o_bs + (int64_t)h * D;
+
+    const int q0 = qt * BQ + wave * QT * 16;
+    uint4 qf[QT][KS];
+#pragma unroll
+    for (int j = 0; j < QT; ++j)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int q = q0 + j * 16 + li, d0 = s * 32 + lg * 8;
+            qf[j][s] = (q < p.Nq && d0 < D) ? *(const uint4*)(Q + (int64_t)q * p.q_rs + d0) : make_uint4(0, 0, 0, 0);
+        }
+    f32x4 oacc[NDT][QT];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int j = 0; j < QT; ++j) oacc[d][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int j = 0; j < QT; ++j) { mrun[j] = -1e30f; lrun[j] = 0.f; }
+    const float c = p.scale * 1.4426950408889634f;
+    const int ntiles = (p.Nkv + KVT - 1) / KVT;
+    const bool ragged = (p.Nkv % KVT) != 0;
+
+    // ---- DMA slots (as in attn_kernel): pad / ONES slots are written once into all three ring slots, their lanes masked off
+    unsigned koff[KP], voff[VP];
+    bool kdata[KP], vdata[VP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        const int sidx = i * NT + t, row = sidx / (PK / 16), ch = sidx - row * (PK / 16);
+        kdata[i] = ch * 8 < D && sidx < NSK;
+        koff[i] = (unsigned)(row * (int)p.k_rs + ch * 8) * 2u;
+        if (sidx < NSK) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) *(uint4*)(rK + r * KBYTES + sidx * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+        const int sidx = i * NT + t, row = sidx / (PV / 16), ch = sidx - row * (PV / 16);
+        vdata[i] = ch * 8 < D && sidx < NSV;
+        voff[i] = (unsigned)(row * (int)p.v_rs + ch * 8) * 2u;
+        if (sidx < NSV) {
+            const uint4 fill = make_uint4((ONES && ch * 8 == D) ? (unsigned)T::from_f32(1.0f) : 0u, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) *(uint4*)(rV + r * VBYTES + sidx * 16) = fill;
+        }
+    }
+    __syncthreads();
+    const unsigned kstep = (unsigned)(KVT * (int)p.k_rs * 2), vstep = (unsigned)(KVT * (int)p.v_rs * 2);
+    int k_issued = 0, v_issued = 0;
+    auto dma_k = [&]() {        // next K tile -> ring slot k_issued % 3
+        const bool check = ragged && k_issued + 1 == ntiles;
+        const int kv0 = k_issued * KVT;
+        unsigned char* bK = rK + (k_issued % 3) * KBYTES;
+#pragma unroll
+        for (int i = 0; i < KP; ++i) {
+            if (NSK % NT == 0 || i * NT + wave * 64 < NSK) {
+                if (kdata[i] && (!check || kv0 + (i * NT + t) / (PK / 16) < p.Nkv)) glds16_asm((const unsigned char*)Kp + koff[i], bK + (i * NT + wave * 64) * 16);
+                koff[i] += kstep;
+            }
+        }
+        ++k_issued;
+    };
+    auto dma_v = [&]() {
+        const bool check = ragged && v_issued + 1 == ntiles;
+        const int kv0 = v_issued * KVT;
+        unsigned char* bV = rV + (v_issued % 3) * VBYTES;
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            if (NSV % NT == 0 || i * NT + wave * 64 < NSV) {
+                if (vdata[i] && (!check || kv0 + (i * NT + t) / (PV / 16) < p.Nkv)) glds16_asm((const unsigned char*)Vp + voff[i], bV + (i * NT + wave * 64) * 16);
+                voff[i] += vstep;
+            }
+        }
+        ++v_issued;
+    };
+    auto sync_step = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    auto qk = [&](const int it, f32x4 (&sacc)[KT][QT], auto mask_tag) {      // S^T = K(it) Q^T
+        constexpr bool MASK = decltype(mask_tag)::value;
+        const unsigned char* sK = rK + (it % 3) * KBYTES;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int j = 0; j < QT; ++j) sacc[kt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const uint4 kf = *(const uint4*)(sK + (kt * 16 + li) * PK + (s * 4 + lg) * 16);
+#pragma unroll
+                for (int j = 0; j < QT; ++j) sacc[kt][j] = T::mfma(kf, qf[j][s], sacc[kt][j]);
+            }
+        if constexpr (MASK) {      // ragged last tile: keys past Nkv get -inf scores (selects, no branch)
+            const int lim = p.Nkv - it * KVT - lg * 4;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < QT; ++j) sacc[kt][j][r] = (kt * 16 + r < lim) ? sacc[kt][j][r] : -1e30f;
+        }
+    };
+    auto pv = [&](const int it, const uint4 (&pb)[US][QT]) {   // O^T += V(it)^T P^T
+        const unsigned char* sV = rV + (it % 3) * VBYTES;
+#pragma unroll
+        for (int u = 0; u < US; ++u)
+#pragma unroll
+            for (int d = 0; d < NDT; ++d) {
+                const unsigned char* a0 = sV + (u * 32 + 4 * lg + (li >> 2)) * PV + (d * 16 + 4 * (li & 3)) * 2;
+                const uint2 lo = ds_read_tr16(a0);
+                const uint2 hi = ds_read_tr16(a0 + 16 * PV);
+                const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                for (int j = 0; j < QT; ++j) oacc[d][j] = T::mfma(vf, pb[u][j], oacc[d][j]);
+            }
+    };
+    auto softmax = [&](f32x4 (&sacc)[KT][QT], uint4 (&pb)[US][QT]) {
+#pragma unroll
+        for (int j = 0; j < QT; ++j) {
+            float mx = sacc[0][j][0];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kt][j][r]);
+            mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), (16 << 10) | 0x1f)));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[j], mx);
+            const float mc = mnew * c;
+            const vv_f32x2 c2 = {c, c}, nmc2 = {-mc, -mc};
+            vv_f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    const vv_f32x2 a2 = __builtin_elementwise_fma((vv_f32x2){sacc[kt][j][r], sacc[kt][j][r + 1]}, c2, nmc2);
+                    const float e0 = __builtin_amdgcn_exp2f(a2.x), e1 = __builtin_amdgcn_exp2f(a2.y);
+                    sacc[kt][j][r] = e0; sacc[kt][j][r + 1] = e1;
+                    if (!ONES) ps2 += (vv_f32x2){e0, e1};
+                }
+            const float ps = ps2.x + ps2.y;
+            // always rescale (alpha = 1 when the maximum did not move): a branch here would cut the basic block and with it the
+            // interleaving of this VALU work with the MFMAs of qk / pv
+            const float alpha = __builtin_amdgcn_exp2f((mrun[j] - mnew) * c);
+            if (!ONES) lrun[j] = lrun[j] * alpha + ps;
+#pragma unroll
+            for (int d = 0; d < NDT; ++d) oacc[d][j] *= alpha;
+            mrun[j] = mnew;
+#pragma unroll
+            for (int u = 0; u < US; ++u)
+                pb[u][j] = make_uint4(pack2<T>(sacc[2 * u][j][0], sacc[2 * u][j][1]), pack2<T>(sacc[2 * u][j][2], sacc[2 * u][j][3]),
+                                      pack2<T>(sacc[2 * u + 1][j][0], sacc[2 * u + 1][j][1]), pack2<T>(sacc[2 * u + 1][j][2], sacc[2 * u + 1][j][3]));
+        }
+    };
+
+    // ---- pipeline.  Step `it`: issue K(it+2), V(it+1); S_b = K(it+1) Q^T; O^T += V(it-1)^T P(it-1); P(it) = softmax(S_a); swap a/b.
+    f32x4 sA[KT][QT], sB[KT][QT];
+    uint4 pA[US][QT], pB[US][QT];
+    dma_k(); dma_v();
+    if (ntiles > 1) dma_k();
+    sync_step();
+    if (ragged && ntiles == 1) qk(0, sA, std::true_type{}); else qk(0, sA, std::false_type{});
+    // one step, straight-line: DO_QK / DO_PV / MASK are compile-time so that qk, pv and the softmax share ONE basic block
+    auto step = [&](const int it, f32x4 (&sc)[KT][QT], f32x4 (&sn)[KT][QT], uint4 (&pc)[US][QT], uint4 (&pp)[US][QT], auto qk_tag, auto pv_tag,
+                    auto mask_tag) {
+        if (it + 2 < ntiles) dma_k();
+        if (it + 1 < ntiles) dma_v();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(qk_tag)::value) qk(it + 1, sn, mask_tag);
+        if constexpr (decltype(pv_tag)::value) pv(it - 1, pp);
+        softmax(sc, pc);
+        // interleave: every MFMA (with the LDS read that feeds it) is followed by a few of the softmax's VALU instructions, so the
+        // matrix pipe runs under the exponent math of this same wave
+        if constexpr (HINT > 0 && (decltype(qk_tag)::value || decltype(pv_tag)::value)) {
+            constexpr int NM = (decltype(qk_tag)::value ? KS * KT * QT : 0) + (decltype(pv_tag)::value ? US * NDT * QT : 0);
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);     // VALU (softmax)
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        sync_step();
+    };
+    using TT = std::true_type; using FF = std::false_type;
+    // the step that computes the scores of the LAST tile carries the ragged-key mask
+    auto step_any = [&](const int it, f32x4 (&sc)[KT][QT], f32x4 (&sn)[KT][QT], uint4 (&pc)[US][QT], uint4 (&pp)[US][QT]) {
+        const bool has_qk = it + 1 < ntiles, has_pv = it > 0, mask = ragged && it + 2 == ntiles;
+        if (has_qk && has_pv && !mask) step(it, sc, sn, pc, pp, TT{}, TT{}, FF{});         // steady state
+        else if (has_qk && has_pv) step(it, sc, sn, pc, pp, TT{}, TT{}, TT{});
+        else if (has_qk && !mask) step(it, sc, sn, pc, pp, TT{}, FF{}, FF{});
+        else if (has_qk) step(it, sc, sn, pc, pp, TT{}, FF{}, TT{});
+        else if (has_pv) step(it, sc, sn, pc, pp, FF{}, TT{}, FF{});
+        else step(it, sc, sn, pc, pp, FF{}, FF{}, FF{});
+    };
+    for (int it = 0; it < ntiles; it += 2) {
+        step_any(it, sA, sB, pA, pB);
+        if (it + 1 < ntiles) step_any(it + 1, sB, sA, pB, pA);
+    }
+    if ((ntiles - 1) & 1) pv(ntiles - 1, pB); else pv(ntiles - 1, pA);
+
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+        float l;
+        if (ONES) {
+            l = __shfl(oacc[D / 16][j][(D % 16) % 4], ((D % 16) / 4) * 16 + li);
+        } else {
+            l = lrun[j];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
+        const float inv = 1.0f / l;
+        const int q = q0 + j * 16 + li;
+        if (q < p.Nq) {
+#pragma unroll
+            for (int d = 0; d < NDT; ++d) {
+                const int dd = d * 16 + lg * 4;
+                if (dd < D) {
+                    const uint2 o2 = make_uint2(pack2<T>(oacc[d][j][0] * inv, oacc[d][j][1] * inv), pack2<T>(oacc[d][j][2] * inv, oacc[d][j][3] * inv));
+                    *(uint2*)(O + (int64_t)q * p.o_rs + dd) = o2;
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int D, int OCC, int KIND, int HINT = 0>
+int attn_pipe_launch(const vv_attn_params& p, hipStream_t st) {
+    constexpr int BQ = 128;
+    const int nqt = (p.Nq + BQ - 1) / BQ;
+    const int64_t nblk = (int64_t)p.B * p.heads * nqt;
+    if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_attention: grid too large");
+    hipLaunchKernelGGL((attn_pipe_kernel<T, D, OCC, KIND, HINT>), dim3((unsigned)nblk), dim3(256), 0, st, p, nqt);
+    VV_CHECK_LAUNCH("vv_attention(pipelined)");
+    return VV_OK;
+}
+
 template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0>
 int attn_launch(const vv_attn_params& p, hipStream_t st) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
@@ -366,6 +660,11 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
             if (var == 10) return attn_launch<T, D, 2, 64, 4, false, 1, true>(p, st);   // DMA, uncapped registers (2 waves/SIMD)
             if (var == 13) return attn_launch<T, D, 2, 32, 4, false, 4, true>(p, st);   // DMA, 32-key tiles, capped at 128 VGPRs (4 waves/SIMD)
             if (var == 14) return attn_launch<T, D, 2, 64, 4, true, 3>(p, st);          // register staged, capped at 168 VGPRs (3 waves/SIMD)
+            if constexpr (D <= 64) {
+                if (var == 20) return attn_pipe_launch<T, D, 2, 0, 0>(p, st);               // software pipelined, 2 waves/SIMD, compiler's order
+                if (var == 21) return attn_pipe_launch<T, D, 2, 0, 3>(p, st);               // ... sched_group_barrier: 3 VALU per MFMA
+                if (var == 22) return attn_pipe_launch<T, D, 2, 0, 5>(p, st);               // ... 5 VALU per MFMA
+            }
 #endif
             // default for d <= 64: K/V by LDS-DMA, double buffered, 3 waves/SIMD (d = 80 would spill: stays register staged)
             const bool cross = p.Nkv < 128 && p.Nq != p.Nkv;
