@@ -92,7 +92,10 @@ def run_infill_on_frames(frames_rgb, mask_frames, mask_dilation_iter=8, ckpt="2-
 # CLI entry point (reference diffuerase.py:121-155)
 # =============================
 def main():
-    import tools  # the reference's own frame I/O helper (cv2); only needed for the CLI
+    try:
+        import tools  # the reference's own frame I/O helper (cv2), when the drop-in sits next to the GUI
+    except ImportError:
+        from videovanish_amd import frameio as tools   # cv2-free FFV1 / Matroska I/O with the same two functions
     ap = argparse.ArgumentParser(description="Remove masked objects from a video (DiffuEraser hot path on MI355X).")
     ap.add_argument("--color_video", required=True, type=str, help="Input color video path.")
     ap.add_argument("--mask_video", required=True, type=str, help="Input mask video path.")

@@ -1,0 +1,118 @@
+"""cv2-free frame I/O (reference tools.py:4-45): FFV1 v3 (csrc/vv_ffv1.c) in Matroska, lossless round trips, the
+reference's nearest-resize-on-write and start/max-frame semantics, and structure checks of the byte stream.
+PARITY UNPINNED against ffmpeg / cv2 (absent): these tests pin self-consistency and the RFC 9043 structure only."""
+import os
+
+import numpy as np
+import pytest
+
+from videovanish_amd import frameio as FIO
+
+
+def _frames(T, H, W, seed, kind):
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        return [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(T)]
+    if kind == "flat":            # long zero runs: exercises the run mode of the Golomb-Rice coder
+        out = []
+        for t in range(T):
+            f = np.full((H, W, 3), 17 * t % 256, np.uint8)
+            f[H // 4: H // 2, W // 3: W // 2] = (255, 0, 128)
+            out.append(f)
+        return out
+    ys, xs = np.mgrid[0:H, 0:W]   # smooth gradients + a little noise: small residuals, adaptive k
+    out = []
+    for t in range(T):
+        base = np.stack([(xs * 3 + t * 5) % 256, (ys * 2 + xs) % 256, (xs + ys + 7 * t) % 256], -1)
+        out.append(np.clip(base + rng.integers(-2, 3, (H, W, 3)), 0, 255).astype(np.uint8))
+    return out
+
+
+@pytest.mark.parametrize("kind", ["noise", "flat", "smooth"])
+@pytest.mark.parametrize("H,W,nv", [(16, 24, 1), (37, 53, 1), (64, 40, 3), (1, 7, 1), (9, 1, 2)])
+def test_ffv1_frame_round_trip_is_lossless(kind, H, W, nv):
+    f = _frames(1, H, W, 5, kind)[0]
+    cfg = FIO.ffv1_config_record(nv)
+    pkt = FIO.ffv1_encode(f, nv)
+    assert np.array_equal(FIO.ffv1_decode(cfg, pkt, W, H), f)
+    if kind == "flat" and H * W > 200:
+        assert len(pkt) < H * W * 3 // 4          # the run mode actually compresses flat areas
+    if kind == "noise" and H * W > 200:
+        assert len(pkt) < int(H * W * 3 * 1.35)   # incompressible input costs ~9 bits per 8-bit sample, not more
+
+
+def test_ffv1_stream_structure():
+    f = _frames(1, 32, 48, 7, "smooth")[0]
+    cfg = FIO.ffv1_config_record(2)
+    pkt = FIO.ffv1_encode(f, 2)
+
+    def crc(b):          # CRC-32 / polynomial 0x04C11DB7, MSB first, init 0 (RFC 9043 4.9.3): zero over data || crc
+        c = 0
+        for x in b:
+            c ^= x << 24
+            for _ in range(8):
+                c = ((c << 1) ^ 0x04C11DB7) & 0xFFFFFFFF if c & 0x80000000 else (c << 1) & 0xFFFFFFFF
+        return c
+    assert crc(cfg) == 0 and len(cfg) < 64
+    # two slices, each ends in [slice_size:3][error_status:1][crc:4]; walking back from the end lands exactly on byte 0
+    end, n = len(pkt), 0
+    while end > 0:
+        size = int.from_bytes(pkt[end - 8: end - 5], "big")
+        assert pkt[end - 5] == 0 and crc(pkt[end - 8 - size: end]) == 0
+        end -= size + 8
+        n += 1
+    assert end == 0 and n == 2
+    bad = bytearray(pkt)
+    bad[10] ^= 0x40
+    with pytest.raises(RuntimeError, match="CRC"):
+        FIO.ffv1_decode(cfg, bytes(bad), 48, 32)
+    with pytest.raises(RuntimeError, match="CRC"):
+        FIO.ffv1_decode(cfg[:-1] + bytes([cfg[-1] ^ 1]), pkt, 48, 32)
+
+
+def test_mkv_round_trip_and_tools_api(tmp_path):
+    T, H, W = 7, 36, 52
+    frames = _frames(T, H, W, 11, "smooth")
+    path = str(tmp_path / "clip.mkv")
+    FIO.write_video_frames_to_path(path, frames, 24.0, H, W)
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"\x1a\x45\xdf\xa3" and b"matroska" in raw[:64] and b"V_FFV1" in raw[:400]
+    got, fps = FIO.load_video_frames_from_path(path)
+    assert abs(fps - 24.0) < 1e-3 and len(got) == T and all(np.array_equal(a, b) for a, b in zip(got, frames))
+    sub, _ = FIO.load_video_frames_from_path(path, 2, 3)          # reference tools.py:17-23: skip start_frame, stop at max_frames
+    assert len(sub) == 3 and np.array_equal(sub[0], frames[2]) and np.array_equal(sub[2], frames[4])
+    tail, _ = FIO.load_video_frames_from_path(path, 5, -1)
+    assert len(tail) == 2
+    with pytest.raises(AssertionError):
+        FIO.load_video_frames_from_path(path, 99, -1)             # "No frames read"
+    with pytest.raises(AssertionError):
+        FIO.load_video_frames_from_path(str(tmp_path / "missing.mkv"))
+
+
+def test_write_resizes_mismatched_frames_with_nearest(tmp_path):
+    """reference tools.py:41-42 (the reference's early-return quirk leaves frames 1.. at the model size: SURVEY a6)."""
+    big = _frames(1, 40, 64, 3, "noise")[0]
+    small = _frames(1, 20, 32, 4, "noise")[0]
+    path = str(tmp_path / "mixed.mkv")
+    FIO.write_video_frames_to_path(path, [big, small], 30.0, 40, 64)
+    got, _ = FIO.load_video_frames_from_path(path)
+    assert np.array_equal(got[0], big)
+    assert np.array_equal(got[1], FIO.resize_nearest(small, 64, 40)) and np.array_equal(got[1][::2, ::2], small)
+
+
+def test_cli_end_to_end_with_own_frame_io(tmp_path, monkeypatch):
+    """diffuerase.main() with NO `tools` module importable falls back to videovanish_amd.frameio (hot path stubbed: CPU test)."""
+    import sys
+    import diffuerase
+    monkeypatch.setitem(sys.modules, "tools", None)               # import tools -> ImportError
+    T, H, W = 4, 24, 32
+    frames = _frames(T, H, W, 1, "smooth")
+    masks = [np.zeros((H, W, 3), np.uint8) for _ in range(T)]
+    color, mask = str(tmp_path / "c.mkv"), str(tmp_path / "m.mkv")
+    FIO.write_video_frames_to_path(color, frames, 25.0, H, W)
+    FIO.write_video_frames_to_path(mask, masks, 25.0, H, W)
+    monkeypatch.setattr(diffuerase, "run_infill_on_frames", lambda fr, mk, **kw: [255 - f for f in fr])
+    monkeypatch.setattr(sys, "argv", ["diffuerase.py", "--color_video", color, "--mask_video", mask])
+    diffuerase.main()
+    out, fps = FIO.load_video_frames_from_path(color + "_vanished.mkv")
+    assert abs(fps - 25.0) < 1e-3 and len(out) == T and all(np.array_equal(o, 255 - f) for o, f in zip(out, frames))

@@ -58,6 +58,19 @@ def main():
         ("bf16 weights only", dict(dtype=torch.bfloat16, classes=("w",))),
         ("bf16 activations only", dict(dtype=torch.bfloat16, classes=("a",))),
     ]
+    dec = lambda n: n.startswith("vae.decoder") or n.startswith("vae.post_quant")
+    enc = lambda n: n.startswith("vae.encoder") or n.startswith("vae.quant")
+    L = len(vcfg.block_out)
+    tail = lambda n: n.startswith("vae.decoder.conv_out") or n.startswith(f"vae.decoder.up_blocks.{L - 1}")
+    plans += [      # which part of the VAE, and how much of a split-precision layer, is needed
+        ("fp16, VAE decoder exact (3-pass split)", dict(dtype=torch.float16, exact=dec)),
+        ("fp16, VAE encoder exact", dict(dtype=torch.float16, exact=enc)),
+        ("fp16, decoder last block + conv_out exact", dict(dtype=torch.float16, exact=tail)),
+        ("fp16, decoder activations exact (2-pass)", dict(dtype=torch.float16, exact=lambda n: {"a"} if dec(n) else False)),
+        ("fp16, decoder weights exact (2-pass)", dict(dtype=torch.float16, exact=lambda n: {"w"} if dec(n) else False)),
+        ("fp16, decoder exact + conv_in/out exact", dict(dtype=torch.float16, exact=lambda n: dec(n) or n.endswith("conv_in") or n.endswith("conv_out"))),
+        ("fp16, decoder exact + ResBlock conv acts exact", dict(dtype=torch.float16, exact=lambda n: True if dec(n) else ({"a"} if ".resnets." in n else False))),
+    ]
     print(f"# arch={args.arch} T={args.T} {args.W}x{args.H}; per-pixel max-abs / mean-abs in [0,1] vs the fp32 oracle")
     for steps in args.steps:
         kw = dict(steps=steps, chunk=args.T, overlap=0, seed=7, ucfg=ucfg, vcfg=vcfg, return_float=True)

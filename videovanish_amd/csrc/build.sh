@@ -28,3 +28,7 @@ for p in "${pids[@]}"; do wait $p; done
 rm -f build/vv_attn.o
 hipcc --offload-arch=gfx950 -shared -fPIC -o libvvhip.so build/*.o
 echo "built $(pwd)/libvvhip.so"
+# host-side frame I/O codec (FFV1, plain C, no GPU): libvvio.so
+if [ ! -f libvvio.so ] || [ vv_ffv1.c -nt libvvio.so ]; then
+  gcc -O2 -std=c99 -fPIC -shared -Wall -o libvvio.so vv_ffv1.c
+fi

@@ -1,0 +1,585 @@
+/* vv_ffv1.c -- host-side FFV1 (RFC 9043) version 3 intra codec for the frame I/O on either side of the hot path
+ * (reference tools.py:30-45 writes FFV1 in Matroska through cv2/ffmpeg).  Plain C, no GPU: codec I/O is CPU
+ * work outside the timed path.  Built into libvvio.so by build.sh; bound by videovanish_amd/frameio.py.
+ *
+ * What is implemented (the subset ffmpeg's encoder emits for 8-bit packed RGB, and what this encoder writes):
+ *   version 3, micro_version 4; coder_type 0 (Golomb-Rice sample coding, range coder for the headers); colorspace_type 1
+ *   (RGB through the reversible JPEG 2000 RCT, planes G, B-G, R-G coded with 9 bits); no alpha; num_h_slices = 1,
+ *   num_v_slices >= 1 (horizontal bands); ec = 1 (CRC-32 per slice and on the configuration record); intra = 1.
+ * The decoder additionally accepts any quantisation-table set with 3 or 5 context inputs and states_coded = 0.
+ * Range-coded sample data (coder_type 1/2) is refused: it needs RFC 9043's default_state_transition table, which this file
+ * does not carry.
+ *
+ * PARITY UNPINNED against a real FFV1 decoder (no ffmpeg / cv2 in the build image): restated from RFC 9043 and the public
+ * libavcodec ffv1 sources; pinned here only by lossless round trips and structural checks (tests/test_frameio_cpu.py).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define CONTEXT_SIZE 32
+#define MAX_CTX 32768
+
+/* ---------------------------------------------------------------------------------------------------------------- CRC */
+/* CRC-32, polynomial 0x04C11DB7, MSB first, init 0, no final xor; stored big-endian so that crc(data || crc) == 0 */
+static uint32_t crc_table[256];
+static int crc_ready;
+static void crc_init(void) {
+    for (int i = 0; i < 256; ++i) {
+        uint32_t c = (uint32_t)i << 24;
+        for (int k = 0; k < 8; ++k) c = (c & 0x80000000u) ? (c << 1) ^ 0x04C11DB7u : (c << 1);
+        crc_table[i] = c;
+    }
+    crc_ready = 1;
+}
+static uint32_t crc32_mpeg(const uint8_t* p, int n) {
+    if (!crc_ready) crc_init();
+    uint32_t c = 0;
+    for (int i = 0; i < n; ++i) c = (c << 8) ^ crc_table[(c >> 24) ^ p[i]];
+    return c;
+}
+static void put_be32(uint8_t* p, uint32_t v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; }
+
+/* -------------------------------------------------------------------------------------------------------- range coder */
+typedef struct {
+    int low, range, outstanding_count, outstanding_byte;
+    uint8_t zero_state[256], one_state[256];
+    uint8_t *start, *ptr, *end;
+    int overflow;
+} RangeCoder;
+
+/* state transition table of the HEADER coder (libavcodec ff_build_rac_states(c, 0.05 * 2^32, 256 - 8)) */
+static void build_rac_states(RangeCoder* c) {
+    const int64_t one = 1LL << 32;
+    const int64_t factor = (int64_t)(0.05 * (double)(1LL << 32));
+    const int max_p = 256 - 8;
+    int64_t p;
+    int last_p8 = 0, p8, i;
+    memset(c->zero_state, 0, 256);
+    memset(c->one_state, 0, 256);
+    p = one / 2;
+    for (i = 0; i < 128; i++) {
+        p8 = (int)((256 * p + one / 2) >> 32);
+        if (p8 <= last_p8) p8 = last_p8 + 1;
+        if (last_p8 && last_p8 < 256 && p8 <= max_p) c->one_state[last_p8] = (uint8_t)p8;
+        p += ((one - p) * factor + one / 2) >> 32;
+        last_p8 = p8;
+    }
+    for (i = 256 - max_p; i <= max_p; i++) {
+        if (c->one_state[i]) continue;
+        p = (i * one + 128) >> 8;
+        p += ((one - p) * factor + one / 2) >> 32;
+        p8 = (int)((256 * p + one / 2) >> 32);
+        if (p8 <= i) p8 = i + 1;
+        if (p8 > max_p) p8 = max_p;
+        c->one_state[i] = (uint8_t)p8;
+    }
+    for (i = 1; i < 255; i++) c->zero_state[i] = (uint8_t)(256 - c->one_state[256 - i]);
+}
+
+static void rc_init_enc(RangeCoder* c, uint8_t* buf, int size) {
+    c->start = c->ptr = buf; c->end = buf + size;
+    c->low = 0; c->range = 0xFF00; c->outstanding_count = 0; c->outstanding_byte = -1; c->overflow = 0;
+    build_rac_states(c);
+}
+static void rc_out(RangeCoder* c, int b) { if (c->ptr < c->end) *c->ptr++ = (uint8_t)b; else c->overflow = 1; }
+static void rc_renorm_enc(RangeCoder* c) {
+    while (c->range < 0x100) {
+        if (c->outstanding_byte < 0) {
+            c->outstanding_byte = c->low >> 8;
+        } else if (c->low <= 0xFF00) {
+            rc_out(c, c->outstanding_byte);
+            for (; c->outstanding_count; c->outstanding_count--) rc_out(c, 0xFF);
+            c->outstanding_byte = c->low >> 8;
+        } else if (c->low >= 0x10000) {
+            rc_out(c, c->outstanding_byte + 1);
+            for (; c->outstanding_count; c->outstanding_count--) rc_out(c, 0x00);
+            c->outstanding_byte = (c->low >> 8) & 0xFF;
+        } else {
+            c->outstanding_count++;
+        }
+        c->low = (c->low & 0xFF) << 8;
+        c->range <<= 8;
+    }
+}
+static void put_rac(RangeCoder* c, uint8_t* state, int bit) {
+    int range1 = (c->range * (*state)) >> 8;
+    if (!bit) { c->range -= range1; *state = c->zero_state[*state]; }
+    else { c->low += c->range - range1; c->range = range1; *state = c->one_state[*state]; }
+    rc_renorm_enc(c);
+}
+/* ff_rac_terminate(c, version): version 1 first codes a 0 with state 129 (the Golomb-Rice hand-over bit of FFV1 >= 3.2) */
+static int rc_terminate(RangeCoder* c, int version) {
+    if (version == 1) { uint8_t st = 129; put_rac(c, &st, 0); }
+    c->range = 0xFF; c->low += 0xFF; rc_renorm_enc(c);
+    c->range = 0xFF; rc_renorm_enc(c);
+    return (int)(c->ptr - c->start);
+}
+static void put_symbol(RangeCoder* c, uint8_t* state, int v, int is_signed) {
+    if (v) {
+        const int a = v < 0 ? -v : v;
+        int e = 0, i;
+        while ((a >> (e + 1)) != 0) e++;          /* floor(log2(a)) */
+        put_rac(c, state + 0, 0);
+        for (i = 0; i < e; i++) put_rac(c, state + 1 + (i < 9 ? i : 9), 1);
+        put_rac(c, state + 1 + (e < 9 ? e : 9), 0);
+        for (i = e - 1; i >= 0; i--) put_rac(c, state + 22 + (i < 9 ? i : 9), (a >> i) & 1);
+        if (is_signed) put_rac(c, state + 11 + (e < 10 ? e : 10), v < 0);
+    } else {
+        put_rac(c, state + 0, 1);
+    }
+}
+
+static void rc_init_dec(RangeCoder* c, const uint8_t* buf, int size) {
+    c->start = (uint8_t*)buf; c->ptr = (uint8_t*)buf; c->end = (uint8_t*)buf + size;
+    c->overflow = 0;
+    build_rac_states(c);
+    c->low = size >= 2 ? ((buf[0] << 8) | buf[1]) : 0;
+    c->ptr += 2;
+    c->range = 0xFF00;
+    if (c->low >= 0xFF00) { c->low = 0xFF00; c->end = c->ptr; }
+}
+static void rc_refill(RangeCoder* c) {
+    if (c->range < 0x100) {
+        c->range <<= 8; c->low <<= 8;
+        if (c->ptr < c->end) { c->low += *c->ptr; c->ptr++; }
+        else c->overflow++;
+    }
+}
+static int get_rac(RangeCoder* c, uint8_t* state) {
+    int range1 = (c->range * (*state)) >> 8;
+    c->range -= range1;
+    if (c->low < c->range) { *state = c->zero_state[*state]; rc_refill(c); return 0; }
+    c->low -= c->range; *state = c->one_state[*state]; c->range = range1; rc_refill(c); return 1;
+}
+static int get_symbol(RangeCoder* c, uint8_t* state, int is_signed, int* err) {
+    if (get_rac(c, state + 0)) return 0;
+    int e = 0, i;
+    unsigned a = 1;
+    while (get_rac(c, state + 1 + (e < 9 ? e : 9))) { if (++e > 31) { *err = 1; return 0; } }
+    for (i = e - 1; i >= 0; i--) a += a + get_rac(c, state + 22 + (i < 9 ? i : 9));
+    int s = -(is_signed && get_rac(c, state + 11 + (e < 10 ? e : 10)));
+    return (int)((a ^ (unsigned)s) - (unsigned)s);
+}
+
+/* ---------------------------------------------------------------------------------------------- Golomb-Rice bit I/O */
+typedef struct { uint8_t* buf; int cap; int64_t bitpos; int overflow; } BitW;
+static void bw_put(BitW* w, int n, uint32_t v) {          /* n <= 32 bits, MSB first */
+    for (int i = n - 1; i >= 0; --i) {
+        const int64_t byte = w->bitpos >> 3;
+        if (byte >= w->cap) { w->overflow = 1; w->bitpos++; continue; }
+        if ((w->bitpos & 7) == 0) w->buf[byte] = 0;
+        w->buf[byte] |= (uint8_t)(((v >> i) & 1u) << (7 - (w->bitpos & 7)));
+        w->bitpos++;
+    }
+}
+typedef struct { const uint8_t* buf; int64_t nbits; int64_t pos; int overflow; } BitR;
+static int br_get1(BitR* r) {
+    if (r->pos >= r->nbits) { r->overflow = 1; r->pos++; return 0; }
+    const int b = (r->buf[r->pos >> 3] >> (7 - (r->pos & 7))) & 1;
+    r->pos++;
+    return b;
+}
+static uint32_t br_get(BitR* r, int n) { uint32_t v = 0; for (int i = 0; i < n; ++i) v = (v << 1) | (uint32_t)br_get1(r); return v; }
+
+typedef struct { int16_t drift; uint16_t error_sum; int8_t bias; uint8_t count; } VlcState;
+static const uint8_t log2_run[41] = {0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7,
+                                     8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24};
+
+static int fold(int diff, int bits) {           /* sign-extend the low `bits` bits */
+    const int sh = 32 - bits;
+    return (int)((uint32_t)diff << sh) >> sh;
+}
+static void update_vlc_state(VlcState* st, int v) {
+    int drift = st->drift, count = st->count;
+    st->error_sum += (uint16_t)(v < 0 ? -v : v);
+    drift += v;
+    if (count == 128) { count >>= 1; drift >>= 1; st->error_sum >>= 1; }
+    count++;
+    if (drift <= -count) {
+        st->bias = (int8_t)(st->bias - 1 < -128 ? -128 : st->bias - 1);
+        drift = drift + count > -count + 1 ? drift + count : -count + 1;
+    } else if (drift > 0) {
+        st->bias = (int8_t)(st->bias + 1 > 127 ? 127 : st->bias + 1);
+        drift = drift - count < 0 ? drift - count : 0;
+    }
+    st->drift = (int16_t)drift; st->count = (uint8_t)count;
+}
+static int vlc_k(const VlcState* st) { int i = st->count, k = 0; while (i < st->error_sum) { k++; i += i; } return k; }
+static void put_vlc_symbol(BitW* w, VlcState* st, int v, int bits) {
+    v = fold(v - st->bias, bits);
+    const int k = vlc_k(st);
+    const int code = v ^ ((2 * st->drift + st->count) >> 31);
+    /* set_sr_golomb(code, k, limit 12, esc_len bits) */
+    int u = -2 * code - 1; u ^= (u >> 31);
+    const int e = u >> k;
+    if (e < 12) bw_put(w, e + k + 1, (1u << k) + ((unsigned)u & ((1u << k) - 1u)));
+    else { bw_put(w, 12, 0); bw_put(w, bits, (uint32_t)(u - 12 + 1)); }
+    update_vlc_state(st, v);
+}
+static int get_vlc_symbol(BitR* r, VlcState* st, int bits) {
+    const int k = vlc_k(st);
+    int e = 0, u;
+    while (e < 12 && br_get1(r) == 0) e++;
+    if (e < 12) u = (e << k) + (int)br_get(r, k);
+    else u = (int)br_get(r, bits) + 12 - 1;
+    int v = (u >> 1) ^ -(u & 1);
+    v ^= ((2 * st->drift + st->count) >> 31);
+    const int ret = fold(v + st->bias, bits);
+    update_vlc_state(st, v);
+    return ret;
+}
+
+/* ------------------------------------------------------------------------------------------------------ codec state */
+typedef struct {
+    int16_t quant[5][256];
+    int context_count;
+    int five;                         /* quant[3] / quant[4] in use */
+} QuantSet;
+
+static inline int mid_pred(int a, int b, int c) {
+    if (a > b) { if (c > b) { if (c > a) b = a; else b = c; } }
+    else { if (b > c) { if (c > a) b = c; else b = a; } }
+    return b;
+}
+static inline int get_context(const QuantSet* q, const int16_t* src, const int16_t* last, const int16_t* last2) {
+    const int LT = last[-1], T = last[0], RT = last[1], L = src[-1];
+    int c = q->quant[0][(L - LT) & 0xFF] + q->quant[1][(LT - T) & 0xFF] + q->quant[2][(T - RT) & 0xFF];
+    if (q->five) c += q->quant[3][(src[-2] - L) & 0xFF] + q->quant[4][(last2[0] - T) & 0xFF];
+    return c;
+}
+
+/* the encoder's own table set: 9 levels per input (0 | 1..2 | 3..6 | 7..14 | 15..), three inputs -> (9^3 + 1) / 2 = 365 contexts */
+static void default_quant(QuantSet* q) {
+    static const int edge[4] = {1, 3, 7, 15};
+    int scale = 1;
+    memset(q, 0, sizeof(*q));
+    for (int t = 0; t < 3; ++t) {
+        for (int i = 0; i < 128; ++i) { int v = 0; for (int e = 0; e < 4; ++e) if (i >= edge[e]) v = e + 1; q->quant[t][i] = (int16_t)(scale * v); }
+        for (int i = 1; i < 128; ++i) q->quant[t][256 - i] = (int16_t)-q->quant[t][i];
+        q->quant[t][128] = (int16_t)-q->quant[t][127];
+        scale *= 9;
+    }
+    q->context_count = (scale + 1) / 2;
+    q->five = 0;
+}
+static void write_quant_table(RangeCoder* c, const int16_t* tab) {
+    uint8_t state[CONTEXT_SIZE];
+    int last = 0, i;
+    memset(state, 128, sizeof(state));
+    for (i = 1; i < 128; i++)
+        if (tab[i] != tab[i - 1]) { put_symbol(c, state, i - last - 1, 0); last = i; }
+    put_symbol(c, state, i - last - 1, 0);
+}
+static int read_quant_table(RangeCoder* c, int16_t* tab, int scale) {
+    uint8_t state[CONTEXT_SIZE];
+    int v, i = 0, err = 0;
+    memset(state, 128, sizeof(state));
+    for (v = 0; i < 128; v++) {
+        unsigned len = (unsigned)get_symbol(c, state, 0, &err) + 1u;
+        if (err || len > (unsigned)(128 - i) || !len) return -1;
+        while (len--) { tab[i] = (int16_t)(scale * v); i++; }
+    }
+    for (i = 1; i < 128; i++) tab[256 - i] = (int16_t)-tab[i];
+    tab[128] = (int16_t)-tab[127];
+    return 2 * v - 1;
+}
+
+/* ----------------------------------------------------------------------------------------------- configuration record */
+typedef struct {
+    int version, micro, coder, colorspace, bits, chroma_planes, hshift, vshift, alpha, nh, nv, nsets, ec, intra;
+    QuantSet sets[8];
+} Config;
+
+int vvio_ffv1_config_record(int num_v_slices, uint8_t* out, int cap) {
+    RangeCoder c;
+    uint8_t state[CONTEXT_SIZE];
+    QuantSet q;
+    if (cap < 64 || num_v_slices < 1) return -1;
+    default_quant(&q);
+    memset(state, 128, sizeof(state));
+    rc_init_enc(&c, out, cap - 4);
+    put_symbol(&c, state, 3, 0);               /* version */
+    put_symbol(&c, state, 4, 0);               /* micro_version */
+    put_symbol(&c, state, 0, 0);               /* coder_type: Golomb-Rice */
+    put_symbol(&c, state, 1, 0);               /* colorspace_type: RGB (JPEG 2000 RCT) */
+    put_symbol(&c, state, 8, 0);               /* bits_per_raw_sample */
+    put_rac(&c, state, 1);                     /* chroma_planes */
+    put_symbol(&c, state, 0, 0);               /* log2_h_chroma_subsample */
+    put_symbol(&c, state, 0, 0);               /* log2_v_chroma_subsample */
+    put_rac(&c, state, 0);                     /* extra_plane (alpha) */
+    put_symbol(&c, state, 0, 0);               /* num_h_slices - 1 */
+    put_symbol(&c, state, num_v_slices - 1, 0);
+    put_symbol(&c, state, 1, 0);               /* quant_table_set_count */
+    for (int t = 0; t < 5; ++t) write_quant_table(&c, q.quant[t]);
+    put_rac(&c, state, 0);                     /* states_coded = 0 for the set */
+    put_symbol(&c, state, 1, 0);               /* ec */
+    put_symbol(&c, state, 1, 0);               /* intra */
+    const int n = rc_terminate(&c, 0);
+    if (c.overflow) return -1;
+    put_be32(out + n, crc32_mpeg(out, n));
+    return n + 4;
+}
+
+static int parse_config(const uint8_t* rec, int len, Config* cf) {
+    RangeCoder c;
+    uint8_t state[CONTEXT_SIZE];
+    int err = 0;
+    if (len < 6) return -1;
+    memset(cf, 0, sizeof(*cf));
+    memset(state, 128, sizeof(state));
+    rc_init_dec(&c, rec, len);
+    cf->version = get_symbol(&c, state, 0, &err);
+    if (cf->version < 3) return -2;
+    cf->micro = get_symbol(&c, state, 0, &err);
+    cf->coder = get_symbol(&c, state, 0, &err);
+    if (cf->coder != 0) return -3;             /* range-coded samples need the static default_state_transition table */
+    cf->colorspace = get_symbol(&c, state, 0, &err);
+    cf->bits = get_symbol(&c, state, 0, &err);
+    cf->chroma_planes = get_rac(&c, state);
+    cf->hshift = get_symbol(&c, state, 0, &err);
+    cf->vshift = get_symbol(&c, state, 0, &err);
+    cf->alpha = get_rac(&c, state);
+    cf->nh = get_symbol(&c, state, 0, &err) + 1;
+    cf->nv = get_symbol(&c, state, 0, &err) + 1;
+    cf->nsets = get_symbol(&c, state, 0, &err);
+    if (err || cf->nsets < 1 || cf->nsets > 8) return -4;
+    for (int s = 0; s < cf->nsets; ++s) {
+        int count = 1;
+        for (int t = 0; t < 5; ++t) {
+            const int r = read_quant_table(&c, cf->sets[s].quant[t], count);
+            if (r < 0) return -5;
+            count *= r;
+            if (count > MAX_CTX) return -5;
+        }
+        cf->sets[s].context_count = (count + 1) / 2;
+        cf->sets[s].five = cf->sets[s].quant[3][127] || cf->sets[s].quant[4][127];
+    }
+    for (int s = 0; s < cf->nsets; ++s)
+        if (get_rac(&c, state)) return -6;     /* coded initial states: not supported */
+    cf->ec = get_symbol(&c, state, 0, &err);
+    if (cf->version > 2 && cf->micro > 2) cf->intra = get_symbol(&c, state, 0, &err);
+    if (err) return -7;
+    if (cf->colorspace != 1 || cf->bits > 8 || cf->alpha || cf->nh != 1) return -8;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------------ slices */
+static void slice_rows(int H, int nv, int sy, int* y0, int* h) {
+    const int a = (int)((int64_t)sy * H / nv), b = (int)((int64_t)(sy + 1) * H / nv);
+    *y0 = a; *h = b - a;
+}
+
+/* one slice (rows y0 .. y0+h-1 of an RGB24 image) -> bytes written, or -1 */
+static int encode_slice(const uint8_t* rgb, int W, int stride, int y0, int h, int sy, int first, const QuantSet* q, uint8_t* out, int cap) {
+    RangeCoder c;
+    uint8_t state[CONTEXT_SIZE];
+    rc_init_enc(&c, out, cap);
+    if (first) { uint8_t keystate = 128; put_rac(&c, &keystate, 1); }     /* key frame flag lives in slice 0's coder */
+    memset(state, 128, sizeof(state));
+    put_symbol(&c, state, 0, 0);               /* slice_x */
+    put_symbol(&c, state, sy, 0);              /* slice_y */
+    put_symbol(&c, state, 0, 0);               /* slice_width - 1 (in slice units) */
+    put_symbol(&c, state, 0, 0);               /* slice_height - 1 */
+    put_symbol(&c, state, 0, 0);               /* quant_table_set_index, plane 0 */
+    put_symbol(&c, state, 0, 0);               /* ... plane 1 (chroma) */
+    put_symbol(&c, state, 3, 0);               /* picture_structure: progressive */
+    put_symbol(&c, state, 0, 0);               /* sar_num */
+    put_symbol(&c, state, 0, 0);               /* sar_den */
+    const int ac_bytes = rc_terminate(&c, 1);
+    if (c.overflow) return -1;
+    BitW bw = {out + ac_bytes, cap - ac_bytes, 0, 0};
+
+    VlcState* vlc[2];
+    for (int p = 0; p < 2; ++p) {
+        vlc[p] = (VlcState*)malloc(sizeof(VlcState) * (size_t)q->context_count);
+        if (!vlc[p]) return -1;
+        for (int i = 0; i < q->context_count; ++i) { vlc[p][i].drift = 0; vlc[p][i].error_sum = 4; vlc[p][i].bias = 0; vlc[p][i].count = 1; }
+    }
+    /* three planes (G, B-G, R-G), three lines each, 3 samples of margin on both sides */
+    const int LW = W + 6;
+    int16_t* lines = (int16_t*)calloc((size_t)3 * 3 * LW, sizeof(int16_t));
+    if (!lines) { free(vlc[0]); free(vlc[1]); return -1; }
+    int run_index = 0;
+    for (int y = 0; y < h; ++y) {
+        int16_t* s[3][3];
+        for (int p = 0; p < 3; ++p)
+            for (int i = 0; i < 3; ++i) s[p][i] = lines + ((size_t)p * 3 + (size_t)((y + 3 - i) % 3)) * LW + 3;   /* [0] current, [1] above, [2] two above */
+        const uint8_t* row = rgb + (size_t)(y0 + y) * stride;
+        for (int x = 0; x < W; ++x) {
+            int r = row[3 * x], g = row[3 * x + 1], b = row[3 * x + 2];
+            b -= g; r -= g; g += (b + r) >> 2; b += 256; r += 256;
+            s[0][0][x] = (int16_t)g; s[1][0][x] = (int16_t)b; s[2][0][x] = (int16_t)r;
+        }
+        for (int p = 0; p < 3; ++p) {
+            int16_t *cur = s[p][0], *last = s[p][1], *last2 = s[p][2];
+            VlcState* vs = vlc[(p + 1) / 2];
+            if (y == 0) { memset(last - 3, 0, sizeof(int16_t) * LW); memset(last2 - 3, 0, sizeof(int16_t) * LW); }
+            else if (y == 1) memset(last2 - 3, 0, sizeof(int16_t) * LW);
+            cur[-1] = last[0]; last[W] = last[W - 1];
+            cur[-2] = cur[-1];       /* (only read by 5-input sets, never by this encoder's own tables) */
+            int run_count = 0, run_mode = 0;
+            for (int x = 0; x < W; ++x) {
+                int context = get_context(q, cur + x, last + x, last2 + x);
+                int diff = cur[x] - mid_pred(cur[x - 1], cur[x - 1] + last[x] - last[x - 1], last[x]);
+                if (context < 0) { context = -context; diff = -diff; }
+                diff = fold(diff, 9);
+                if (context == 0) run_mode = 1;
+                if (run_mode) {
+                    if (diff) {
+                        while (run_count >= 1 << log2_run[run_index]) { run_count -= 1 << log2_run[run_index]; run_index++; bw_put(&bw, 1, 1); }
+                        bw_put(&bw, 1 + log2_run[run_index], (uint32_t)run_count);
+                        if (run_index) run_index--;
+                        run_count = 0; run_mode = 0;
+                        if (diff > 0) diff--;
+                    } else {
+                        run_count++;
+                    }
+                }
+                if (run_mode == 0) put_vlc_symbol(&bw, &vs[context], diff, 9);
+            }
+            if (run_mode) {
+                while (run_count >= 1 << log2_run[run_index]) { run_count -= 1 << log2_run[run_index]; run_index++; bw_put(&bw, 1, 1); }
+                if (run_count) bw_put(&bw, 1, 1);
+            }
+        }
+    }
+    free(lines); free(vlc[0]); free(vlc[1]);
+    if (bw.overflow) return -1;
+    int bytes = ac_bytes + (int)((bw.bitpos + 7) >> 3);
+    if (bytes + 8 > cap || bytes >= (1 << 24)) return -1;
+    out[bytes] = (uint8_t)(bytes >> 16); out[bytes + 1] = (uint8_t)(bytes >> 8); out[bytes + 2] = (uint8_t)bytes;   /* slice_size */
+    bytes += 3;
+    out[bytes++] = 0;                                                                                                /* error_status */
+    put_be32(out + bytes, crc32_mpeg(out, bytes));
+    return bytes + 4;
+}
+
+/* RGB24 frame -> FFV1 packet.  Returns the packet size, or -1 (buffer too small: cap >= 2 * W * H * 3 + 4096 is always enough) */
+int vvio_ffv1_encode_frame(const uint8_t* rgb, int W, int H, int num_v_slices, uint8_t* out, int cap) {
+    QuantSet q;
+    int pos = 0;
+    if (!rgb || !out || W < 1 || H < 1 || num_v_slices < 1 || num_v_slices > H) return -1;
+    default_quant(&q);
+    for (int sy = 0; sy < num_v_slices; ++sy) {
+        int y0, h;
+        slice_rows(H, num_v_slices, sy, &y0, &h);
+        const int n = encode_slice(rgb, W, W * 3, y0, h, sy, sy == 0, &q, out + pos, cap - pos);
+        if (n < 0) return -1;
+        pos += n;
+    }
+    return pos;
+}
+
+static int decode_slice(const Config* cf, const uint8_t* data, int len, int first, int W, int H, uint8_t* rgb) {
+    RangeCoder c;
+    uint8_t state[CONTEXT_SIZE];
+    int err = 0;
+    rc_init_dec(&c, data, len);
+    if (first) { uint8_t keystate = 128; if (!get_rac(&c, &keystate)) return -20; }    /* intra-only streams: every frame is a key frame */
+    memset(state, 128, sizeof(state));
+    const int sx = get_symbol(&c, state, 0, &err), sy = get_symbol(&c, state, 0, &err);
+    const int sw = get_symbol(&c, state, 0, &err) + 1, sh = get_symbol(&c, state, 0, &err) + 1;
+    const int qi0 = get_symbol(&c, state, 0, &err), qi1 = get_symbol(&c, state, 0, &err);
+    (void)get_symbol(&c, state, 0, &err); (void)get_symbol(&c, state, 0, &err); (void)get_symbol(&c, state, 0, &err);
+    if (err || sx != 0 || sw != 1 || sy < 0 || sy + sh > cf->nv || qi0 >= cf->nsets || qi1 >= cf->nsets) return -21;
+    if (cf->micro > 1) { uint8_t st = 129; (void)get_rac(&c, &st); }
+    const int ac_bytes = (int)(c.ptr - c.start) - 1;
+    if (ac_bytes < 0 || ac_bytes > len) return -22;
+    BitR br = {data + ac_bytes, (int64_t)(len - ac_bytes) * 8, 0, 0};
+    const int y0 = (int)((int64_t)sy * H / cf->nv), h = (int)((int64_t)(sy + sh) * H / cf->nv) - y0;
+    const QuantSet* qs[2] = {&cf->sets[qi0], &cf->sets[qi1]};
+    VlcState* vlc[2];
+    for (int p = 0; p < 2; ++p) {
+        vlc[p] = (VlcState*)malloc(sizeof(VlcState) * (size_t)qs[p]->context_count);
+        if (!vlc[p]) return -23;
+        for (int i = 0; i < qs[p]->context_count; ++i) { vlc[p][i].drift = 0; vlc[p][i].error_sum = 4; vlc[p][i].bias = 0; vlc[p][i].count = 1; }
+    }
+    const int LW = W + 6;
+    int16_t* lines = (int16_t*)calloc((size_t)3 * 3 * LW, sizeof(int16_t));
+    if (!lines) { free(vlc[0]); free(vlc[1]); return -23; }
+    int run_index = 0;
+    for (int y = 0; y < h; ++y) {
+        int16_t* s[3][3];
+        for (int p = 0; p < 3; ++p)
+            for (int i = 0; i < 3; ++i) s[p][i] = lines + ((size_t)p * 3 + (size_t)((y + 3 - i) % 3)) * LW + 3;
+        for (int p = 0; p < 3; ++p) {
+            int16_t *cur = s[p][0], *last = s[p][1], *last2 = s[p][2];
+            const QuantSet* q = qs[(p + 1) / 2];
+            VlcState* vs = vlc[(p + 1) / 2];
+            if (y == 0) { memset(last - 3, 0, sizeof(int16_t) * LW); memset(last2 - 3, 0, sizeof(int16_t) * LW); }
+            else if (y == 1) memset(last2 - 3, 0, sizeof(int16_t) * LW);
+            cur[-1] = last[0]; last[W] = last[W - 1];
+            cur[-2] = cur[-1];
+            int run_count = 0, run_mode = 0;
+            for (int x = 0; x < W; ++x) {
+                int context = get_context(q, cur + x, last + x, last2 + x), sign = 0, diff;
+                if (context < 0) { context = -context; sign = 1; }
+                if (context == 0 && run_mode == 0) run_mode = 1;
+                if (run_mode) {
+                    if (run_count == 0 && run_mode == 1) {
+                        if (br_get1(&br)) {
+                            run_count = 1 << log2_run[run_index];
+                            if (x + run_count <= W) run_index++;
+                        } else {
+                            run_count = log2_run[run_index] ? (int)br_get(&br, log2_run[run_index]) : 0;
+                            if (run_index) run_index--;
+                            run_mode = 2;
+                        }
+                    }
+                    run_count--;
+                    if (run_count < 0) {
+                        run_mode = 0; run_count = 0;
+                        diff = get_vlc_symbol(&br, &vs[context], 9);
+                        if (diff >= 0) diff++;
+                    } else {
+                        diff = 0;
+                    }
+                } else {
+                    diff = get_vlc_symbol(&br, &vs[context], 9);
+                }
+                if (sign) diff = -diff;
+                cur[x] = (int16_t)((mid_pred(cur[x - 1], cur[x - 1] + last[x] - last[x - 1], last[x]) + diff) & 0x1FF);
+            }
+        }
+        uint8_t* row = rgb + (size_t)(y0 + y) * W * 3;
+        for (int x = 0; x < W; ++x) {
+            int g = s[0][0][x], b = s[1][0][x], r = s[2][0][x];
+            b -= 256; r -= 256; g -= (b + r) >> 2; b += g; r += g;
+            row[3 * x] = (uint8_t)r; row[3 * x + 1] = (uint8_t)g; row[3 * x + 2] = (uint8_t)b;
+        }
+    }
+    free(lines); free(vlc[0]); free(vlc[1]);
+    return br.overflow ? -24 : 0;
+}
+
+/* FFV1 packet + configuration record -> RGB24 (W*H*3 bytes).  0 = ok, negative = error code */
+int vvio_ffv1_decode_frame(const uint8_t* cfg, int cfglen, const uint8_t* data, int len, int W, int H, uint8_t* rgb) {
+    Config* cf = (Config*)malloc(sizeof(Config));
+    if (!cf) return -1;
+    if (cfglen < 5 || crc32_mpeg(cfg, cfglen) != 0) { free(cf); return -10; }
+    int r = parse_config(cfg, cfglen - 4, cf);
+    if (r < 0) { free(cf); return r; }
+    /* walk the slices from the END of the packet: [... slice][size:3][status:1 crc:4 when ec] */
+    const int trailer = 3 + (cf->ec ? 5 : 0);
+    int end = len, nslices = 0;
+    int starts[1024], lens[1024];
+    while (end > 0) {
+        if (end < trailer) { free(cf); return -11; }
+        const uint8_t* t = data + end - trailer;
+        const int size = (t[0] << 16) | (t[1] << 8) | t[2];
+        const int total = size + trailer;
+        if (total > end || nslices >= 1024) { free(cf); return -12; }
+        if (cf->ec && crc32_mpeg(data + end - total, total) != 0) { free(cf); return -13; }
+        starts[nslices] = end - total; lens[nslices] = size; nslices++;
+        end -= total;
+    }
+    for (int i = nslices - 1, k = 0; i >= 0; --i, ++k) {
+        r = decode_slice(cf, data + starts[i], lens[i], k == 0, W, H, rgb);
+        if (r < 0) { free(cf); return r; }
+    }
+    free(cf);
+    return 0;
+}
+
+int vvio_abi_version(void) { return 1; }

@@ -1,0 +1,265 @@
+"""cv2-free frame I/O with the API of the reference's `tools` module (reference tools.py:4-45):
+
+    load_video_frames_from_path(video_path, start_frame=0, max_frames=-1) -> (list of (H, W, 3) uint8 RGB frames, fps)
+    write_video_frames_to_path(out_video, frames, fps, H0, W0)            -> lossless FFV1 in Matroska (.mkv)
+
+The reference goes through cv2 (ffmpeg): `VideoWriter_fourcc(*"FFV1")` into an .mkv (tools.py:32-37), RGB<->BGR swaps
+(:21,:40) and a NEAREST resize of frames whose size differs from (W0, H0) (:41-42).  Here the container is written / parsed in
+Python (EBML is a few dozen lines) and the codec is the plain-C FFV1 v3 intra codec in csrc/vv_ffv1.c (libvvio.so; Golomb-Rice
+coded 8-bit RGB, what ffmpeg emits for bgr0).  Frames are RGB in, RGB out: no BGR detour.
+
+Reading supports what this module writes (V_FFV1 or V_MS/VFW/FOURCC 'FFV1', version 3, Golomb-Rice, 8-bit RGB, no alpha) plus
+uncompressed RGB24/BGR24 Matroska tracks (V_UNCOMPRESSED) and `.npy` / `.npz` frame stacks; other codecs (H.264, ...) raise a
+clear error -- decoding them is out of scope (codec I/O is either side of the hot path).
+PARITY UNPINNED against ffmpeg / cv2 (absent from the build image): pinned by lossless round trips and structure checks only.
+"""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libvvio.so")
+_lib = None
+
+
+def _io():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(_LIB_PATH):
+            raise RuntimeError(f"videovanish_amd: frame I/O codec missing ({_LIB_PATH}); run videovanish_amd/csrc/build.sh")
+        L = C.CDLL(_LIB_PATH)
+        for name in ("vvio_abi_version", "vvio_ffv1_config_record", "vvio_ffv1_encode_frame", "vvio_ffv1_decode_frame"):
+            if not hasattr(L, name):
+                raise RuntimeError(f"libvvio.so does not export {name}")
+        _lib = L
+    return _lib
+
+
+# ---- FFV1 ----------------------------------------------------------------------------------------------------------------
+def ffv1_config_record(num_v_slices=1):
+    buf = (C.c_uint8 * 4096)()
+    n = _io().vvio_ffv1_config_record(int(num_v_slices), buf, 4096)
+    if n < 0:
+        raise RuntimeError("vvio_ffv1_config_record failed")
+    return bytes(buf[:n])
+
+
+def ffv1_encode(frame_rgb, num_v_slices=1):
+    f = np.ascontiguousarray(frame_rgb, dtype=np.uint8)
+    H, W, ch = f.shape
+    assert ch == 3
+    cap = 2 * W * H * 3 + 4096 * num_v_slices
+    out = np.empty(cap, np.uint8)
+    n = _io().vvio_ffv1_encode_frame(f.ctypes.data_as(C.c_void_p), W, H, int(num_v_slices), out.ctypes.data_as(C.c_void_p), cap)
+    if n < 0:
+        raise RuntimeError("vvio_ffv1_encode_frame failed")
+    return out[:n].tobytes()
+
+
+def ffv1_decode(config, packet, W, H):
+    out = np.empty((H, W, 3), np.uint8)
+    cfg = (C.c_uint8 * len(config)).from_buffer_copy(config)
+    pkt = (C.c_uint8 * len(packet)).from_buffer_copy(packet)
+    r = _io().vvio_ffv1_decode_frame(cfg, len(config), pkt, len(packet), W, H, out.ctypes.data_as(C.c_void_p))
+    if r != 0:
+        reasons = {-10: "configuration record CRC mismatch", -2: "FFV1 version < 3", -3: "range-coded samples (coder_type != 0) are not supported",
+                   -6: "coded initial states are not supported", -8: "only 8-bit RGB without alpha / a single slice column is supported",
+                   -13: "slice CRC mismatch", -20: "not a key frame"}
+        raise RuntimeError(f"FFV1 decode failed ({r}): {reasons.get(r, 'malformed stream')}")
+    return out
+
+
+# ---- EBML / Matroska -----------------------------------------------------------------------------------------------------
+def _vint_size(n):
+    """EBML data-size field."""
+    for length in range(1, 9):
+        if n < (1 << (7 * length)) - 1:
+            return ((1 << (7 * length)) | n).to_bytes(length, "big")
+    raise ValueError("EBML size too large")
+
+
+def _el(eid, payload):
+    return eid + _vint_size(len(payload)) + payload
+
+
+def _uint(v):
+    n = max(1, (int(v).bit_length() + 7) // 8)
+    return int(v).to_bytes(n, "big")
+
+
+ID_EBML, ID_SEGMENT, ID_INFO, ID_TRACKS, ID_TRACKENTRY, ID_CLUSTER = b"\x1a\x45\xdf\xa3", b"\x18\x53\x80\x67", b"\x15\x49\xa9\x66", b"\x16\x54\xae\x6b", b"\xae", b"\x1f\x43\xb6\x75"
+ID_TIMECODESCALE, ID_DURATION, ID_MUXAPP, ID_WRITEAPP = b"\x2a\xd7\xb1", b"\x44\x89", b"\x4d\x80", b"\x57\x41"
+ID_TRACKNUM, ID_TRACKUID, ID_TRACKTYPE, ID_FLAGLACING, ID_CODECID, ID_CODECPRIVATE, ID_DEFAULTDURATION, ID_VIDEO = b"\xd7", b"\x73\xc5", b"\x83", b"\x9c", b"\x86", b"\x63\xa2", b"\x23\xe3\x83", b"\xe0"
+ID_PIXELW, ID_PIXELH, ID_COLOURSPACE = b"\xb0", b"\xba", b"\x2e\xb5\x24"
+ID_TIMECODE, ID_SIMPLEBLOCK, ID_BLOCKGROUP, ID_BLOCK = b"\xe7", b"\xa3", b"\xa0", b"\xa1"
+
+
+def write_mkv_ffv1(path, frames, fps, num_v_slices=None):
+    """frames: iterable of (H, W, 3) uint8 RGB arrays of one size."""
+    frames = list(frames)
+    H, W = frames[0].shape[:2]
+    nv = num_v_slices or max(1, min(H, (H + 539) // 540))       # bands of <= 540 rows keep a slice far below the 16 MB size field
+    fps = float(fps) if fps and fps > 0 else 25.0
+    dur_ns = int(round(1e9 / fps))
+    head = _el(ID_EBML, _el(b"\x42\x86", _uint(1)) + _el(b"\x42\xf7", _uint(1)) + _el(b"\x42\xf2", _uint(4)) + _el(b"\x42\xf3", _uint(8)) +
+               _el(b"\x42\x82", b"matroska") + _el(b"\x42\x87", _uint(4)) + _el(b"\x42\x85", _uint(2)))
+    info = _el(ID_INFO, _el(ID_TIMECODESCALE, _uint(1000000)) + _el(ID_MUXAPP, b"videovanish_amd.frameio") + _el(ID_WRITEAPP, b"videovanish_amd.frameio") +
+               _el(ID_DURATION, struct.pack(">d", len(frames) * 1000.0 / fps)))
+    video = _el(ID_VIDEO, _el(ID_PIXELW, _uint(W)) + _el(ID_PIXELH, _uint(H)))
+    track = _el(ID_TRACKENTRY, _el(ID_TRACKNUM, _uint(1)) + _el(ID_TRACKUID, _uint(1)) + _el(ID_TRACKTYPE, _uint(1)) + _el(ID_FLAGLACING, _uint(0)) +
+                _el(ID_CODECID, b"V_FFV1") + _el(ID_CODECPRIVATE, ffv1_config_record(nv)) + _el(ID_DEFAULTDURATION, _uint(dur_ns)) + video)
+    with open(path, "wb") as f:
+        f.write(head)
+        f.write(ID_SEGMENT + b"\x01\xff\xff\xff\xff\xff\xff\xff")          # unknown size: clusters are streamed
+        f.write(info)
+        f.write(_el(ID_TRACKS, track))
+        per_cluster = max(1, int(round(fps)))                               # about one second per cluster
+        for c0 in range(0, len(frames), per_cluster):
+            t0 = int(round(c0 * 1000.0 / fps))
+            blocks = []
+            for i in range(c0, min(len(frames), c0 + per_cluster)):
+                fr = frames[i]
+                assert fr.shape[:2] == (H, W), "all frames of a track must have one size"
+                rel = int(round(i * 1000.0 / fps)) - t0
+                blocks.append(_el(ID_SIMPLEBLOCK, b"\x81" + struct.pack(">h", rel) + b"\x80" + ffv1_encode(fr, nv)))     # track 1, key frame
+            f.write(_el(ID_CLUSTER, _el(ID_TIMECODE, _uint(t0)) + b"".join(blocks)))
+
+
+def _read_vint(buf, pos, is_id):
+    b0 = buf[pos]
+    length = 1
+    mask = 0x80
+    while length <= 8 and not (b0 & mask):
+        length += 1
+        mask >>= 1
+    if length > 8:
+        raise RuntimeError("malformed EBML")
+    raw = buf[pos:pos + length]
+    if is_id:
+        return bytes(raw), pos + length
+    val = int.from_bytes(raw, "big") & ((1 << (7 * length)) - 1)
+    if val == (1 << (7 * length)) - 1:
+        val = -1                                                            # unknown size
+    return val, pos + length
+
+
+def _children(buf, start, end):
+    pos = start
+    while pos < end:
+        eid, p = _read_vint(buf, pos, True)
+        size, p = _read_vint(buf, p, False)
+        stop = end if size < 0 else p + size
+        yield eid, p, stop
+        pos = stop
+
+
+def read_mkv(path, start_frame=0, max_frames=-1):
+    with open(path, "rb") as f:
+        buf = memoryview(f.read())
+    tracks, frames = {}, []
+    fps = 0.0
+    want = None
+    idx = 0
+    for eid, a, b in _children(buf, 0, len(buf)):
+        if eid != ID_SEGMENT:
+            continue
+        for sid, sa, sb in _children(buf, a, b):
+            if sid == ID_TRACKS:
+                for tid, ta, tb in _children(buf, sa, sb):
+                    if tid != ID_TRACKENTRY:
+                        continue
+                    tr = {}
+                    for fid, fa, fb in _children(buf, ta, tb):
+                        if fid == ID_TRACKNUM: tr["num"] = int.from_bytes(buf[fa:fb], "big")
+                        elif fid == ID_TRACKTYPE: tr["type"] = int.from_bytes(buf[fa:fb], "big")
+                        elif fid == ID_CODECID: tr["codec"] = bytes(buf[fa:fb]).rstrip(b"\x00").decode()
+                        elif fid == ID_CODECPRIVATE: tr["private"] = bytes(buf[fa:fb])
+                        elif fid == ID_DEFAULTDURATION: tr["dur"] = int.from_bytes(buf[fa:fb], "big")
+                        elif fid == ID_VIDEO:
+                            for vid, va, vb in _children(buf, fa, fb):
+                                if vid == ID_PIXELW: tr["W"] = int.from_bytes(buf[va:vb], "big")
+                                elif vid == ID_PIXELH: tr["H"] = int.from_bytes(buf[va:vb], "big")
+                                elif vid == ID_COLOURSPACE: tr["fourcc"] = bytes(buf[va:vb])
+                    if tr.get("type") == 1 and want is None:
+                        want = tr
+                        tracks[tr["num"]] = tr
+            elif sid == ID_CLUSTER and want is not None:
+                for cid, ca, cb in _children(buf, sa, sb):
+                    blk = None
+                    if cid == ID_SIMPLEBLOCK:
+                        blk = (ca, cb)
+                    elif cid == ID_BLOCKGROUP:
+                        for gid, ga, gb in _children(buf, ca, cb):
+                            if gid == ID_BLOCK:
+                                blk = (ga, gb)
+                    if blk is None:
+                        continue
+                    num, p = _read_vint(buf, blk[0], False)
+                    if num != want["num"]:
+                        continue
+                    payload = bytes(buf[p + 3: blk[1]])
+                    if idx >= start_frame and (max_frames <= 0 or len(frames) < max_frames):
+                        frames.append(_decode_payload(want, payload))
+                    idx += 1
+                    if max_frames > 0 and len(frames) >= max_frames:
+                        break
+    if want is None:
+        raise RuntimeError(f"{path}: no video track")
+    if want.get("dur"):
+        fps = 1e9 / want["dur"]
+    return frames, fps
+
+
+def _decode_payload(tr, payload):
+    codec, W, H = tr.get("codec", ""), tr["W"], tr["H"]
+    if codec == "V_FFV1":
+        return ffv1_decode(tr["private"], payload, W, H)
+    if codec == "V_MS/VFW/FOURCC":
+        priv = tr.get("private", b"")
+        if len(priv) >= 40 and priv[16:20] == b"FFV1":
+            return ffv1_decode(priv[40:], payload, W, H)           # BITMAPINFOHEADER (40 bytes) + FFV1 configuration record
+        raise RuntimeError(f"unsupported VFW codec {priv[16:20]!r}: this reader decodes FFV1 and uncompressed RGB only")
+    if codec == "V_UNCOMPRESSED":
+        fourcc = tr.get("fourcc", b"RGB\x18")
+        a = np.frombuffer(payload, np.uint8)[: H * W * 3].reshape(H, W, 3)
+        return a[..., ::-1].copy() if fourcc.startswith(b"BGR") else a.copy()
+    raise RuntimeError(f"unsupported codec {codec!r}: this reader decodes FFV1 (v3, Golomb-Rice, 8-bit RGB) and uncompressed RGB Matroska only")
+
+
+# ---- the reference's tools.py API ----------------------------------------------------------------------------------------
+def resize_nearest(frame, W0, H0):
+    """cv2.resize(f, (W0, H0), interpolation=INTER_NEAREST) restated: src index = min(floor(dst * scale), size - 1) (reference tools.py:41-42)."""
+    H, W = frame.shape[:2]
+    ys = np.minimum((np.arange(H0) * (H / float(H0))).astype(np.int64), H - 1)
+    xs = np.minimum((np.arange(W0) * (W / float(W0))).astype(np.int64), W - 1)
+    return frame[ys][:, xs]
+
+
+def load_video_frames_from_path(video_path, start_frame=0, max_frames=-1):
+    """reference tools.py:4-28: (list of RGB uint8 frames, fps); asserts that at least one frame was read."""
+    assert os.path.isfile(video_path), f"Failed to open video: {video_path}"
+    ext = os.path.splitext(video_path)[1].lower()
+    if ext == ".npy":
+        arr, fps = np.load(video_path), 25.0
+        frames = [f for f in arr[start_frame: (start_frame + max_frames) if max_frames > 0 else None]]
+    elif ext == ".npz":
+        z = np.load(video_path)
+        arr, fps = z["frames"], float(z["fps"]) if "fps" in z else 25.0
+        frames = [f for f in arr[start_frame: (start_frame + max_frames) if max_frames > 0 else None]]
+    else:
+        frames, fps = read_mkv(video_path, start_frame, max_frames)
+    assert len(frames) > 0, "No frames read"
+    return frames, fps
+
+
+def write_video_frames_to_path(out_video, mask_frames, fps, H0, W0):
+    """reference tools.py:30-45: lossless FFV1 / MKV; frames of another size are NEAREST-resized to (W0, H0) first (:41-42)."""
+    out = []
+    for f in mask_frames:
+        f = np.asarray(f, dtype=np.uint8)
+        if f.shape[0] != H0 or f.shape[1] != W0:
+            f = resize_nearest(f, W0, H0)
+        out.append(np.ascontiguousarray(f))
+    write_mkv_ffv1(out_video, out, fps)
+    print(f"[ok] wrote {len(out)} frames to {out_video}")
