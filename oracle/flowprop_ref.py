@@ -252,13 +252,27 @@ def propagate(frames_u8, masks_u8, flows_fw, flows_bw):
     return res, (fa | fb).numpy()
 
 
-def flow_propagation_prior(frames, masks2d, weight_seed=0, iters=ITERS, P=None):
+def subvideo_ranges(T, subvideo_length, pad_len=5):
+    """Sub-video schedule of ProPainter's image propagation ([UNVERIFIED-3P], public inference script): sub-videos of
+    min(100, subvideo_length) frames, each propagated together with pad_len frames of context on both sides; only the inner
+    frames are kept.  Returns [(s_f, e_f, keep_lo, keep_hi)] in frame indices."""
+    L = min(100, int(subvideo_length))
+    if L <= 0 or T <= L:
+        return [(0, T, 0, T)]
+    return [(max(0, f - pad_len), min(T, f + L + pad_len), f, min(T, f + L)) for f in range(0, T, L)]
+
+
+def flow_propagation_prior(frames, masks2d, weight_seed=0, iters=ITERS, P=None, subvideo_length=0):
     """Restatement of the prior the reference obtains at diffuerase.py:52-57 (flow part only).  frames: list of (H,W,3)
-    u8 with H,W multiples of 8; masks2d: list of (H,W) u8."""
+    u8 with H,W multiples of 8; masks2d: list of (H,W) u8.  subvideo_length > 0: propagate per sub-video (reference passes 50)."""
     P = P or Params(weight_seed)
     T = len(frames)
     with torch.no_grad():
         fw = [raft_flow(P, frames[t], frames[t + 1], iters) for t in range(T - 1)]
         bw = [raft_flow(P, frames[t + 1], frames[t], iters) for t in range(T - 1)]
-        out, _ = propagate(np.stack(frames), np.stack(masks2d), fw, bw)
+        out = [None] * T
+        for (s, e, lo, hi) in subvideo_ranges(T, subvideo_length):
+            sub, _ = propagate(np.stack(frames[s:e]), np.stack(masks2d[s:e]), fw[s:e - 1], bw[s:e - 1])
+            for t in range(lo, hi):
+                out[t] = sub[t - s]
     return out

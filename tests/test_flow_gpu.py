@@ -190,3 +190,38 @@ def test_raft_batched_pairs_match_single(gpu):
     assert batched.shape == (3, H, W, 2)
     for t in range(3):
         assert torch.equal(batched[t], single[t])
+
+
+def test_subvideo_propagation_matches_oracle(gpu):
+    """Propainter.forward(subvideo_length=...) (reference diffuerase.py:55 passes 50): propagation per sub-video with 5 frames of
+    context; here T = 13, subvideo_length = 4 -> four sub-videos.  Flows from the oracle, so the propagation must be bit-exact."""
+    from oracle import flowprop_ref as FP
+    from videovanish_amd import flowprop
+    T, H, W = 13, 32, 48
+    rng = np.random.default_rng(71)
+    base = rng.integers(0, 256, (H + 2 * T, W + T, 3), dtype=np.uint8)
+    frames = [np.ascontiguousarray(base[2 * t: 2 * t + H, t: t + W]) for t in range(T)]
+    masks = []
+    for t in range(T):
+        m = np.zeros((H, W), np.uint8)
+        m[H // 4: H // 2, W // 4 + t: W // 2 + t] = 255
+        masks.append(m)
+    assert flowprop.subvideo_ranges(T, 4) == FP.subvideo_ranges(T, 4) == [(0, 9, 0, 4), (0, 13, 4, 8), (3, 13, 8, 12), (7, 13, 12, 13)]
+    assert flowprop.subvideo_ranges(60, 50) == [(0, 55, 0, 50), (45, 60, 50, 60)] and flowprop.subvideo_ranges(50, 50) == [(0, 50, 0, 50)]
+    g = torch.Generator().manual_seed(3)
+    fw = [torch.randn(2, H, W, generator=g) * 2 for _ in range(T - 1)]
+    bw = [-f + 0.05 * torch.randn(2, H, W, generator=g) for f in fw]
+    ref = [None] * T
+    for (s, e, lo, hi) in FP.subvideo_ranges(T, 4):
+        sub, _ = FP.propagate(np.stack(frames[s:e]), np.stack(masks[s:e]), fw[s:e - 1], bw[s:e - 1])
+        for t in range(lo, hi):
+            ref[t] = sub[t - s]
+    to_dev = lambda f: f.permute(1, 2, 0).contiguous().to(gpu)
+    fr, mk = torch.from_numpy(np.stack(frames)).to(gpu), torch.from_numpy(np.stack(masks)).to(gpu)
+    out = torch.empty_like(fr)
+    for (s, e, lo, hi) in flowprop.subvideo_ranges(T, 4):
+        sub, _ = flowprop.propagate(fr[s:e].contiguous(), mk[s:e].contiguous(), [to_dev(f) for f in fw[s:e - 1]], [to_dev(f) for f in bw[s:e - 1]])
+        out[lo:hi] = sub[lo - s: hi - s]
+    assert np.array_equal(out.cpu().numpy(), np.stack(ref))
+    whole, _ = FP.propagate(np.stack(frames), np.stack(masks), fw, bw)
+    assert not np.array_equal(np.stack(whole), np.stack(ref))        # the sub-video schedule really changes the result

@@ -69,8 +69,18 @@ def propagate(frames_u8, masks_u8, fw, bw):
     return out, filled
 
 
-def flow_propagation_prior(frames, masks, device=None, progress=None, dtype="fp16", weight_seed=0, iters=ITERS):
-    """list of (H0,W0,3) u8 + list of (H0,W0) u8 masks -> list of (H0,W0,3) u8 prior frames."""
+def subvideo_ranges(T, subvideo_length, pad_len=5):
+    """Sub-video schedule of ProPainter's image propagation (third-party, restated from the public inference script): sub-videos
+    of min(100, subvideo_length) frames propagated with pad_len frames of context on both sides, inner frames kept."""
+    L = min(100, int(subvideo_length))
+    if L <= 0 or T <= L:
+        return [(0, T, 0, T)]
+    return [(max(0, f - pad_len), min(T, f + L + pad_len), f, min(T, f + L)) for f in range(0, T, L)]
+
+
+def flow_propagation_prior(frames, masks, device=None, progress=None, dtype="fp16", weight_seed=0, iters=ITERS, subvideo_length=0):
+    """list of (H0,W0,3) u8 + list of (H0,W0) u8 masks -> list of (H0,W0,3) u8 prior frames.
+    subvideo_length > 0: the propagation runs per sub-video as the reference's ProPainter call asks (diffuerase.py:55)."""
     ctx, raft = _model(device, dtype, weight_seed)
     dev = ctx.device
     H0, W0 = frames[0].shape[:2]
@@ -85,7 +95,15 @@ def flow_propagation_prior(frames, masks, device=None, progress=None, dtype="fp1
     fw, bw = flows_for_clip(raft, fr.contiguous(), iters)
     if progress is not None:
         progress(40, "running flow prior (propagation)")
-    out, _ = propagate(fr.contiguous(), mk.contiguous(), fw, bw)
+    T = fr.shape[0]
+    ranges = subvideo_ranges(T, subvideo_length)
+    if len(ranges) == 1:
+        out, _ = propagate(fr.contiguous(), mk.contiguous(), fw, bw)
+    else:
+        out = torch.empty_like(fr)
+        for (s, e, lo, hi) in ranges:
+            sub, _ = propagate(fr[s:e].contiguous(), mk[s:e].contiguous(), fw[s:e - 1], bw[s:e - 1])
+            out[lo:hi] = sub[lo - s: hi - s]
     if (H, W) != (H0, W0):
         out = hip.resize_u8(out.contiguous(), H0, W0, mode="bilinear")
     return list(out.cpu().numpy())

@@ -16,5 +16,17 @@ class Propainter:
         self.model_dir, self.device = model_dir, device
 
     def forward(self, frames, masks, ref_stride=10, neighbor_length=10, subvideo_length=50, mask_dilation=0, progress=None):
+        """Same signature as the third-party call (reference diffuerase.py:52-57).  Built: RAFT flows (both directions) + flow-guided
+        image propagation, run per sub-video of min(100, subvideo_length) frames with 5 frames of context (`subvideo_length`), after an
+        optional mask dilation (`mask_dilation`, L1 ball like the reference's own dilation).  NOT built: the recurrent
+        flow-completion network and the sparse-window transformer -- `ref_stride` and `neighbor_length` select the transformer's
+        reference / neighbour frames and therefore have nothing to act on; hole pixels no consistent flow reaches keep the frame's mean colour."""
+        import numpy as np
         from .flowprop import flow_propagation_prior
-        return flow_propagation_prior(frames, masks, device=self.device, progress=progress)
+        if ref_stride <= 0 or neighbor_length <= 0 or subvideo_length <= 0:
+            raise ValueError("Propainter.forward: ref_stride, neighbor_length and subvideo_length must be positive")
+        if mask_dilation:
+            from . import hip
+            m = torch.from_numpy(np.stack([mm if mm.ndim == 3 else mm[..., None] for mm in masks])).to(self.device if self.device is not None else get_device())
+            masks = list(hip.mask_collapse_dilate(m.contiguous(), int(mask_dilation)).cpu().numpy())
+        return flow_propagation_prior(frames, masks, device=self.device, progress=progress, subvideo_length=subvideo_length)
