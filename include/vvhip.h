@@ -109,6 +109,35 @@ typedef struct {
 int vv_groupnorm_nsplit(int HW, int C);
 int vv_groupnorm(const vv_groupnorm_params* host_p, int dtype, void* stream);
 
+/* statistics half of vv_groupnorm only (out / gamma / beta unused): leaves (mean, rstd) per (frame, group) in
+ * stats_ws[(F * nsplit + f) * groups * 2 ...]; consumed by vv_gn_affine for the fused motion module */
+int vv_groupnorm_stats(const vv_groupnorm_params* host_p, int dtype, void* stream);
+/* out[0][c] = rstd_g * gamma_c, out[1][c] = beta_c - mean_g * out[0][c]  (mean_rstd: [groups][2] device floats) */
+int vv_gn_affine(const float* mean_rstd, const float* gamma, const float* beta, int C, int groups, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K5 fused: a whole AnimateDiff temporal transformer ("motion module": GroupNorm apply, proj_in, 2 x (LayerNorm + positional
+ * embedding, per-head QKV, attention over the F frames of a pixel, out projection), LayerNorm + GEGLU feed-forward, proj_out,
+ * residuals) in ONE kernel for C = 320, F = 32, 8 heads: one wave owns one pixel's 32 tokens end to end (trunk and activations in
+ * registers), the weights stream through an LDS ring.  Replaces the 17 launches of the unfused block (reference diffuerase.py:62-67
+ * -> DiffuEraser.forward -> UNetMotionModel motion modules; SURVEY row a5.5 / north_star "temporal attention").
+ *   stream : the module's weights as 670 pre-swizzled [64 x 64] h16 slabs in consumption order (packing.pack_motion_stream)
+ *   params : fp32 block (biases, LayerNorm affine, GEGLU bias in chunk order, positional table), n_params floats
+ *   gn_affine : [2][320] per-call GroupNorm scale / shift (vv_groupnorm_stats + vv_gn_affine)
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* x;         /* fp32 [F*HW][320] trunk input (frames-major) */
+    const float* res1;      /* optional second residual, same shape, or NULL */
+    void* out;              /* [F*HW][320] fp32 or h16 */
+    int32_t out_dtype;
+    const void* stream;     /* h16 weight slabs */
+    const float* params;
+    const float* gn_affine;
+    int32_t C, F, heads, HW;
+    int32_t n_slabs, n_params;
+} vv_motion_params;
+int vv_motion_module_c320(const vv_motion_params* host_p, int dtype, void* stream);
+
 /* LayerNorm over the last dim of a [M][C] fp32 matrix, eps 1e-5; out = LN(x)*gamma+beta (+ pe[(m / rows_per_frame)][c]). */
 int vv_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, const float* pe,
                  int rows_per_frame, void* out, int dtype, void* stream);

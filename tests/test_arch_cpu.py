@@ -54,6 +54,7 @@ def _build(monkeypatch):
     monkeypatch.setattr(packing, "pack_matrix", lambda w, h16, geglu=False: w)
     monkeypatch.setattr(packing, "pack_conv", lambda w, h16, cin_pad=None: (w, w.shape[1] * w.shape[2] * w.shape[3]))
     monkeypatch.setattr(packing, "geglu_interleave", lambda w, b: (w, b))
+    monkeypatch.setattr(packing, "pack_motion_stream", lambda w, h16, heads=8: (w["proj_in.w"], w["proj_in.b"]))
     monkeypatch.setattr(vnn.Linear, "__call__", lambda self, *a, **k: None)      # CrossAttention projects the text K/V at build time
     from videovanish_amd.unet import BrushNet, UNetMotion
     from videovanish_amd.vae import VAE

@@ -187,13 +187,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 template <typename T>
-int gn_launch(const vv_groupnorm_params& p, hipStream_t st) {
+int gn_launch(const vv_groupnorm_params& p, hipStream_t st, bool apply = true) {
     const int C = p.C0 + p.C1;
     const GNGeom g = gn_geom(p.HW, C);
     const int threads = (g.threads + 63) / 64 * 64;
     hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), (size_t)2 * g.krows * C * sizeof(float), st, p, g);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.pool_frames ? 1 : p.F), dim3(256), 0, st, p, g);
-    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
+    if (apply) hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
     VV_CHECK_LAUNCH("vv_groupnorm");
     return VV_OK;
 }
@@ -215,6 +215,20 @@ extern "C" int vv_groupnorm(const vv_groupnorm_params* pp, int dtype, void* stre
     if (p.out_dtype != VV_F32 && p.out_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_groupnorm: out_dtype mismatch");
     if (p.F <= 0 || p.HW <= 0) VV_FAIL(VV_E_ARG, "vv_groupnorm: empty input");
     return dtype == VV_BF16 ? gn_launch<BF16>(p, (hipStream_t)stream) : gn_launch<F16>(p, (hipStream_t)stream);
+}
+
+// statistics only: (mean, rstd) of frame f, group g at stats_ws[(F * nsplit + f) * groups * 2 + 2 g] (pooled: identical for every f)
+extern "C" int vv_groupnorm_stats(const vv_groupnorm_params* pp, int dtype, void* stream) {
+    if (!pp) VV_FAIL(VV_E_ARG, "vv_groupnorm_stats: null params");
+    const vv_groupnorm_params& p = *pp;
+    const int C = p.C0 + p.C1;
+    if (dtype != VV_BF16 && dtype != VV_F16) VV_FAIL(VV_E_ARG, "vv_groupnorm_stats: bad dtype");
+    if (!p.in0 || !p.stats_ws) VV_FAIL(VV_E_ARG, "vv_groupnorm_stats: null pointer");
+    if (p.C0 <= 0 || p.C0 % 8 || p.C1 % 8 || (p.C1 > 0 && !p.in1)) VV_FAIL(VV_E_ARG, "vv_groupnorm_stats: channels must be multiples of 8");
+    if (p.groups <= 0 || p.groups > 256 || C % p.groups || C / 8 > 1024) VV_FAIL(VV_E_ARG, "vv_groupnorm_stats: groups=%d C=%d", p.groups, C);
+    if (p.in_dtype != VV_F32 && p.in_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_groupnorm_stats: in_dtype mismatch");
+    if (p.F <= 0 || p.HW <= 0) VV_FAIL(VV_E_ARG, "vv_groupnorm_stats: empty input");
+    return dtype == VV_BF16 ? gn_launch<BF16>(p, (hipStream_t)stream, false) : gn_launch<F16>(p, (hipStream_t)stream, false);
 }
 
 extern "C" int vv_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, const float* pe, int rows_per_frame,

@@ -62,6 +62,12 @@ class GroupNormParams(C.Structure):
                 ("out", C.c_void_p), ("out_dtype", C.c_int32)]
 
 
+class MotionParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("res1", C.c_void_p), ("out", C.c_void_p), ("out_dtype", C.c_int32), ("stream", C.c_void_p),
+                ("params", C.c_void_p), ("gn_affine", C.c_void_p), ("C", C.c_int32), ("F", C.c_int32), ("heads", C.c_int32), ("HW", C.c_int32),
+                ("n_slabs", C.c_int32), ("n_params", C.c_int32)]
+
+
 class AttnParams(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
                 ("q_bs", C.c_int64), ("k_bs", C.c_int64), ("v_bs", C.c_int64), ("o_bs", C.c_int64),
@@ -76,7 +82,8 @@ EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name
            "vv_preprocess", "vv_brushnet_input", "vv_pad_channels", "vv_decode_blend", "vv_blur_compose",
            "vv_avgpool2_f32", "vv_corr_lookup", "vv_raft_ctx_split", "vv_raft_flow_prep", "vv_gru_rh", "vv_gru_update", "vv_add_flow",
            "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32", "vv_u8_is_zero",
-           "vv_raft_prep", "vv_split_f32", "vv_pad_channels_f32", "vv_window_average"]
+           "vv_raft_prep", "vv_split_f32", "vv_pad_channels_f32", "vv_window_average",
+           "vv_groupnorm_stats", "vv_gn_affine", "vv_motion_module_c320"]
 
 
 def lib():
@@ -204,6 +211,28 @@ def groupnorm(dtype, x0, gamma, beta, groups, eps, *, x1=None, F, HW, silu=False
                         silu=int(act) if act is not None else int(silu), stats_ws=ws.data_ptr(), out=out.data_ptr(), out_dtype=dt_of(out))
     with _Prof("groupnorm", 0.0, F * HW * Ctot * (2 * x0.element_size() + out.element_size())):
         _check(lib().vv_groupnorm(C.byref(p), dtype, _stream()), "vv_groupnorm")
+    return out
+
+
+def motion_module_c320(dtype, x, stream_w, params, gamma, beta, groups, eps, *, F, HW, res1=None, out_dtype=torch.float32):
+    """The fused motion module (vv_motion.hip): clip-pooled GroupNorm statistics -> per-channel affine -> ONE kernel for the whole block."""
+    _need_cuda(x, stream_w, params, gamma, beta, res1)
+    Cc = x.shape[-1]
+    nsplit = lib().vv_groupnorm_nsplit(HW, Cc)
+    ws = torch.empty(F * (nsplit + 1) * groups * 2, dtype=torch.float32, device=x.device)
+    gp = GroupNormParams(in0=x.data_ptr(), in1=0, in_dtype=dt_of(x), C0=Cc, C1=0, F=F, HW=HW, groups=groups, pool_frames=1, eps=eps,
+                         gamma=gamma.data_ptr(), beta=beta.data_ptr(), silu=0, stats_ws=ws.data_ptr(), out=0, out_dtype=F32)
+    with _Prof("groupnorm", 0.0, F * HW * Cc * x.element_size()):
+        _check(lib().vv_groupnorm_stats(C.byref(gp), dtype, _stream()), "vv_groupnorm_stats")
+    aff = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    fin = ws.data_ptr() + F * nsplit * groups * 2 * 4
+    _check(lib().vv_gn_affine(C.c_void_p(fin), _p(gamma), _p(beta), Cc, groups, _p(aff), _stream()), "vv_gn_affine")
+    out = torch.empty((F * HW, Cc), dtype=out_dtype, device=x.device)
+    mp = MotionParams(x=x.data_ptr(), res1=res1.data_ptr() if res1 is not None else 0, out=out.data_ptr(), out_dtype=dt_of(out),
+                      stream=stream_w.data_ptr(), params=params.data_ptr(), gn_affine=aff.data_ptr(), C=Cc, F=F, heads=8, HW=HW,
+                      n_slabs=stream_w.shape[0], n_params=params.numel())
+    with _Prof("motion_module_fused[c320]", 2.0 * 22 * Cc * Cc * F * HW + 8.0 * F * Cc * F * HW, F * HW * Cc * (x.element_size() * 2 + out.element_size())):
+        _check(lib().vv_motion_module_c320(C.byref(mp), dtype, _stream()), "vv_motion_module_c320")
     return out
 
 

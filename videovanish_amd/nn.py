@@ -308,10 +308,32 @@ class SpatialTransformer:
 
 
 class MotionModule:
-    """AnimateDiff temporal transformer."""
+    """AnimateDiff temporal transformer.  At C = 320, 8 heads and 32-frame clips the whole module runs as ONE kernel
+    (csrc/vv_motion.hip: one wave per pixel, trunk and activations in registers, weights streamed through an LDS ring); every other
+    shape runs the layer-by-layer path below."""
+    FUSED = True          # class-level switch (tests / A-B runs compare both paths on the same weights)
 
     def __init__(self, ctx, name, C, cfg, pe_table):
         self.ctx = ctx
+        self.C, self.groups = C, cfg.groups
+        self.fused = None
+        if C == 320 and cfg.heads == 8:
+            src = ctx.src
+            b = name + ".transformer_blocks.0"
+            w = {}
+            w["proj_in.w"], w["proj_in.b"] = src.linear(name + ".proj_in", C, C)
+            w["proj_out.w"], w["proj_out.b"] = src.linear(name + ".proj_out", C, C)
+            for a in ("attn1", "attn2"):
+                for nm, key in (("q", "to_q"), ("k", "to_k"), ("v", "to_v")):
+                    w[f"{a}.{nm}"], _ = src.linear(f"{b}.{a}.{key}", C, C, 1.0, False)
+                w[f"{a}.o"], w[f"{a}.ob"] = src.linear(f"{b}.{a}.to_out.0", C, C)
+            for i in (1, 2, 3):
+                w[f"ln{i}.g"], w[f"ln{i}.b"] = src.norm(f"{b}.norm{i}", C)
+            w["ff1.w"], w["ff1.b"] = src.linear(b + ".ff.net.0.proj", C, 8 * C)
+            w["ff2.w"], w["ff2.b"] = src.linear(b + ".ff.net.2", 4 * C, C)
+            w["pe"] = pe_table.detach().float().cpu()
+            stream, params = packing.pack_motion_stream(w, ctx.h16, cfg.heads)
+            self.fused = (ctx.dev(stream), ctx.dev(params))
         self.norm = GroupNorm(ctx, name + ".norm", C, cfg.groups, 1e-6)
         self.proj_in = Linear(ctx, name + ".proj_in", C, C)
         b = name + ".transformer_blocks.0"
@@ -331,6 +353,10 @@ class MotionModule:
 
     def _run(self, x, F, H, W, res1, out_dtype):
         HW = H * W
+        if (self.fused is not None and MotionModule.FUSED and F == 32 and HW % 4 == 0 and x.dtype == torch.float32
+                and (res1 is None or res1.dtype == torch.float32)):
+            return hip.motion_module_c320(self.ctx.dt, x, self.fused[0], self.fused[1], self.norm.g, self.norm.b, self.groups, self.norm.eps,
+                                          F=F, HW=HW, res1=res1, out_dtype=out_dtype)
         if F > self.pe.shape[0]:
             raise RuntimeError(f"motion module: clip of {F} frames exceeds the positional table ({self.pe.shape[0]})")
         h = self.norm(x, F, HW, pool_frames=True)

@@ -47,3 +47,76 @@ def geglu_interleave(w, b):
     bv, bg = b[:inner].reshape(inner // 16, 16), b[inner:].reshape(inner // 16, 16)
     bi = torch.stack([bv, bg], 1).reshape(two_inner)
     return wi, bi
+
+
+# ---- fused motion module (csrc/vv_motion.hip): the whole module's weights as one stream of pre-swizzled [64 x 64] h16 slabs ---------
+def _perm32():
+    """position p = 8 lg + e of a 32-wide MFMA k step holds logical index 16 (e >> 2) + 4 lg + (e & 3) (two 16-row accumulator tiles
+    of the previous layer packed into one operand: vv_motion.hip PERM32)."""
+    p = torch.arange(32)
+    e, lg = p & 7, p >> 3
+    return 16 * (e >> 2) + 4 * lg + (e & 3)
+
+
+def _permute_k(w):
+    """[N, K] (K % 32 == 0) -> columns reordered per PERM32 inside every 32-wide k step."""
+    N, K = w.shape
+    idx = (torch.arange(0, K, 32)[:, None] + _perm32()[None, :]).reshape(-1)
+    return w[:, idx]
+
+
+def _slab(block, h16):
+    """[rows <= 64, 64] fp32 -> one [64, 64] h16 slab, 16-byte chunk c of row r stored at chunk c ^ (r & 7)."""
+    rows = block.shape[0]
+    out = torch.zeros((64, 64), dtype=torch.float32)
+    out[:rows] = block
+    out = out.to(h16).view(64, 8, 8)
+    src = torch.arange(8)[None, :] ^ (torch.arange(64)[:, None] & 7)          # stored chunk j of row r = logical chunk j ^ (r & 7)
+    return torch.gather(out, 1, src[:, :, None].expand(64, 8, 8)).reshape(64, 64)
+
+
+def _dense_slabs(wp, h16, rows_per_block):
+    """[N, K] (already k-permuted) -> slabs in the order (row block, k tile)."""
+    N, K = wp.shape
+    return [_slab(wp[r0:r0 + rows_per_block, k0:k0 + 64], h16) for r0 in range(0, N, rows_per_block) for k0 in range(0, K, 64)]
+
+
+def pack_motion_stream(w, h16, heads=8):
+    """w: dict of fp32 tensors of one motion module at C = 320 -- proj_in/proj_out (.w [C,C], .b), attn1/attn2 (q, k, v, o weights, o bias),
+    ln1..3 (g, b), ff1 (w [8C, C], b), ff2 (w [C, 4C], b), pe [32, C].  Returns (stream [670, 64, 64] h16, params [16320] fp32) in the
+    consumption order of vv_motion.hip."""
+    C = w["proj_in.w"].shape[0]
+    D = C // heads
+    assert C == 320 and D == 40
+    slabs = _dense_slabs(_permute_k(w["proj_in.w"]), h16, 64)
+    for a in ("attn1", "attn2"):
+        for h in range(heads):
+            for nm in ("q", "k", "v"):
+                wh = torch.zeros((48, C))
+                wh[:D] = w[f"{a}.{nm}"][h * D:(h + 1) * D]
+                slabs += _dense_slabs(_permute_k(wh), h16, 48)
+            wo = torch.zeros((C, 64))
+            perm = _perm32()
+            wo[:, :32] = w[f"{a}.o"][:, h * D + perm]                      # k step 0: d = PERM32 (all < 32)
+            p = torch.arange(32)
+            e, lg = p & 7, p >> 3
+            d1 = 32 + 4 * lg + e                                           # k step 1: accumulator tile 2 (d = 32..47) + a zero tile
+            ok = (e < 4) & (d1 < D)
+            wo[:, 32 + p[ok]] = w[f"{a}.o"][:, h * D + d1[ok]]
+            slabs += _dense_slabs(wo, h16, 64)
+    inner = 4 * C
+    b1 = []
+    for c in range(inner // 64):
+        rows = []
+        for i in range(4):
+            rows += list(range(64 * c + 16 * i, 64 * c + 16 * i + 16)) + list(range(inner + 64 * c + 16 * i, inner + 64 * c + 16 * i + 16))
+        rows = torch.tensor(rows)
+        slabs += _dense_slabs(_permute_k(w["ff1.w"][rows]), h16, 64)
+        b1.append(w["ff1.b"][rows])
+        slabs += _dense_slabs(_permute_k(w["ff2.w"][:, 64 * c:64 * c + 64]), h16, 64)
+    slabs += _dense_slabs(_permute_k(w["proj_out.w"]), h16, 64)
+    stream = torch.stack(slabs)
+    params = torch.cat([w["proj_in.b"], w["ln1.g"], w["ln1.b"], w["attn1.ob"], w["ln2.g"], w["ln2.b"], w["attn2.ob"], w["ln3.g"], w["ln3.b"],
+                        torch.cat(b1), w["ff2.b"], w["proj_out.b"], w["pe"][:32].reshape(-1)]).float()
+    assert stream.shape[0] == 670 and params.numel() == 16320
+    return stream.contiguous(), params.contiguous()
