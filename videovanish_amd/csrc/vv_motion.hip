@@ -116,30 +116,42 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
     auto slab_mma = [&](const unsigned char* s, auto rt_tag, f32x4* acc /* [RT][2] */, const uint4 (&x0)[2], const uint4 (&x1)[2]) {
         constexpr int RT = decltype(rt_tag)::value;
         const int sw = li & 7;
+        // all fragment reads of the slab first (8 LDS reads in flight), then the MFMAs: with ONE wave per SIMD a read that is waited for
+        // right before its two MFMAs exposes the whole LDS latency every 32 matrix cycles
+        uint4 w[2][RT];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int off = ((kk * 4 + lg) ^ sw) << 4;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const uint4 w = *(const uint4*)(s + (rt * 16 + li) * 128 + off);
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) acc[rt * 2 + tt] = T::mfma(w, kk ? x1[tt] : x0[tt], acc[rt * 2 + tt]);
-            }
+            for (int rt = 0; rt < RT; ++rt) w[kk][rt] = *(const uint4*)(s + (rt * 16 + li) * 128 + off);
         }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) acc[rt * 2 + tt] = T::mfma(w[kk][rt], kk ? x1[tt] : x0[tt], acc[rt * 2 + tt]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * RT, 0);      // keep the reads together, ahead of the MFMAs (hipcc otherwise
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * RT, 0);      // re-serialises read -> wait -> 2 MFMAs to save registers)
     };
     // same with the operands exchanged: D = X * W^T (lane = output channel li, registers = tokens 4 lg + r): V^T for the attention
     auto slab_mma_t = [&](const unsigned char* s, f32x4* acc /* [3][2] */, const uint4 (&x0)[2], const uint4 (&x1)[2]) {
         const int sw = li & 7;
+        uint4 w[2][3];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int off = ((kk * 4 + lg) ^ sw) << 4;
 #pragma unroll
-            for (int rt = 0; rt < 3; ++rt) {
-                const uint4 w = *(const uint4*)(s + (rt * 16 + li) * 128 + off);
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) acc[rt * 2 + tt] = T::mfma(kk ? x1[tt] : x0[tt], w, acc[rt * 2 + tt]);
-            }
+            for (int rt = 0; rt < 3; ++rt) w[kk][rt] = *(const uint4*)(s + (rt * 16 + li) * 128 + off);
         }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) acc[rt * 2 + tt] = T::mfma(kk ? x1[tt] : x0[tt], w[kk][rt], acc[rt * 2 + tt]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
     };
     // full-width layer: t[20][2] (+)= W [320 x 320] * a   (5 row blocks x 5 k tiles = 25 slabs)
     auto dense320 = [&](f32x4 (&acc)[20][2]) {
