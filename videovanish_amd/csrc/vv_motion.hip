@@ -50,6 +50,23 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// two GELUs at once on packed fp32 math (v_pk_fma_f32)
+__device__ __forceinline__ vv_f32x2 gelu2(vv_f32x2 x) {
+    const vv_f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    const vv_f32x2 z = ax * 0.70710678118654752f;
+    const vv_f32x2 d = __builtin_elementwise_fma(z, (vv_f32x2){0.3275911f, 0.3275911f}, (vv_f32x2){1.0f, 1.0f});
+    const vv_f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    vv_f32x2 q = __builtin_elementwise_fma(t, (vv_f32x2){1.061405429f, 1.061405429f}, (vv_f32x2){-1.453152027f, -1.453152027f});
+    q = __builtin_elementwise_fma(q, t, (vv_f32x2){1.421413741f, 1.421413741f});
+    q = __builtin_elementwise_fma(q, t, (vv_f32x2){-0.284496736f, -0.284496736f});
+    q = __builtin_elementwise_fma(q, t, (vv_f32x2){0.254829592f, 0.254829592f});
+    q = q * t;
+    const vv_f32x2 ez = z * z * -1.4426950408889634f;
+    const vv_f32x2 e = {__builtin_amdgcn_exp2f(ez.x), __builtin_amdgcn_exp2f(ez.y)};
+    const vv_f32x2 erfc = q * e;                                       // 1 - erf(|x| / sqrt 2)
+    return __builtin_elementwise_fma(ax * 0.5f, (vv_f32x2){1.0f, 1.0f} - erfc, x * 0.5f);      // 0.5 x (1 + sign(x) (1 - erfc))
+}
+
 template <typename T>
 __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_params p) {
     __shared__ __attribute__((aligned(1024))) unsigned char ring[NSLOT * SLAB];
@@ -313,10 +330,10 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float4 bv = *(const float4*)(prm + P_B1 + c * 128 + (2 * i) * 16 + 4 * lg), bg = *(const float4*)(prm + P_B1 + c * 128 + (2 * i + 1) * 16 + 4 * lg);
-                hv[i][0] = (g[2 * i][tt][0] + bv.x) * gelu_fast(g[2 * i + 1][tt][0] + bg.x);
-                hv[i][1] = (g[2 * i][tt][1] + bv.y) * gelu_fast(g[2 * i + 1][tt][1] + bg.y);
-                hv[i][2] = (g[2 * i][tt][2] + bv.z) * gelu_fast(g[2 * i + 1][tt][2] + bg.z);
-                hv[i][3] = (g[2 * i][tt][3] + bv.w) * gelu_fast(g[2 * i + 1][tt][3] + bg.w);
+                const vv_f32x2 g01 = gelu2((vv_f32x2){g[2 * i + 1][tt][0] + bg.x, g[2 * i + 1][tt][1] + bg.y});
+                const vv_f32x2 g23 = gelu2((vv_f32x2){g[2 * i + 1][tt][2] + bg.z, g[2 * i + 1][tt][3] + bg.w});
+                hv[i][0] = (g[2 * i][tt][0] + bv.x) * g01.x; hv[i][1] = (g[2 * i][tt][1] + bv.y) * g01.y;
+                hv[i][2] = (g[2 * i][tt][2] + bv.z) * g23.x; hv[i][3] = (g[2 * i][tt][3] + bv.w) * g23.y;
             }
             hf0[tt] = frag(hv[0], hv[1]); hf1[tt] = frag(hv[2], hv[3]);
         }
