@@ -190,6 +190,7 @@ def main():
                     help="VAE decoder in one pass of h16 operands instead of split precision (3 MFMA passes per GEMM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--dump-kernels", default=None, help="write the raw per-kernel table (launches, seconds, flops, bytes) to this JSON file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -321,6 +322,8 @@ def main():
         "kernel_times_s": {k: [v[0], round(v[1], 3), round(v[2] / v[1] / 1e12, 1) if v[2] else round(v[3] / v[1] / 1e9, 1)] for k, v in
                            sorted(kernels.items(), key=lambda kv: -kv[1][1])},
     }
+    if args.dump_kernels:      # raw per-key table (launches, seconds, flops, algorithmic bytes); with VV_PROFILE_SHAPES=1 the GEMM keys carry M,N,K
+        json.dump(kernels, open(args.dump_kernels, "w"))
     print(json.dumps(res))
     if world > 1:
         import torch.distributed as td

@@ -204,12 +204,12 @@ def test_subvideo_propagation_matches_oracle(gpu):
     masks = []
     for t in range(T):
         m = np.zeros((H, W), np.uint8)
-        m[H // 4: H // 2, W // 4 + t: W // 2 + t] = 255
+        m[H // 4: 3 * H // 4, W // 4: 3 * W // 4] = 255      # static hole + sub-pixel flows: filling it needs long-range propagation
         masks.append(m)
     assert flowprop.subvideo_ranges(T, 4) == FP.subvideo_ranges(T, 4) == [(0, 9, 0, 4), (0, 13, 4, 8), (3, 13, 8, 12), (7, 13, 12, 13)]
     assert flowprop.subvideo_ranges(60, 50) == [(0, 55, 0, 50), (45, 60, 50, 60)] and flowprop.subvideo_ranges(50, 50) == [(0, 50, 0, 50)]
     g = torch.Generator().manual_seed(3)
-    fw = [torch.randn(2, H, W, generator=g) * 2 for _ in range(T - 1)]
+    fw = [torch.randn(2, H, W, generator=g) * 0.4 for _ in range(T - 1)]
     bw = [-f + 0.05 * torch.randn(2, H, W, generator=g) for f in fw]
     ref = [None] * T
     for (s, e, lo, hi) in FP.subvideo_ranges(T, 4):
