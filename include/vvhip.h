@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VV_ABI_VERSION 4
+#define VV_ABI_VERSION 5
 
 enum { VV_BF16 = 0, VV_F16 = 1, VV_F32 = 2, VV_U8 = 3 };
 enum { VV_OK = 0, VV_E_ARG = -1, VV_E_UNSUPPORTED = -2, VV_E_LAUNCH = -3 };
@@ -161,6 +161,10 @@ typedef struct {
     int64_t q_hs, k_hs, v_hs;         /* head strides (elements) of q / k / v; 0 = D (heads side by side inside a row).  The
                                          head-major QKV layout written by vv_conv_gemm's split_heads store uses
                                          hs = Nq*D, rs = D: a head's K/V rows are contiguous 2*D-byte records */
+    int32_t q_prescaled;              /* 1: q already holds scale * log2(e) * Q (folded into the query projection weights by the
+                                         caller, so the single h16 rounding of q covers it); the kernel then skips its own scaling.
+                                         The d = 40 spatial kernel subtracts the softmax reference maximum on the matrix pipe and
+                                         needs Q in that form: with q_prescaled = 0 it rescales (and re-rounds) Q itself */
 } vv_attn_params;
 int vv_attention(const vv_attn_params* host_p, int dtype, void* stream);
 

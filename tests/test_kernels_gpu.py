@@ -307,6 +307,46 @@ def test_attention_online_softmax_rescale(gpu):
     assert (got - ref).abs().max().item() <= 2 ** -6 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("dname,td,ulp", [("bf16", torch.bfloat16, 2 ** -8), ("fp16", torch.float16, 2 ** -11)])
+def test_attention_d40_lazy_reference_maximum(gpu, dname, td, ulp):
+    """The d = 40 spatial kernel subtracts a LAZY reference maximum on the matrix pipe (vv_attn.hip, LAZY): exercise what that adds --
+    q_prescaled (scale * log2 e folded into q before its one rounding), maxima that creep up by less than the lag the kernel tolerates,
+    maxima that jump by hundreds in a late tile, a first tile far BELOW the rest (the reference must still be set from it and then
+    rise), a ragged last tile, and rows past Nq."""
+    from videovanish_amd import hip
+    dt = hip.dtype_id(dname)
+    g = torch.Generator().manual_seed(11)
+    B, heads, N, D = 2, 8, 64 * 9 - 37, 40
+    C = heads * D
+    c = hip.attention_q_scale(D)
+    q = torch.randn(B, N, heads, D, generator=g)
+    k = torch.randn(B, N, heads, D, generator=g)
+    v = _r(torch.randn(B, N, heads, D, generator=g), td)
+    u = q[:, :1].mean(2, keepdim=True) * 0 + torch.randn(B, 1, heads, D, generator=g)      # a common direction per (b, head)
+    q = q + 2.0 * u                                                                          # every query likes keys along u
+    ramp = torch.linspace(-3.0, 3.0, N).view(1, N, 1, 1)                                     # key affinity creeps up tile after tile
+    k = k * 0.3 + u * ramp / (u * u).sum(-1, keepdim=True) * 4.0
+    k[:, :64] -= 3.0 * u[:, :1] * 1.0                                                        # first tile far below the rest
+    k[0, 500] = q[0, 17] * 5.0                                                               # one late key dominates some rows by a wide margin
+    k = _r(k, td)
+    for prescaled in (True, False):
+        qs = _r(q * c, td) if prescaled else _r(q, td)
+        s = torch.einsum("bqhd,bkhd->bhqk", qs.double(), k.double()) * (1.0 if prescaled else c)
+        pr = torch.exp2(s - s.amax(-1, keepdim=True))
+        ref = torch.einsum("bhqk,bkhd->bqhd", pr / pr.sum(-1, keepdim=True), v.double()).float()
+        hm = torch.stack([qs, k, v], 1).permute(0, 1, 3, 2, 4).contiguous().to(td).to(gpu)      # head-major, as the pipeline stores it
+        out = torch.empty(B, N, C, dtype=td, device=gpu)
+        hip.attention(dt, hm, hm, hm, out, B=B, heads=heads, Nq=N, Nkv=N, D=D, q_bs=3 * N * C, k_bs=3 * N * C, v_bs=3 * N * C, o_bs=N * C,
+                      q_rs=D, k_rs=D, v_rs=D, o_rs=C, k_off=N * C, v_off=2 * N * C, q_hs=N * D, k_hs=N * D, v_hs=N * D, q_prescaled=prescaled)
+        got = out.float().cpu().reshape(B, N, heads, D)
+        assert torch.isfinite(got).all()
+        spread = float((s.amax(-1) - s.amin(-1)).max())
+        assert spread > 60                                  # the case really spans far more than the h16 exponent range would forgive
+        # without q_prescaled the kernel re-rounds c*q: the scores (|s| up to hundreds here) then carry that second rounding
+        tol = (6 if prescaled else 64) * ulp * max(1.0, ref.abs().max().item())
+        assert (got - ref).abs().max().item() <= tol, (prescaled, (got - ref).abs().max().item(), tol)
+
+
 def test_elementwise(gpu):
     from videovanish_amd import hip
     g = torch.Generator().manual_seed(8)

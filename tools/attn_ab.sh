@@ -1,4 +1,4 @@
-for v in 0 20 21 22; do echo "== VV_ATTN_VARIANT=$v"; VV_ATTN_VARIANT=$v python - <<'PY'
+for v in ${VARIANTS:-0 30}; do echo "== VV_ATTN_VARIANT=$v"; VV_ATTN_VARIANT=$v python - <<'PY'
 import sys, os
 sys.path.insert(0, os.getcwd())
 import torch
@@ -17,7 +17,7 @@ for dname in ("bf16", "fp16"):
     B, heads, N, D = 8, 8, 14400, 40
     C = heads * D
     g = torch.Generator().manual_seed(0)
-    qkv = (torch.randn(B, 3, heads, N, D, generator=g) * 1.0).to(td).to(dev)       # head-major layout as the pipeline uses it
+    qkv = (torch.randn(B, 3, heads, N, D, generator=g) * float(os.environ.get("QSCALE", "1.0"))).to(td).to(dev)       # head-major layout as the pipeline uses it
     out = torch.empty(B * N, C, dtype=td, device=dev)
     fn = lambda: hip.attention(DT, qkv, qkv, qkv, out, B=B, heads=heads, Nq=N, Nkv=N, D=D, q_bs=N * 3 * C, k_bs=N * 3 * C, v_bs=N * 3 * C,
                                o_bs=N * C, q_rs=D, k_rs=D, v_rs=D, o_rs=C, k_off=N * C, v_off=2 * N * C, q_hs=N * D, k_hs=N * D, v_hs=N * D)

@@ -31,7 +31,16 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
 // softmax of tile k, ONE barrier per tile, no staging registers); DMA = false: register staged through dynamic LDS.
 // KIND only names the instantiation (0 spatial self-attention, 1 cross-attention to the text tokens; temporal attention has its own
 // tile shape): profilers then report the launches of each use separately (profiles/*_kernel_stats.csv).
-template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0>
+//
+// LAZY = true (needs DMA and a spare K-dim pad slot, i.e. D % 32 != 0): the softmax reference maximum is subtracted ON THE MATRIX PIPE and
+// is only refreshed when it is about to matter.  Q is held pre-multiplied by scale * log2(e); the first two zero-padded k slots of
+// every Q row carry -m split into hi + lo h16 parts and the same slots of every K row are 1.0 (written once, the LDS-DMA never touches
+// them), so the QK^T MFMAs deliver x = c q.k - m directly and P = exp2(x) needs neither the per-tile row maximum (13 v_max per 16
+// queries) nor the scale-and-shift (8 v_pk_fma).  m is allowed to lag the true running maximum by < 1 (P < 2: harmless in h16, the
+// denominator rides the ONES column of V in fp32): a tile whose packed P has any value >= 2.0 -- one OR tree over the packed registers,
+// bit 14 is the top exponent bit of both h16 formats -- takes the slow path (wave-uniform branch: QK^T again, classic maximum, rescale
+// of O^T, new pad slots).  Tile 0 always takes it.  Results equal the classic form up to the rounding of c*q to h16.
+template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0, bool LAZY = false>
 __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params p, const int nqt) {
     constexpr int DK = (D + 31) / 32 * 32, DKC = DK / 8, KS = DK / 32;
     constexpr int DV = (D + 15) / 16 * 16, DVC = DV / 8, NDT = DV / 16;
@@ -43,6 +52,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
     // spare zero-padded V column (d = 40 -> 48): put 1.0 there, then row D of O^T accumulates sum_k P = the softmax
     // denominator on the MATRIX pipe instead of 16 packed adds per tile on the (issue-bound) VALU
     constexpr bool ONES = DV > D;
+    static_assert(!LAZY || (DMA && ONES && DK - D >= 2 && D % 8 == 0), "LAZY needs the DMA path, the ONES column and two spare k slots");
+    constexpr int PS = D / 32, PLG = (D % 32) / 8;       // LAZY: the pad slots D, D+1 live in qf[.][PS].x of the lanes with lg == PLG
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sK = smem;
     unsigned char* sV = smem + KVT * PK;
@@ -83,6 +94,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
         for (int s = 0; s < KS; ++s) {
             const int q = q0 + j * 16 + li, d0 = s * 32 + lg * 8;
             qf[j][s] = (q < p.Nq && d0 < D) ? *(const uint4*)(Q + (int64_t)q * p.q_rs + d0) : make_uint4(0, 0, 0, 0);
+            if (LAZY && !p.q_prescaled) {
+                float qv[8];
+                unpack8<T>(qf[j][s], qv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qv[e] *= p.scale * 1.4426950408889634f;
+                qf[j][s] = pack8<T>(qv);
+            }
         }
 
     f32x4 oacc[NDT][QT];
@@ -92,8 +110,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
         for (int j = 0; j < QT; ++j) oacc[d][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float mrun[QT], lrun[QT];
 #pragma unroll
-    for (int j = 0; j < QT; ++j) { mrun[j] = -1e30f; lrun[j] = 0.f; }
-    const float c = p.scale * 1.4426950408889634f;
+    for (int j = 0; j < QT; ++j) { mrun[j] = LAZY ? 0.f : -1e30f; lrun[j] = 0.f; }
+    const float c = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
 
     uint4 rk[KCH], rv[VCH];
     auto load_kv = [&](int kv0) {
@@ -136,31 +154,106 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
 
         // ---- S^T = K Q^T
         f32x4 sacc[KT][QT];
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int j = 0; j < QT; ++j) sacc[kt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                const uint4 kf = *(const uint4*)(sK + (kt * 16 + li) * PK + (s * 4 + lg) * 16);
-#pragma unroll
-                for (int j = 0; j < QT; ++j) sacc[kt][j] = T::mfma(kf, qf[j][s], sacc[kt][j]);
-            }
-        }
-        if (MASK) {
+        auto qk = [&]() {
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kv0 + kt * 16 + lg * 4 + r >= p.Nkv) {
+                for (int j = 0; j < QT; ++j) sacc[kt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int j = 0; j < QT; ++j) sacc[kt][j][r] = -1e30f;
-                    }
-        }
-        // ---- online softmax (per query column = per lane, replicated over the 4 lane groups)
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const uint4 kf = *(const uint4*)(sK + (kt * 16 + li) * PK + (s * 4 + lg) * 16);
+#pragma unroll
+                    for (int j = 0; j < QT; ++j) sacc[kt][j] = T::mfma(kf, qf[j][s], sacc[kt][j]);
+                }
+            }
+            if (MASK) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kv0 + kt * 16 + lg * 4 + r >= p.Nkv) {
+#pragma unroll
+                            for (int j = 0; j < QT; ++j) sacc[kt][j][r] = -1e30f;
+                        }
+            }
+        };
         uint4 pb[US][QT];
+        // ---- O^T += V^T P^T   (A = V^T via transposed LDS reads; k-slot order matches the packing of pb)
+        auto pv = [&]() {
+#pragma unroll
+            for (int u = 0; u < US; ++u) {
+#pragma unroll
+                for (int d = 0; d < NDT; ++d) {
+                    const unsigned char* a0 = sV + (u * 32 + 4 * lg + (li >> 2)) * PV + (d * 16 + 4 * (li & 3)) * 2;
+                    const uint2 lo = ds_read_tr16(a0);
+                    const uint2 hi = ds_read_tr16(a0 + 16 * PV);
+                    const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                    for (int j = 0; j < QT; ++j) oacc[d][j] = T::mfma(vf, pb[u][j], oacc[d][j]);
+                }
+            }
+        };
+        qk();
+        if constexpr (LAZY) {
+            // ---- fast path: x = c q.k - m came off the matrix pipe; P = exp2(x), packed
+            unsigned any = 0;
+#pragma unroll
+            for (int j = 0; j < QT; ++j) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[kt][j][r] = __builtin_amdgcn_exp2f(sacc[kt][j][r]);
+#pragma unroll
+                for (int u = 0; u < US; ++u) {
+                    pb[u][j] = make_uint4(pack2<T>(sacc[2 * u][j][0], sacc[2 * u][j][1]), pack2<T>(sacc[2 * u][j][2], sacc[2 * u][j][3]),
+                                          pack2<T>(sacc[2 * u + 1][j][0], sacc[2 * u + 1][j][1]), pack2<T>(sacc[2 * u + 1][j][2], sacc[2 * u + 1][j][3]));
+                    any |= pb[u][j].x | pb[u][j].y | pb[u][j].z | pb[u][j].w;
+                }
+            }
+            const bool slow = it == 0 || __builtin_amdgcn_ballot_w64((any & 0x40004000u) != 0) != 0;      // wave-uniform
+            if (slow) {
+                qk();          // the scores again (relative to the old m; tile 0: m = 0)
+#pragma unroll
+                for (int j = 0; j < QT; ++j) {
+                    float mx = sacc[0][j][0];
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kt][j][r]);
+                    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), (16 << 10) | 0x1f)));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    if (it != 0) mx = fmaxf(mx, 0.f);                      // the reference only ever rises
+                    // new reference = the h16 hi + lo pair nearest to m + mx; the shift applied now is the difference of the two
+                    // REPRESENTED references, so this tile, the rescaled O^T and every later tile agree exactly
+                    const float target = mrun[j] + mx;
+                    const unsigned short hi = T::from_f32(-target);
+                    const unsigned short lo = T::from_f32(-target - T::to_f32(hi));
+                    const float mnew = -(T::to_f32(hi) + T::to_f32(lo));
+                    const float shift = mnew - mrun[j];
+                    mrun[j] = mnew;
+                    if (lg == PLG) qf[j][PS].x = (unsigned)hi | ((unsigned)lo << 16);
+                    if (it != 0) {
+                        const float alpha = __builtin_amdgcn_exp2f(-shift);
+#pragma unroll
+                        for (int d = 0; d < NDT; ++d) oacc[d][j] *= alpha;
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sacc[kt][j][r] = __builtin_amdgcn_exp2f(sacc[kt][j][r] - shift);
+#pragma unroll
+                    for (int u = 0; u < US; ++u)
+                        pb[u][j] = make_uint4(pack2<T>(sacc[2 * u][j][0], sacc[2 * u][j][1]), pack2<T>(sacc[2 * u][j][2], sacc[2 * u][j][3]),
+                                              pack2<T>(sacc[2 * u + 1][j][0], sacc[2 * u + 1][j][1]), pack2<T>(sacc[2 * u + 1][j][2], sacc[2 * u + 1][j][3]));
+                }
+                pv();
+            } else {
+                pv();      // (the PV MFMAs are duplicated into both arms so that O^T stays in place: no phi copies of 24 registers per tile)
+            }
+        } else {
+        // ---- online softmax (per query column = per lane, replicated over the 4 lane groups)
 #pragma unroll
         for (int j = 0; j < QT; ++j) {
             float mx = sacc[0][j][0];
@@ -201,19 +294,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
                 pb[u][j] = make_uint4(pack2<T>(sacc[2 * u][j][0], sacc[2 * u][j][1]), pack2<T>(sacc[2 * u][j][2], sacc[2 * u][j][3]),
                                       pack2<T>(sacc[2 * u + 1][j][0], sacc[2 * u + 1][j][1]), pack2<T>(sacc[2 * u + 1][j][2], sacc[2 * u + 1][j][3]));
         }
-        // ---- O^T += V^T P^T   (A = V^T via transposed LDS reads; k-slot order matches the packing of pb)
-#pragma unroll
-        for (int u = 0; u < US; ++u) {
-#pragma unroll
-            for (int d = 0; d < NDT; ++d) {
-                const unsigned char* a0 = sV + (u * 32 + 4 * lg + (li >> 2)) * PV + (d * 16 + 4 * (li & 3)) * 2;
-                const uint2 lo = ds_read_tr16(a0);
-                const uint2 hi = ds_read_tr16(a0 + 16 * PV);
-                const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-#pragma unroll
-                for (int j = 0; j < QT; ++j) oacc[d][j] = T::mfma(vf, pb[u][j], oacc[d][j]);
-            }
         }
+        if constexpr (!LAZY) pv();
     };
     const bool ragged = (p.Nkv % KVT) != 0;
     if constexpr (DMA) {
@@ -227,7 +309,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
             const int sidx = i * NT + t, row = sidx / (PK / 16), ch = sidx - row * (PK / 16);
             kdata[i] = ch * 8 < D && sidx < NSK;
             koff[i] = (unsigned)(row * (int)p.k_rs + ch * 8) * 2u;
-            if (sidx < NSK) { *(uint4*)(dK0 + sidx * 16) = make_uint4(0, 0, 0, 0); *(uint4*)(dK1 + sidx * 16) = make_uint4(0, 0, 0, 0); }
+            if (sidx < NSK) {
+                const unsigned one2 = (unsigned)T::from_f32(1.0f) * 0x10001u;      // LAZY: K[key][D] = K[key][D+1] = 1 (multiplies the -m slots of Q)
+                const uint4 fill = make_uint4((LAZY && ch * 8 == D) ? one2 : 0u, 0, 0, 0);
+                *(uint4*)(dK0 + sidx * 16) = fill; *(uint4*)(dK1 + sidx * 16) = fill;
+            }
         }
 #pragma unroll
         for (int i = 0; i < VP; ++i) {
@@ -245,18 +331,20 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
         auto dma_issue = [&](unsigned char* bK, unsigned char* bV, auto check_tag) {
             constexpr bool CHECK = decltype(check_tag)::value;      // ragged last tile: rows past Nkv keep the stale (finite) tile
             const int kv0 = issued * KVT;
+            // tile base = wave-uniform pointer (SGPR pair), per-lane part = a constant 32-bit offset: the DMA takes the saddr + voffset
+            // form and the loop carries no per-lane address arithmetic
+            const unsigned char* kt = (const unsigned char*)Kp + (size_t)issued * kstep;
+            const unsigned char* vt = (const unsigned char*)Vp + (size_t)issued * vstep;
 #pragma unroll
             for (int i = 0; i < KP; ++i) {
                 if (NSK % NT == 0 || i * NT + wave * 64 < NSK) {
-                    if (kdata[i] && (!CHECK || kv0 + (i * NT + t) / (PK / 16) < p.Nkv)) glds16((const unsigned char*)Kp + koff[i], bK + (i * NT + wave * 64) * 16);
-                    koff[i] += kstep;
+                    if (kdata[i] && (!CHECK || kv0 + (i * NT + t) / (PK / 16) < p.Nkv)) glds16(kt + koff[i], bK + (i * NT + wave * 64) * 16);
                 }
             }
 #pragma unroll
             for (int i = 0; i < VP; ++i) {
                 if (NSV % NT == 0 || i * NT + wave * 64 < NSV) {
-                    if (vdata[i] && (!CHECK || kv0 + (i * NT + t) / (PV / 16) < p.Nkv)) glds16((const unsigned char*)Vp + voff[i], bV + (i * NT + wave * 64) * 16);
-                    voff[i] += vstep;
+                    if (vdata[i] && (!CHECK || kv0 + (i * NT + t) / (PV / 16) < p.Nkv)) glds16(vt + voff[i], bV + (i * NT + wave * 64) * 16);
                 }
             }
             ++issued;
@@ -394,7 +482,7 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(const vv_attn_param
     float mrun[QT], lrun[QT];
 #pragma unroll
     for (int j = 0; j < QT; ++j) { mrun[j] = -1e30f; lrun[j] = 0.f; }
-    const float c = p.scale * 1.4426950408889634f;
+    const float c = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
     const int ntiles = (p.Nkv + KVT - 1) / KVT;
     const bool ragged = (p.Nkv % KVT) != 0;
 
@@ -616,7 +704,7 @@ int attn_pipe_launch(const vv_attn_params& p, hipStream_t st) {
     return VV_OK;
 }
 
-template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0>
+template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0, bool LAZY = false>
 int attn_launch(const vv_attn_params& p, hipStream_t st) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
     constexpr int PK = DK * 2 + 32, PV = DV * 2 + ((DV * 2) % 64 == 0 ? 32 : 0);   // conflict-free ds_read_b128 / ds_read_b64_tr_b16 (bank model: tools/lds_bank_model.py)
@@ -625,7 +713,7 @@ int attn_launch(const vv_attn_params& p, hipStream_t st) {
     const int nqt = (p.Nq + BQ - 1) / BQ;
     const int64_t nblk = (int64_t)p.B * p.heads * nqt;
     if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_attention: grid too large");
-    auto kern = attn_kernel<T, D, QT, KVT, NW, PREFETCH, OCC, DMA, KIND>;
+    auto kern = attn_kernel<T, D, QT, KVT, NW, PREFETCH, OCC, DMA, KIND, LAZY>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -668,6 +756,16 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
 #endif
             // default for d <= 64: K/V by LDS-DMA, double buffered, 3 waves/SIMD (d = 80 would spill: stays register staged)
             const bool cross = p.Nkv < 128 && p.Nq != p.Nkv;
+            if constexpr (D == 40) {      // lazy reference maximum on the matrix pipe (spare k slots 40, 41)
+#ifdef VV_AB
+                if (var == 30) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0>(p, st);      // classic online softmax
+                if (var == 31) return attn_launch<T, D, 4, 64, 4, false, 2, true, 0, true>(p, st);      // lazy, 64 queries per wave, 2 waves/SIMD
+                if (var == 32) return attn_launch<T, D, 4, 64, 2, false, 4, true, 0, true>(p, st);      // lazy, 64 queries per wave, 2-wave blocks
+                if (var == 34) return attn_launch<T, D, 2, 32, 4, false, 4, true, 0, true>(p, st);      // lazy, 32-key tiles, 128-VGPR cap (4 waves/SIMD)
+                if (var == 33) return attn_launch<T, D, 2, 64, 2, false, 6, true, 0, true>(p, st);      // lazy, 2-wave blocks (6 blocks per CU)
+#endif
+                if (!cross) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true>(p, st);
+            }
             if (D <= 64) return cross ? attn_launch<T, D, 2, 64, 4, false, 3, true, 1>(p, st) : attn_launch<T, D, 2, 64, 4, false, 3, true, 0>(p, st);
             return cross ? attn_launch<T, D, 2, 64, 4, true, 1, false, 1>(p, st) : attn_launch<T, D, 2, 64, 4, true, 1, false, 0>(p, st);
         }

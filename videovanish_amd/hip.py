@@ -11,7 +11,7 @@ import torch
 BF16, F16, F32, U8 = 0, 1, 2, 3
 EPI_NONE, EPI_GEGLU = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 _DT = {"bf16": BF16, "fp16": F16}
 _TORCH_H16 = {BF16: torch.bfloat16, F16: torch.float16}
 
@@ -73,7 +73,7 @@ class AttnParams(C.Structure):
                 ("q_bs", C.c_int64), ("k_bs", C.c_int64), ("v_bs", C.c_int64), ("o_bs", C.c_int64),
                 ("q_rs", C.c_int64), ("k_rs", C.c_int64), ("v_rs", C.c_int64), ("o_rs", C.c_int64),
                 ("B", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nkv", C.c_int32), ("D", C.c_int32),
-                ("scale", C.c_float), ("q_hs", C.c_int64), ("k_hs", C.c_int64), ("v_hs", C.c_int64)]
+                ("scale", C.c_float), ("q_hs", C.c_int64), ("k_hs", C.c_int64), ("v_hs", C.c_int64), ("q_prescaled", C.c_int32)]
 
 
 EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name", "vv_conv_gemm", "vv_groupnorm_nsplit",
@@ -245,14 +245,20 @@ def layernorm(dtype, x, gamma, beta, pe=None, rows_per_frame=1):
     return out
 
 
+def attention_q_scale(D):
+    """factor a caller folds into its query projection for vv_attention(q_prescaled=1): softmax scale * log2(e)."""
+    return float(D) ** -0.5 * 1.4426950408889634
+
+
 def attention(dtype, q, k, v, out, *, B, heads, Nq, Nkv, D, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, q_off=0, k_off=0, v_off=0,
-              q_hs=0, k_hs=0, v_hs=0):
-    """q/k/v/out: h16 tensors (any shape); element offsets *_off select a column block inside a fused QKV buffer."""
+              q_hs=0, k_hs=0, v_hs=0, q_prescaled=False):
+    """q/k/v/out: h16 tensors (any shape); element offsets *_off select a column block inside a fused QKV buffer.
+    q_prescaled: q already carries D**-0.5 * log2(e) (attention_q_scale(D) folded into the query projection)."""
     _need_cuda(q, k, v, out)
     es = 2
     p = AttnParams(q=q.data_ptr() + q_off * es, k=k.data_ptr() + k_off * es, v=v.data_ptr() + v_off * es, o=out.data_ptr(),
                    q_bs=q_bs, k_bs=k_bs, v_bs=v_bs, o_bs=o_bs, q_rs=q_rs, k_rs=k_rs, v_rs=v_rs, o_rs=o_rs, B=B, heads=heads, Nq=Nq,
-                   Nkv=Nkv, D=D, scale=float(D) ** -0.5, q_hs=q_hs, k_hs=k_hs, v_hs=v_hs)
+                   Nkv=Nkv, D=D, scale=float(D) ** -0.5, q_hs=q_hs, k_hs=k_hs, v_hs=v_hs, q_prescaled=1 if q_prescaled else 0)
     kind = "temporal" if (Nq <= 32 and Nkv <= 32) else ("cross" if Nkv < 128 and Nq != Nkv else "spatial")
     if os.environ.get("VV_PROFILE_SHAPES"):
         kind = f"B{B},N{Nq}|" + kind

@@ -209,11 +209,17 @@ class ResBlock:
 class SelfAttention:
     """attn with fused QKV projection (no bias) + output projection (bias) + residual."""
 
-    def __init__(self, ctx, name, C, heads, qkv_bias=False, precise=False):
+    def __init__(self, ctx, name, C, heads, qkv_bias=False, precise=False, prescale_q=False):
         self.ctx, self.C, self.heads, self.precise = ctx, C, heads, precise
+        # prescale_q (spatial use only): softmax scale * log2(e) folded into the fp32 query weights BEFORE their one rounding to h16,
+        # so the attention kernel gets c*q at the same precision as q (vv_attention, q_prescaled; the d = 40 kernel wants it)
+        self.prescale_q = bool(prescale_q) and not precise
         ws, bs = [], []
         for n in ("to_q", "to_k", "to_v"):
             w, b = ctx.src.linear(f"{name}.{n}", C, C, 1.0, qkv_bias)
+            if n == "to_q" and self.prescale_q:
+                w = w * hip.attention_q_scale(C // heads)
+                b = b * hip.attention_q_scale(C // heads) if b is not None else None
             ws.append(w); bs.append(b)
         self.qkv = Linear(ctx, weight=torch.cat(ws, 0), bias_t=torch.cat(bs, 0) if qkv_bias else None, precise=precise)
         self.out = Linear(ctx, name + ".to_out.0", C, C, precise=precise)
@@ -235,11 +241,12 @@ class SelfAttention:
         o = torch.empty((B * N, C), dtype=self.ctx.h16, device=n.device)
         hip.attention(dt, qkv, qkv, qkv, o, B=B, heads=self.heads, Nq=N, Nkv=N, D=D, q_bs=N * 3 * C, k_bs=N * 3 * C,
                       v_bs=N * 3 * C, o_bs=N * C, q_rs=D, k_rs=D, v_rs=D, o_rs=C, k_off=N * C, v_off=2 * N * C,
-                      q_hs=N * D, k_hs=N * D, v_hs=N * D)
+                      q_hs=N * D, k_hs=N * D, v_hs=N * D, q_prescaled=self.prescale_q)
         return self.out(o, res0=res)
 
     def temporal(self, n, res, Fr, HW, res1=None):
         """sequence = frames; rows of the [F*HW, 3C] QKV matrix gathered with stride HW*3C inside the kernel."""
+        assert not self.prescale_q
         C, dt = self.C, self.ctx.dt
         # (a per-pixel head-major QKV -- split_tokens < 0 -- makes this core 15 % faster but scatters the QKV GEMM's stores over
         # records 3*C*F elements apart: +9 % on that GEMM, a net loss; measured in profiles/r1_gemm_ab.txt)
@@ -291,7 +298,7 @@ class SpatialTransformer:
         self.proj_in = Conv(ctx, name + ".proj_in", C, C, k=1)
         b = name + ".transformer_blocks.0"
         self.n1, self.n2, self.n3 = (LayerNorm(ctx, f"{b}.norm{i}", C) for i in (1, 2, 3))
-        self.attn1 = SelfAttention(ctx, b + ".attn1", C, cfg.heads)
+        self.attn1 = SelfAttention(ctx, b + ".attn1", C, cfg.heads, prescale_q=(C // cfg.heads == 40))
         self.attn2 = CrossAttention(ctx, b + ".attn2", C, cfg.heads, text_h16)
         self.ff = FeedForward(ctx, b + ".ff", C)
         self.proj_out = Conv(ctx, name + ".proj_out", C, C, k=1)
