@@ -27,6 +27,14 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gp_t)gptr, (lp_t)lds_wave_base, 16, 0, 0);
 }
 
+__device__ __forceinline__ void glds16_asm(const void* gptr, void* lds_wave_base) {
+    typedef void __attribute__((address_space(3))) * lp_t;
+    const unsigned dst = (unsigned)(size_t)(lp_t)lds_wave_base;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gptr), "s"(dst) : "memory");
+}
+
 // DMA = true: K/V tiles go global -> LDS by LDS-DMA into two static buffers (tile k+1 in flight during the MFMAs and the
 // softmax of tile k, ONE barrier per tile, no staging registers); DMA = false: register staged through dynamic LDS.
 // KIND only names the instantiation (0 spatial self-attention, 1 cross-attention to the text tokens; temporal attention has its own
@@ -40,7 +48,7 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
 // denominator rides the ONES column of V in fp32): a tile whose packed P has any value >= 2.0 -- one OR tree over the packed registers,
 // bit 14 is the top exponent bit of both h16 formats -- takes the slow path (wave-uniform branch: QK^T again, classic maximum, rescale
 // of O^T, new pad slots).  Tile 0 always takes it.  Results equal the classic form up to the rounding of c*q to h16.
-template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0, bool LAZY = false>
+template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0, bool LAZY = false, int HACK = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params p, const int nqt) {
     constexpr int DK = (D + 31) / 32 * 32, DKC = DK / 8, KS = DK / 32;
     constexpr int DV = (D + 15) / 16 * 16, DVC = DV / 8, NDT = DV / 16;
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
                 for (int kt = 0; kt < KT; ++kt) {
                     const uint4 kf = *(const uint4*)(sK + (kt * 16 + li) * PK + (s * 4 + lg) * 16);
 #pragma unroll
-                    for (int j = 0; j < QT; ++j) sacc[kt][j] = T::mfma(kf, qf[j][s], sacc[kt][j]);
+                    for (int j = 0; j < QT; ++j) { if (HACK == 4) sacc[kt][j][0] += __builtin_bit_cast(float, kf.x ^ qf[j][s].x) * 1e-30f; else sacc[kt][j] = T::mfma(kf, qf[j][s], sacc[kt][j]); }
                 }
             }
             if (MASK) {
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
                     const uint2 hi = ds_read_tr16(a0 + 16 * PV);
                     const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
 #pragma unroll
-                    for (int j = 0; j < QT; ++j) oacc[d][j] = T::mfma(vf, pb[u][j], oacc[d][j]);
+                    for (int j = 0; j < QT; ++j) { if (HACK == 3) oacc[d][j][0] += __builtin_bit_cast(float, vf.x ^ pb[u][j].x); else oacc[d][j] = T::mfma(vf, pb[u][j], oacc[d][j]); }
                 }
             }
         };
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc[kt][j][r] = __builtin_amdgcn_exp2f(sacc[kt][j][r]);
+                    for (int r = 0; r < 4; ++r) sacc[kt][j][r] = HACK == 2 ? sacc[kt][j][r] * 0.01f : __builtin_amdgcn_exp2f(sacc[kt][j][r]);
 #pragma unroll
                 for (int u = 0; u < US; ++u) {
                     pb[u][j] = make_uint4(pack2<T>(sacc[2 * u][j][0], sacc[2 * u][j][1]), pack2<T>(sacc[2 * u][j][2], sacc[2 * u][j][3]),
@@ -351,8 +359,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
         };
         auto step = [&](const int it, unsigned char* cK, unsigned char* cV, unsigned char* nK, unsigned char* nV) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of tile `it` has landed
-            __syncthreads();                                      // ... everybody's has, and everybody is done with tile it-1
-            if (it + 1 < ntiles) {
+            if (HACK != 1) __syncthreads();                       // ... everybody's has, and everybody is done with tile it-1
+            if (it + 1 < ntiles && HACK != 5) {
                 if (ragged && it + 2 == ntiles) dma_issue(nK, nV, std::true_type{});
                 else dma_issue(nK, nV, std::false_type{});
             }
@@ -422,13 +430,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
 // kernel to 256 VGPRs with spills, i.e. 2 waves per SIMD without the intra-wave overlap that was to pay for the lost wave.  K tiles are DMA'd two tiles ahead and V tiles
 // one ahead into 3-slot rings; the LDS-DMA is issued from inline asm (hipcc then orders no ds_read behind it) and every wait is
 // the hand-placed vmcnt(0) + s_barrier at the end of a step.  2 waves per SIMD (the second S tile and the deferred P cost 48 VGPRs).
-__device__ __forceinline__ void glds16_asm(const void* gptr, void* lds_wave_base) {
-    typedef void __attribute__((address_space(3))) * lp_t;
-    const unsigned dst = (unsigned)(size_t)(lp_t)lds_wave_base;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gptr), "s"(dst) : "memory");
-}
 
 template <typename T, int D, int OCC, int KIND, int HINT = 0>
 __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(const vv_attn_params p, const int nqt) {
@@ -704,7 +705,7 @@ int attn_pipe_launch(const vv_attn_params& p, hipStream_t st) {
     return VV_OK;
 }
 
-template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0, bool LAZY = false>
+template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0, bool LAZY = false, int HACK = 0>
 int attn_launch(const vv_attn_params& p, hipStream_t st) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
     constexpr int PK = DK * 2 + 32, PV = DV * 2 + ((DV * 2) % 64 == 0 ? 32 : 0);   // conflict-free ds_read_b128 / ds_read_b64_tr_b16 (bank model: tools/lds_bank_model.py)
@@ -713,7 +714,7 @@ int attn_launch(const vv_attn_params& p, hipStream_t st) {
     const int nqt = (p.Nq + BQ - 1) / BQ;
     const int64_t nblk = (int64_t)p.B * p.heads * nqt;
     if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_attention: grid too large");
-    auto kern = attn_kernel<T, D, QT, KVT, NW, PREFETCH, OCC, DMA, KIND, LAZY>;
+    auto kern = attn_kernel<T, D, QT, KVT, NW, PREFETCH, OCC, DMA, KIND, LAZY, HACK>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -761,6 +762,15 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
                 if (var == 30) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0>(p, st);      // classic online softmax
                 if (var == 31) return attn_launch<T, D, 4, 64, 4, false, 2, true, 0, true>(p, st);      // lazy, 64 queries per wave, 2 waves/SIMD
                 if (var == 32) return attn_launch<T, D, 4, 64, 2, false, 4, true, 0, true>(p, st);      // lazy, 64 queries per wave, 2-wave blocks
+                if (var == 41) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true, 1>(p, st);      // timing probes (WRONG results): no barrier
+                if (var == 42) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true, 2>(p, st);      // ... no exp
+                if (var == 43) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true, 3>(p, st);      // ... no PV MFMAs
+                if (var == 44) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true, 4>(p, st);      // ... no QK MFMAs
+                if (var == 45) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true, 5>(p, st);      // ... no DMA
+                if (var == 35) return attn_launch<T, D, 2, 32, 8, false, 2, true, 0, true>(p, st);      // lazy, 8 waves (256 queries per block), 32-key tiles, 4 waves/SIMD
+                if (var == 36) return attn_launch<T, D, 2, 64, 8, false, 1, true, 0, true>(p, st);      // lazy, 8 waves, 64-key tiles, 2 waves/SIMD
+                if (var == 37) return attn_launch<T, D, 2, 64, 6, false, 2, true, 0, true>(p, st);      // lazy, 6 waves (192 queries per block), 3 waves/SIMD
+                if (var == 38) return attn_launch<T, D, 2, 64, 12, false, 1, true, 0, true>(p, st);     // lazy, 12 waves (384 queries per block), 3 waves/SIMD
                 if (var == 34) return attn_launch<T, D, 2, 32, 4, false, 4, true, 0, true>(p, st);      // lazy, 32-key tiles, 128-VGPR cap (4 waves/SIMD)
                 if (var == 33) return attn_launch<T, D, 2, 64, 2, false, 6, true, 0, true>(p, st);      // lazy, 2-wave blocks (6 blocks per CU)
 #endif
