@@ -1,0 +1,35 @@
+/* libvvio.so -- host-side frame codec of the MI355X VideoVanish build (plain C, no GPU): FFV1 version 3 (RFC 9043), 8-bit RGB
+ * (JPEG 2000 RCT), Golomb-Rice coder, intra only, slice CRCs -- the codec the reference writes with
+ * cv2.VideoWriter(fourcc "FFV1") (reference tools.py:28-45) and reads back with cv2.VideoCapture (tools.py:4-25).
+ * The Matroska container is written / parsed in Python (videovanish_amd/frameio.py); these entry points code single frames.
+ * Source: videovanish_amd/csrc/vv_ffv1.c (built by csrc/build.sh with gcc); binding: videovanish_amd/frameio.py (ctypes).
+ * Conventions: caller-owned buffers, no global state, thread safe, negative return = error. */
+#ifndef VVIO_H
+#define VVIO_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VVIO_ABI_VERSION 1
+int vvio_abi_version(void);
+
+/* FFV1 configuration record (the Matroska CodecPrivate payload after the BITMAPINFOHEADER; RFC 9043 section 4.2) for RGB24 frames cut
+ * into num_v_slices horizontal slices.  Returns the record length, or -1 if cap is too small. */
+int vvio_ffv1_config_record(int num_v_slices, uint8_t* out, int cap);
+
+/* One RGB24 frame ([H][W][3], what tools.load_video_frames_from_path returns per frame) -> one FFV1 packet (key frame).
+ * Returns the packet size, or -1 (buffer too small: cap >= 2 * W * H * 3 + 4096 is always enough).  Replaces VideoWriter.write
+ * (reference tools.py:43). */
+int vvio_ffv1_encode_frame(const uint8_t* rgb, int W, int H, int num_v_slices, uint8_t* out, int cap);
+
+/* FFV1 packet + configuration record -> RGB24 (W*H*3 bytes).  Accepts what this encoder writes and the subset of FFV1 v3 streams with the
+ * same parameters (8-bit RGB, Golomb-Rice sample coding = coder_type 0, any slice grid, 3- or 5-input quantisation tables, CRC on or off;
+ * range-coded sample data is refused with an error).
+ * 0 = ok, negative = error code.  Replaces VideoCapture.read (reference tools.py:17-21). */
+int vvio_ffv1_decode_frame(const uint8_t* cfg, int cfglen, const uint8_t* data, int len, int W, int H, uint8_t* rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

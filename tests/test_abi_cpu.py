@@ -36,6 +36,19 @@ def test_binding_lists_match_header(lib):
     assert lib.vv_abi_version() == hip.ABI_VERSION == 5
 
 
+def test_vvio_header_symbols_are_exported():
+    """include/vvio.h (frame codec, libvvio.so): every declared entry point is exported and the ABI versions agree."""
+    src = open(os.path.join(ROOT, "include", "vvio.h")).read()
+    ver = int(re.search(r"#define VVIO_ABI_VERSION (\d+)", src).group(1))
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(vvio_[a-z0-9_]+)\s*\(", src)))
+    assert names == ["vvio_abi_version", "vvio_ffv1_config_record", "vvio_ffv1_decode_frame", "vvio_ffv1_encode_frame"]
+    io = ctypes.CDLL(os.path.join(ROOT, "videovanish_amd", "csrc", "libvvio.so"))
+    for n in names:
+        assert hasattr(io, n), f"{n} declared in include/vvio.h but not exported"
+    assert io.vvio_abi_version() == ver
+
+
 def test_argument_validation_without_gpu(lib):
     """Launchers validate arguments before touching the device: bad args -> negative code + message."""
     from videovanish_amd import hip
@@ -69,7 +82,7 @@ def test_struct_layouts_match_header(tmp_path):
     import subprocess
     from videovanish_amd import hip
     probes = {"vv_conv_params": (hip.ConvParams, ["weight", "bias", "out", "ldo", "act", "split_heads", "split_tokens", "tile_hint"]),
-              "vv_attn_params": (hip.AttnParams, ["o", "q_rs", "D", "scale", "q_hs", "v_hs"]),
+              "vv_attn_params": (hip.AttnParams, ["o", "q_rs", "D", "scale", "q_hs", "v_hs", "q_prescaled"]),
               "vv_groupnorm_params": (hip.GroupNormParams, ["groups", "eps", "gamma", "stats_ws", "out_dtype"])}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "vvhip.h"', "int main(void) {"]
     for name, (_, fields) in probes.items():

@@ -53,7 +53,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
     constexpr int DK = (D + 31) / 32 * 32, DKC = DK / 8, KS = DK / 32;
     constexpr int DV = (D + 15) / 16 * 16, DVC = DV / 8, NDT = DV / 16;
     constexpr int KT = KVT / 16, US = KVT / 32;
-    constexpr int PK = DK * 2 + 32, PV = DV * 2 + ((DV * 2) % 64 == 0 ? 32 : 0);   // conflict-free ds_read_b128 / ds_read_b64_tr_b16 (bank model: tools/lds_bank_model.py)
+    // conflict-free ds_read_b128 / ds_read_b64_tr_b16 (bank model: tools/lds_bank_model.py).  SHORTK (LAZY, d = 40): a K row in LDS is only
+    // its 5 data chunks + the constant chunk (96 B, also conflict free); the k slots 48..63 the second MFMA slab still reads alias the
+    // first 32 B of the NEXT row -- finite numbers that meet the zeros of Q's padding -- so a K tile takes 6 LDS-DMA wave instructions
+    // instead of 10 (the fill time follows the instruction count, masked lanes are not free: tools/attn_fill_rate.hip)
+    constexpr bool SHORTK = LAZY && D == 40 && HACK != 8;
+    constexpr int PK = SHORTK ? 96 : DK * 2 + 32, PV = DV * 2 + ((DV * 2) % 64 == 0 ? 32 : 0);
     constexpr int NT = NW * 64;
     constexpr int KCH = (KVT * DKC + NT - 1) / NT, VCH = (KVT * DVC + NT - 1) / NT;
     constexpr int BQ = NW * QT * 16;
@@ -68,8 +73,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
     constexpr int NSK = KVT * PK / 16, NSV = KVT * PV / 16;            // 16-byte LDS slots per K / V tile (multiples of 64)
     constexpr int KP = (NSK + NT - 1) / NT, VP = (NSV + NT - 1) / NT;  // DMA passes
     static_assert(!DMA || (NSK % 64 == 0 && NSV % 64 == 0), "K/V tile must be whole 1 KB wave blocks");
-    __shared__ __attribute__((aligned(1024))) unsigned char dK0[DMA ? KVT * PK : 16];
-    __shared__ __attribute__((aligned(1024))) unsigned char dK1[DMA ? KVT * PK : 16];
+    __shared__ __attribute__((aligned(1024))) unsigned char dK0[DMA ? KVT * PK + (SHORTK ? 64 : 0) : 16];      // SHORTK: the last row's alias reads stay inside
+    __shared__ __attribute__((aligned(1024))) unsigned char dK1[DMA ? KVT * PK + (SHORTK ? 64 : 0) : 16];
     __shared__ __attribute__((aligned(1024))) unsigned char dV0[DMA ? KVT * PV : 16];
     __shared__ __attribute__((aligned(1024))) unsigned char dV1[DMA ? KVT * PV : 16];
 
@@ -333,6 +338,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
                 *(uint4*)(dV0 + sidx * 16) = fill; *(uint4*)(dV1 + sidx * 16) = fill;
             }
         }
+        if (SHORTK && t < 4) { *(uint4*)(dK0 + KVT * PK + t * 16) = make_uint4(0, 0, 0, 0); *(uint4*)(dK1 + KVT * PK + t * 16) = make_uint4(0, 0, 0, 0); }
         __syncthreads();    // the fill is complete before the first DMA lands (rows past Nkv of a ragged tile stay finite)
         const unsigned kstep = (unsigned)(KVT * (int)p.k_rs * 2), vstep = (unsigned)(KVT * (int)p.v_rs * 2);
         int issued = 0;     // tiles issued so far (= index of the tile the offsets address)
@@ -767,6 +773,7 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
                 if (var == 43) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true, 3>(p, st);      // ... no PV MFMAs
                 if (var == 44) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true, 4>(p, st);      // ... no QK MFMAs
                 if (var == 45) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true, 5>(p, st);      // ... no DMA
+                if (var == 48) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true, 8>(p, st);      // lazy with full 160-byte K rows
                 if (var == 35) return attn_launch<T, D, 2, 32, 8, false, 2, true, 0, true>(p, st);      // lazy, 8 waves (256 queries per block), 32-key tiles, 4 waves/SIMD
                 if (var == 36) return attn_launch<T, D, 2, 64, 8, false, 1, true, 0, true>(p, st);      // lazy, 8 waves, 64-key tiles, 2 waves/SIMD
                 if (var == 37) return attn_launch<T, D, 2, 64, 6, false, 2, true, 0, true>(p, st);      // lazy, 6 waves (192 queries per block), 3 waves/SIMD
