@@ -27,12 +27,12 @@
 extern "C" {
 #endif
 
-#define VV_ABI_VERSION 5
+#define VV_ABI_VERSION 6
 
 enum { VV_BF16 = 0, VV_F16 = 1, VV_F32 = 2, VV_U8 = 3 };
 enum { VV_OK = 0, VV_E_ARG = -1, VV_E_UNSUPPORTED = -2, VV_E_LAUNCH = -3 };
 enum { VV_EPI_NONE = 0, VV_EPI_GEGLU = 1 };
-enum { VV_ACT_NONE = 0, VV_ACT_SILU = 1, VV_ACT_RELU = 2 };
+enum { VV_ACT_NONE = 0, VV_ACT_SILU = 1, VV_ACT_RELU = 2, VV_ACT_LRELU = 3 /* x > 0 ? x : act_slope * x */ };
 
 int vv_abi_version(void);
 const char* vv_last_error(void);
@@ -76,7 +76,7 @@ typedef struct {
     int32_t epilogue;     /* VV_EPI_* ; GEGLU expects weight rows interleaved in blocks of 16: [v0..15 g0..15 v16..] */
     float out_scale;      /* multiplies the accumulated product+bias before residuals (1.0f = none) */
     int32_t ksize_w;      /* kernel width (0 = same as ksize); k = (ky*ksize_w + kx)*Cin + c */
-    int32_t act;          /* VV_ACT_NONE or VV_ACT_RELU applied last (after residuals) */
+    int32_t act;          /* VV_ACT_NONE, VV_ACT_RELU or VV_ACT_LRELU (slope act_slope) applied last (after residuals) */
     int32_t split_heads;  /* > 0: head-major store for a fused QKV projection (h16 out, no residuals): column n = (which, head, d) with
                              N = 3 * split_heads * split_dim, row m = (b, token) with split_tokens rows per b;
                              out[(((b*3 + which)*split_heads + head)*split_tokens + token)*split_dim + d]; ldo is ignored */
@@ -86,6 +86,7 @@ typedef struct {
     int32_t tile_hint;    /* 0 = automatic tiling; 1 = 128-row tiles only; 2 / 3 = the 256-row tile kernel (2-phase / 8-phase form) whenever
                              the shape is eligible (h16 sources with channel counts % 64 == 0, <= 9 taps, no fused resize,
                              Npad % 320 or % 256 == 0; 8-phase: Npad % 256 == 0) */
+    float act_slope;      /* VV_ACT_LRELU: negative-side slope (ProPainter: 0.1 in the alignment offset stacks, 0.2 in the encoders) */
 } vv_conv_params;
 int vv_conv_gemm(const vv_conv_params* host_p, int dtype, void* stream);
 
@@ -220,6 +221,28 @@ int vv_add_flow(float* coords1, const float* dflow, int ld, int64_t M, void* str
 int vv_add_relu_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 int vv_convex_upsample(const float* coords1, const float* mask, int F, int h, int w, float* out, void* stream);   /* F stacked grids -> flow [F][8h][8w][2] */
 int vv_fb_valid(const float* f_ab, const float* f_ba, int H, int W, uint8_t* valid, void* stream);
+
+/* Modulated deformable convolution (DCNv2), SURVEY 8(f) row n1: ProPainter's DeformableAlignment modules call
+ * torchvision.ops.deform_conv2d(x, offset, weight, bias, stride, padding, dilation, mask) (third-party `propainter`, reached from
+ * reference diffuerase.py:52-57).  vv_deform_im2col gathers the deformed, modulated im2col matrix
+ *     col[m][k * C + c] = mask[m][g * K + k] * bilinear(x[b, :, :, c], y * stride - pad + ky * dil + dy, x * stride - pad + kx * dil + dx)
+ * (m = (b, y, x) output pixel, k = ky * kw + kx, g = c / (C / deform_groups), (dy, dx) = offset[m][2 (g K + k)], [.. + 1]; torchvision's
+ * sampling rule: a sample at or beyond -1 / H (W) is 0, neighbours outside the image count as 0) in the conv weights' own k order, and
+ * the convolution itself is then vv_conv_gemm with ksize = 1 over K * C input channels.
+ * raw != NULL: the DeformableAlignment front end is fused in -- raw is the conv_offset output [M][3 * deform_groups * K] = (o1 | o2 | m):
+ * offset = max_residue * tanh(cat(o1, o2)) + flow (flow [M][2] as (dx, dy), may be NULL), mask = sigmoid(m). */
+typedef struct {
+    const void* x;            /* [B][H][W][C] NHWC, h16 (= dtype) or fp32 */
+    int32_t x_dtype;
+    const float* offset;      /* [M][2 * deform_groups * K] or NULL when raw is given */
+    const float* mask;        /* [M][deform_groups * K] or NULL (no modulation) */
+    const float* raw;         /* [M][3 * deform_groups * K] or NULL */
+    const float* flow;        /* [M][2] or NULL (raw mode only) */
+    float max_residue;        /* raw mode only */
+    void* col;                /* [M][K * C] h16 */
+    int32_t B, H, W, C, kh, kw, stride, pad, dil, deform_groups, Ho, Wo;
+} vv_deform_params;
+int vv_deform_im2col(const vv_deform_params* host_p, int dtype, void* stream);
 /* fill the unknown pixels of frame t (cur_t [H][W][3] fp32, in place) from neighbour nb warped by `flow` (t -> nb) */
 int vv_prop_fill(float* cur_t, const float* cur_nb, uint8_t* known_t, const uint8_t* known_nb, const uint8_t* valid,
                  const float* flow, int H, int W, uint8_t* filled_t, void* stream);

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_binding_lists_match_header(lib):
     from videovanish_amd import hip
     assert sorted(hip.EXPORTS) == _declared()
-    assert lib.vv_abi_version() == hip.ABI_VERSION == 5
+    assert lib.vv_abi_version() == hip.ABI_VERSION == 6
 
 
 def test_vvio_header_symbols_are_exported():
@@ -81,7 +81,8 @@ def test_struct_layouts_match_header(tmp_path):
     """sizeof / offsetof of the three parameter structs as gcc compiles include/vvhip.h == the ctypes mirrors in hip.py."""
     import subprocess
     from videovanish_amd import hip
-    probes = {"vv_conv_params": (hip.ConvParams, ["weight", "bias", "out", "ldo", "act", "split_heads", "split_tokens", "tile_hint"]),
+    probes = {"vv_conv_params": (hip.ConvParams, ["weight", "bias", "out", "ldo", "act", "split_heads", "split_tokens", "tile_hint", "act_slope"]),
+              "vv_deform_params": (hip.DeformParams, ["x_dtype", "offset", "flow", "max_residue", "col", "B", "deform_groups", "Wo"]),
               "vv_attn_params": (hip.AttnParams, ["o", "q_rs", "D", "scale", "q_hs", "v_hs", "q_prescaled"]),
               "vv_groupnorm_params": (hip.GroupNormParams, ["groups", "eps", "gamma", "stats_ws", "out_dtype"])}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "vvhip.h"', "int main(void) {"]

@@ -98,6 +98,7 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
                     else { const uint2 r2 = *(const uint2*)((const unsigned short*)p.res1 + rbase + n); v[0] += T::to_f32(r2.x & 0xffff); v[1] += T::to_f32(r2.x >> 16); v[2] += T::to_f32(r2.y & 0xffff); v[3] += T::to_f32(r2.y >> 16); }
                 }
                 if (p.act == VV_ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                else if (p.act == VV_ACT_LRELU) { v[0] = v[0] > 0.f ? v[0] : v[0] * p.act_slope; v[1] = v[1] > 0.f ? v[1] : v[1] * p.act_slope; v[2] = v[2] > 0.f ? v[2] : v[2] * p.act_slope; v[3] = v[3] > 0.f ? v[3] : v[3] * p.act_slope; }
                 // head-major QKV store: out[b][which][head][token][d] = row part + column part
                 const int64_t oc = split ? rowpart + colpart[j] : (int64_t)m * p.ldo + n;
                 if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + oc) = make_float4(v[0], v[1], v[2], v[3]);
@@ -128,6 +129,7 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
                 if (p.res0) x += r0f32 ? ((const float*)p.res0)[ri + r] : T::to_f32(((const unsigned short*)p.res0)[ri + r]);
                 if (p.res1) x += r0f32 ? ((const float*)p.res1)[ri + r] : T::to_f32(((const unsigned short*)p.res1)[ri + r]);
                 if (p.act == VV_ACT_RELU) x = fmaxf(x, 0.f);
+                else if (p.act == VV_ACT_LRELU) x = x > 0.f ? x : x * p.act_slope;
                 if (p.out_dtype == VV_F32) ((float*)p.out)[oc + r] = x;
                 else ((unsigned short*)p.out)[oc + r] = T::from_f32(x);
             }

@@ -10,8 +10,8 @@ import torch
 
 BF16, F16, F32, U8 = 0, 1, 2, 3
 EPI_NONE, EPI_GEGLU = 0, 1
-ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
-ABI_VERSION = 5
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_LRELU = 0, 1, 2, 3
+ABI_VERSION = 6
 _DT = {"bf16": BF16, "fp16": F16}
 _TORCH_H16 = {BF16: torch.bfloat16, F16: torch.float16}
 
@@ -52,7 +52,14 @@ class ConvParams(C.Structure):
                 ("res0", C.c_void_p), ("res1", C.c_void_p), ("res_dtype", C.c_int32), ("out", C.c_void_p),
                 ("out_dtype", C.c_int32), ("ldo", C.c_int32), ("epilogue", C.c_int32), ("out_scale", C.c_float), ("ksize_w", C.c_int32),
                 ("act", C.c_int32), ("split_heads", C.c_int32), ("split_dim", C.c_int32), ("split_tokens", C.c_int32),
-                ("tile_hint", C.c_int32)]
+                ("tile_hint", C.c_int32), ("act_slope", C.c_float)]
+
+
+class DeformParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_dtype", C.c_int32), ("offset", C.c_void_p), ("mask", C.c_void_p), ("raw", C.c_void_p),
+                ("flow", C.c_void_p), ("max_residue", C.c_float), ("col", C.c_void_p), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("C", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32),
+                ("deform_groups", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32)]
 
 
 class GroupNormParams(C.Structure):
@@ -81,7 +88,7 @@ EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name
            "vv_mask_collapse_dilate", "vv_resize_bilinear_u8", "vv_resize_nearest_u8", "vv_feather_composite", "vv_chamfer_dt",
            "vv_preprocess", "vv_brushnet_input", "vv_pad_channels", "vv_decode_blend", "vv_blur_compose",
            "vv_avgpool2_f32", "vv_corr_lookup", "vv_raft_ctx_split", "vv_raft_flow_prep", "vv_gru_rh", "vv_gru_update", "vv_add_flow",
-           "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32", "vv_u8_is_zero",
+           "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_deform_im2col", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32", "vv_u8_is_zero",
            "vv_raft_prep", "vv_split_f32", "vv_pad_channels_f32", "vv_window_average",
            "vv_groupnorm_stats", "vv_gn_affine", "vv_motion_module_c320"]
 
@@ -150,7 +157,8 @@ def _need_cuda(*ts):
 # ----------------------------------------------------------------------------------------------------------------
 def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, Wv=None, Hout=None, Wout=None, ksize=1,
               stride=1, pad_t=0, pad_l=0, bias=None, rowvec=None, res0=None, res1=None, out=None, out_dtype=None,
-              epilogue=EPI_NONE, out_scale=1.0, C0=None, C1=0, ksize_w=0, act=ACT_NONE, out_col=0, split_heads=0, split_dim=0, split_tokens=0, tile_hint=0):
+              epilogue=EPI_NONE, out_scale=1.0, C0=None, C1=0, ksize_w=0, act=ACT_NONE, out_col=0, split_heads=0, split_dim=0, split_tokens=0, tile_hint=0,
+              act_slope=0.0):
     """Launch vv_conv_gemm.  x0/x1: NHWC activations ([F,Hin,Win,C] or any shape with C last); weight: [Npad,Kpad] h16."""
     _need_cuda(x0, x1, weight, bias, rowvec, res0, res1, out)      # out_col: write into columns [out_col, out_col+N) of `out`
     Hv = Hin if Hv is None else Hv
@@ -176,7 +184,7 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
                    res_dtype=res_dt, out=out.data_ptr() + out_col * out.element_size(), out_dtype=dt_of(out),
                    ldo=out.shape[-1],
                    epilogue=epilogue, out_scale=out_scale, ksize_w=ksize_w, act=act, split_heads=split_heads, split_dim=split_dim,
-                   split_tokens=split_tokens, tile_hint=tile_hint)
+                   split_tokens=split_tokens, tile_hint=tile_hint, act_slope=act_slope)
     if PROFILE is not None:
         Npad = weight.shape[0]
         # mirror of launch_t() in vv_gemm.hip (label only): LDS-DMA loaders prefer the 128x128 tile (4 blocks per CU) when N allows
@@ -185,6 +193,21 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
         pref128 = os.environ.get("VV_GEMM_PREF128") is not None
         tile = "128x128" if (epilogue == EPI_GEGLU or (pref128 and Npad % 128 == 0 and dma and not lin and M >= 16384)) else (
             "128x160" if Npad % 160 == 0 else ("128x128" if Npad % 128 == 0 else "128x16"))
+        # mirror of vv_gemm256_try() in vv_gemm256.hip (label only): the long-k / wide-N shapes run on the 256-row kernels
+        if tile_hint != 1 and dma and Hv == Hin and Wv == Win and ksize * (ksize_w or ksize) <= 9 and (
+                (Npad % 320 == 0 and epilogue != EPI_GEGLU) or Npad % 256 == 0):
+            n256 = Npad % 256 == 0
+            form = 0
+            if lin:
+                if n256 and ((epilogue == EPI_GEGLU and K >= 640) or (K >= 1280 and Npad >= 3840) or K >= 5120):
+                    form = 3
+                elif K >= 5120:
+                    form = 1
+            elif ksize == 3 and stride == 1 and K >= 5760 and (C1 == 0 or M <= 65536):
+                form = 1
+            bn = 256 if form == 3 else (320 if (Npad % 320 == 0 and epilogue != EPI_GEGLU) else 256)
+            if form and ((M + 255) // 256) * (Npad // bn) >= 400:
+                tile = f"256x{bn}" + ("p8" if form == 3 else "")
         if os.environ.get("VV_PROFILE_SHAPES"):
             tile = f"M{M},N{N},K{K}|" + tile
         key = f"conv_gemm[{tile},{'f32in' if x0.dtype == torch.float32 else 'h16in'},k{ksize}{'x%d' % ksize_w if ksize_w and ksize_w != ksize else ''}]"
@@ -265,6 +288,25 @@ def attention(dtype, q, k, v, out, *, B, heads, Nq, Nkv, D, q_bs, k_bs, v_bs, o_
     with _Prof(f"attention[{kind},d{D}]", 4.0 * B * heads * Nq * Nkv * D, 2 * B * heads * D * (2 * Nq + 2 * Nkv)):
         _check(lib().vv_attention(C.byref(p), dtype, _stream()), "vv_attention")
     return out
+
+
+def deform_im2col(dtype, x, *, B, H, W, kh=3, kw=3, stride=1, pad=1, dil=1, deform_groups=1, offset=None, mask=None, raw=None, flow=None,
+                  max_residue=0.0):
+    """Deformed, modulated im2col matrix [M, kh*kw*C] (h16) of an NHWC tensor x [B*H*W, C]: see vv_deform_im2col in include/vvhip.h.
+    Either (offset [M, 2*dg*K], mask [M, dg*K] | None) or raw [M, 3*dg*K] (+ flow [M, 2]) -- the DeformableAlignment front end."""
+    _need_cuda(x, offset, mask, raw, flow)
+    Cc = x.shape[-1]
+    Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    col = torch.empty((B * Ho * Wo, kh * kw * Cc), dtype=h16(dtype), device=x.device)
+    for t in (offset, mask, raw, flow):
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError("vv_deform_im2col: offset / mask / raw / flow must be fp32")
+    p = DeformParams(x=x.data_ptr(), x_dtype=dt_of(x), offset=_p(offset), mask=_p(mask), raw=_p(raw), flow=_p(flow), max_residue=max_residue,
+                     col=col.data_ptr(), B=B, H=H, W=W, C=Cc, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, deform_groups=deform_groups, Ho=Ho, Wo=Wo)
+    with _Prof("deform_im2col", 0.0, col.numel() * 2 * 5):
+        _check(lib().vv_deform_im2col(C.byref(p), dtype, _stream()), "vv_deform_im2col")
+    return col, Ho, Wo
 
 
 def axpby(x, y, ca, cb, out=None):
