@@ -243,6 +243,17 @@ typedef struct {
     int32_t B, H, W, C, kh, kw, stride, pad, dil, deform_groups, Ho, Wo;
 } vv_deform_params;
 int vv_deform_im2col(const vv_deform_params* host_p, int dtype, void* stream);
+
+/* Helpers of ProPainter's recurrent flow-completion network (third-party model/recurrent_flow_completion.py, reached from reference
+ * diffuerase.py:52-57 through Propainter.forward -> forward_bidirect_flow / combine_flow).
+ * vv_fc_input: network input rows (flow * (1 - m) | m | 0 0 0 0 0) fp32 [T][H + 2 pad][W + 2 pad][8], replicate-padded (the first Conv3d has
+ *   padding_mode = 'replicate'); flow fp32 [T][H][W][2], mask u8 [T][H][W] (non-zero = hole).
+ * vv_upsample2x_bilinear: F.interpolate(scale_factor = 2, mode = 'bilinear', align_corners = True) on NHWC ([B][H][W][C] -> [B][2H][2W][C],
+ *   h16 -> h16 or fp32 -> fp32; C % 8 == 0) -- the resize inside ProPainter's `deconv` blocks.
+ * vv_flow_combine: combine_flow: out = pred inside the hole, the measured flow outside; pred fp32 rows of ld_pred floats (first two used). */
+int vv_fc_input(const float* flow, const uint8_t* mask, int T, int H, int W, int pad, float* out, void* stream);
+int vv_upsample2x_bilinear(const void* x, int x_dtype, int B, int H, int W, int C, void* out, int dtype, void* stream);
+int vv_flow_combine(const float* pred, int ld_pred, const float* flow, const uint8_t* mask, int64_t npx, float* out, void* stream);
 /* fill the unknown pixels of frame t (cur_t [H][W][3] fp32, in place) from neighbour nb warped by `flow` (t -> nb) */
 int vv_prop_fill(float* cur_t, const float* cur_nb, uint8_t* known_t, const uint8_t* known_nb, const uint8_t* valid,
                  const float* flow, int H, int W, uint8_t* filled_t, void* stream);

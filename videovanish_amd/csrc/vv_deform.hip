@@ -88,3 +88,97 @@ extern "C" int vv_deform_im2col(const vv_deform_params* pp, int dtype, void* str
     VV_CHECK_LAUNCH("vv_deform_im2col");
     return VV_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Helpers of ProPainter's recurrent flow-completion network (row n1; oracle/flowcomplete_ref.py; videovanish_amd/flowcomplete.py).
+namespace {
+
+// network input: (flow * (1 - m) | m | 0 x 5) per pixel, replicate-padded by `pad` pixels (first Conv3d: padding_mode = 'replicate')
+__global__ __launch_bounds__(256) void fc_input_kernel(const float* __restrict__ flow, const uint8_t* __restrict__ mask, int T, int H, int W, int pad,
+                                                      float* __restrict__ out) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)T * Hp * Wp) return;
+    const int t = (int)(gid / (Hp * Wp)), r = (int)(gid - (int64_t)t * Hp * Wp), y = r / Wp, x = r - y * Wp;
+    const int cy = min(max(y - pad, 0), H - 1), cx = min(max(x - pad, 0), W - 1);
+    const int64_t src = ((int64_t)t * H + cy) * W + cx;
+    const float m = mask[src] ? 1.0f : 0.0f;
+    float4* o = (float4*)(out + gid * 8);
+    o[0] = make_float4(flow[2 * src] * (1.0f - m), flow[2 * src + 1] * (1.0f - m), m, 0.f);
+    o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) on NHWC; one lane = 8 channels of one output pixel
+template <typename T, bool F32>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const void* __restrict__ xin, int B, int H, int W, int C, void* __restrict__ out) {
+    const int C8 = C >> 3, Ho = 2 * H, Wo = 2 * W;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)B * Ho * Wo * C8) return;
+    const int c8 = (int)(gid % C8);
+    const int64_t px = gid / C8;
+    const int b = (int)(px / (Ho * Wo)), r = (int)(px - (int64_t)b * Ho * Wo), oy = r / Wo, ox = r - oy * Wo;
+    const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const float fy = sy * (float)oy, fx = sx * (float)ox;
+    const int y0 = (int)fy, x0 = (int)fx, y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float wgt[4] = {(1.f - ly) * (1.f - lx), (1.f - ly) * lx, ly * (1.f - lx), ly * lx};
+    const int ys[4] = {y0, y0, y1, y1}, xs[4] = {x0, x1, x0, x1};
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int64_t off = (((int64_t)b * H + ys[t]) * W + xs[t]) * C + c8 * 8;
+        float v[8];
+        if (F32) { const float4* s = (const float4*)((const float*)xin + off); *(float4*)&v[0] = s[0]; *(float4*)&v[4] = s[1]; }
+        else unpack8<T>(*(const uint4*)((const unsigned short*)xin + off), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += wgt[t] * v[e];
+    }
+    const int64_t o = px * C + c8 * 8;
+    if (F32) { float4* d = (float4*)((float*)out + o); d[0] = *(float4*)&acc[0]; d[1] = *(float4*)&acc[4]; }
+    else *(uint4*)((unsigned short*)out + o) = pack8<T>(acc);
+}
+
+__global__ __launch_bounds__(256) void flow_combine_kernel(const float* __restrict__ pred, int ldp, const float* __restrict__ flow, const uint8_t* __restrict__ mask,
+                                                          int64_t npx, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npx) return;
+    const bool hole = mask[i] != 0;
+    out[2 * i] = hole ? pred[i * ldp] : flow[2 * i];
+    out[2 * i + 1] = hole ? pred[i * ldp + 1] : flow[2 * i + 1];
+}
+
+}  // namespace
+
+extern "C" int vv_fc_input(const float* flow, const uint8_t* mask, int T, int H, int W, int pad, float* out, void* stream) {
+    if (!flow || !mask || !out) VV_FAIL(VV_E_ARG, "vv_fc_input: null pointer");
+    if (T <= 0 || H <= 0 || W <= 0 || pad < 0) VV_FAIL(VV_E_ARG, "vv_fc_input: bad shape");
+    const int64_t n = (int64_t)T * (H + 2 * pad) * (W + 2 * pad);
+    hipLaunchKernelGGL(fc_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flow, mask, T, H, W, pad, out);
+    VV_CHECK_LAUNCH("vv_fc_input");
+    return VV_OK;
+}
+
+extern "C" int vv_upsample2x_bilinear(const void* x, int x_dtype, int B, int H, int W, int C, void* out, int dtype, void* stream) {
+    if (!x || !out) VV_FAIL(VV_E_ARG, "vv_upsample2x_bilinear: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) VV_FAIL(VV_E_ARG, "vv_upsample2x_bilinear: C=%d must be a multiple of 8", C);
+    if (dtype != VV_BF16 && dtype != VV_F16) VV_FAIL(VV_E_ARG, "vv_upsample2x_bilinear: bad dtype");
+    if (x_dtype != VV_F32 && x_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_upsample2x_bilinear: x_dtype mismatch");
+    const int64_t n = (int64_t)B * 4 * H * W * (C / 8);
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == VV_F32) hipLaunchKernelGGL((upsample2x_kernel<F16, true>), grid, blk, 0, st, x, B, H, W, C, out);
+    else if (dtype == VV_BF16) hipLaunchKernelGGL((upsample2x_kernel<BF16, false>), grid, blk, 0, st, x, B, H, W, C, out);
+    else hipLaunchKernelGGL((upsample2x_kernel<F16, false>), grid, blk, 0, st, x, B, H, W, C, out);
+    VV_CHECK_LAUNCH("vv_upsample2x_bilinear");
+    return VV_OK;
+}
+
+extern "C" int vv_flow_combine(const float* pred, int ld_pred, const float* flow, const uint8_t* mask, int64_t npx, float* out, void* stream) {
+    if (!pred || !flow || !mask || !out) VV_FAIL(VV_E_ARG, "vv_flow_combine: null pointer");
+    if (npx <= 0 || ld_pred < 2) VV_FAIL(VV_E_ARG, "vv_flow_combine: bad shape");
+    hipLaunchKernelGGL(flow_combine_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred, ld_pred, flow, mask, npx, out);
+    VV_CHECK_LAUNCH("vv_flow_combine");
+    return VV_OK;
+}

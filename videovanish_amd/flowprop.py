@@ -20,6 +20,14 @@ def _model(device, dtype, weight_seed):
     return _cache[key]
 
 
+def _flow_net(ctx):
+    key = ("fc", id(ctx))
+    if key not in _cache:
+        from .flowcomplete import FlowCompleteNet
+        _cache[key] = FlowCompleteNet(ctx)
+    return _cache[key]
+
+
 PAIRS = 8      # pairs per stacked group
 
 
@@ -78,9 +86,11 @@ def subvideo_ranges(T, subvideo_length, pad_len=5):
     return [(max(0, f - pad_len), min(T, f + L + pad_len), f, min(T, f + L)) for f in range(0, T, L)]
 
 
-def flow_propagation_prior(frames, masks, device=None, progress=None, dtype="fp16", weight_seed=0, iters=ITERS, subvideo_length=0):
+def flow_propagation_prior(frames, masks, device=None, progress=None, dtype="fp16", weight_seed=0, iters=ITERS, subvideo_length=0,
+                           flow_completion=False):
     """list of (H0,W0,3) u8 + list of (H0,W0) u8 masks -> list of (H0,W0,3) u8 prior frames.
-    subvideo_length > 0: the propagation runs per sub-video as the reference's ProPainter call asks (diffuerase.py:55)."""
+    subvideo_length > 0: the propagation runs per sub-video as the reference's ProPainter call asks (diffuerase.py:55).
+    flow_completion: complete the RAFT flows inside the holes with the recurrent flow-completion network first (flowcomplete.py)."""
     ctx, raft = _model(device, dtype, weight_seed)
     dev = ctx.device
     H0, W0 = frames[0].shape[:2]
@@ -93,9 +103,14 @@ def flow_propagation_prior(frames, masks, device=None, progress=None, dtype="fp1
     if progress is not None:
         progress(25, "running flow prior (RAFT)")
     fw, bw = flows_for_clip(raft, fr.contiguous(), iters)
+    T = fr.shape[0]
+    if flow_completion and T > 1:
+        if progress is not None:
+            progress(35, "running flow prior (flow completion)")
+        cf, cb = _flow_net(ctx).complete_flows(torch.stack(fw), torch.stack(bw), mk.contiguous())
+        fw, bw = list(cf), list(cb)
     if progress is not None:
         progress(40, "running flow prior (propagation)")
-    T = fr.shape[0]
     ranges = subvideo_ranges(T, subvideo_length)
     if len(ranges) == 1:
         out, _ = propagate(fr.contiguous(), mk.contiguous(), fw, bw)

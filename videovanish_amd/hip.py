@@ -88,7 +88,7 @@ EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name
            "vv_mask_collapse_dilate", "vv_resize_bilinear_u8", "vv_resize_nearest_u8", "vv_feather_composite", "vv_chamfer_dt",
            "vv_preprocess", "vv_brushnet_input", "vv_pad_channels", "vv_decode_blend", "vv_blur_compose",
            "vv_avgpool2_f32", "vv_corr_lookup", "vv_raft_ctx_split", "vv_raft_flow_prep", "vv_gru_rh", "vv_gru_update", "vv_add_flow",
-           "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_deform_im2col", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32", "vv_u8_is_zero",
+           "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_deform_im2col", "vv_fc_input", "vv_upsample2x_bilinear", "vv_flow_combine", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32", "vv_u8_is_zero",
            "vv_raft_prep", "vv_split_f32", "vv_pad_channels_f32", "vv_window_average",
            "vv_groupnorm_stats", "vv_gn_affine", "vv_motion_module_c320"]
 
@@ -307,6 +307,32 @@ def deform_im2col(dtype, x, *, B, H, W, kh=3, kw=3, stride=1, pad=1, dil=1, defo
     with _Prof("deform_im2col", 0.0, col.numel() * 2 * 5):
         _check(lib().vv_deform_im2col(C.byref(p), dtype, _stream()), "vv_deform_im2col")
     return col, Ho, Wo
+
+
+def fc_input(flow, mask_u8, pad):
+    """flow fp32 [T,H,W,2] + mask u8 [T,H,W] -> fp32 [T, H+2pad, W+2pad, 8] = (flow*(1-m) | m | 0..) replicate-padded."""
+    _need_cuda(flow, mask_u8)
+    T, H, W, _ = flow.shape
+    out = torch.empty((T, H + 2 * pad, W + 2 * pad, 8), dtype=torch.float32, device=flow.device)
+    _check(lib().vv_fc_input(_p(flow), _p(mask_u8), T, H, W, pad, _p(out), _stream()), "vv_fc_input")
+    return out
+
+
+def upsample2x_bilinear(dtype, x, B, H, W):
+    """NHWC rows [B*H*W, C] (h16 or fp32) -> [B*2H*2W, C], bilinear, align_corners=True."""
+    _need_cuda(x)
+    Cc = x.shape[-1]
+    out = torch.empty((B * 4 * H * W, Cc), dtype=x.dtype, device=x.device)
+    _check(lib().vv_upsample2x_bilinear(_p(x), dt_of(x), B, H, W, Cc, _p(out), dtype, _stream()), "vv_upsample2x_bilinear")
+    return out
+
+
+def flow_combine(pred, flow, mask_u8):
+    """pred fp32 [N, ld>=2], flow fp32 [..., 2] with N pixels, mask u8 [N] -> fp32 like flow: pred in the hole, flow outside."""
+    _need_cuda(pred, flow, mask_u8)
+    out = torch.empty_like(flow)
+    _check(lib().vv_flow_combine(_p(pred), pred.shape[-1], _p(flow), _p(mask_u8), C.c_int64(mask_u8.numel()), _p(out), _stream()), "vv_flow_combine")
+    return out
 
 
 def axpby(x, y, ca, cb, out=None):
