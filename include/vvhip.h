@@ -254,6 +254,24 @@ int vv_deform_im2col(const vv_deform_params* host_p, int dtype, void* stream);
 int vv_fc_input(const float* flow, const uint8_t* mask, int T, int H, int W, int pad, float* out, void* stream);
 int vv_upsample2x_bilinear(const void* x, int x_dtype, int B, int H, int W, int C, void* out, int dtype, void* stream);
 int vv_flow_combine(const float* pred, int ld_pred, const float* flow, const uint8_t* mask, int64_t npx, float* out, void* stream);
+
+/* Helpers of ProPainter's inpainting generator (third-party model/propainter.py + model/modules/sparse_transformer.py, reached from reference
+ * diffuerase.py:52-57 through Propainter.forward with ref_stride / neighbor_length of diffuerase.py:53-54).
+ * vv_gather_rows: out[i] = src[idx[i]] (rows of row_bytes, a multiple of 16; idx < 0 -> zeros): window_partition, the rolled neighbour-window
+ *   keys, the pooled global keys and the inverse scatter of the sparse window attention are all row gathers with host-built index tables.
+ * vv_fold_patches: F.fold of tap-major patch rows [B * fh * fw][k * k * C] onto [B][h][w][C] (overlap-add in gather form); normalise = divide by
+ *   the overlap count, gelu = GELU on the result (the fold / normalise / [unfold] / GELU of FusionFeedForward: GELU commutes with the unfold
+ *   gather, which is vv_deform_im2col with zero offsets); also SoftComp's fold.
+ * vv_flow_down4: F.interpolate(flow, scale_factor = 1/4, 'bilinear', align_corners = False) / 4 (flows for the 1/4-resolution features).
+ * vv_gen_compose: acc = first ? img : (acc + img) / 2 with img = ((tanh(pred) + 1) / 2 * 255) inside the hole and the original frame outside
+ *   (the comp_frames update of ProPainter's inference loop; pred fp32 rows of ld_pred floats, ori u8 RGB, mask u8, acc fp32 RGB). */
+int vv_gather_rows(const void* src, const int32_t* idx, int64_t n, int row_bytes, void* out, void* stream);
+int vv_fold_patches(const void* x, int x_dtype, int B, int fh, int fw, int C, int h, int w, int k, int stride, int pad, int normalise, int gelu,
+                    void* out, int out_dtype, int dtype, void* stream);
+int vv_flow_down4(const float* flow, int T, int H, int W, float* out, void* stream);
+/* vv_gen_input: encoder input rows (frame / 127.5 - 1 | mask_in | mask_updated | 0 0 0) fp32 [npx][8] from u8 RGB frames and u8 masks. */
+int vv_gen_input(const uint8_t* frames, const uint8_t* mask_in, const uint8_t* mask_updated, int64_t npx, float* out, void* stream);
+int vv_gen_compose(const float* pred, int ld_pred, const uint8_t* ori, const uint8_t* mask, int64_t npx, float* acc, int first, void* stream);
 /* fill the unknown pixels of frame t (cur_t [H][W][3] fp32, in place) from neighbour nb warped by `flow` (t -> nb) */
 int vv_prop_fill(float* cur_t, const float* cur_nb, uint8_t* known_t, const uint8_t* known_nb, const uint8_t* valid,
                  const float* flow, int H, int W, uint8_t* filled_t, void* stream);

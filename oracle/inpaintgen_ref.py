@@ -291,5 +291,49 @@ def generator(P, masked_frames, flows_f, flows_b, masks_in, masks_updated, l_t, 
     return torch.tanh(x).view(b, l_t, 3, H, W)
 
 
-def get_ref_index(neighbor_ids, length, ref_stride=10):
-    return [i for i in range(0, length, ref_stride) if i not in neighbor_ids]
+def get_ref_index(neighbor_ids, length, ref_stride=10, mid=0, ref_num=-1):
+    """reference frames of one neighbour window (ProPainter inference script): every ref_stride-th frame outside the window; for clips longer
+    than subvideo_length only ref_num of them around the window centre."""
+    if ref_num == -1:
+        return [i for i in range(0, length, ref_stride) if i not in neighbor_ids]
+    out = []
+    for i in range(max(0, mid - ref_stride * (ref_num // 2)), min(length, mid + ref_stride * (ref_num // 2)), ref_stride):
+        if i not in neighbor_ids:
+            if len(out) > ref_num:
+                break
+            out.append(i)
+    return out
+
+
+def window_schedule(T, neighbor_length=10, ref_stride=10, subvideo_length=80):
+    """[(neighbor_ids, ref_ids)] of ProPainter's sliding-window inference loop."""
+    ns = neighbor_length // 2
+    ref_num = subvideo_length // ref_stride if T > subvideo_length else -1
+    out = []
+    for f in range(0, T, ns):
+        nb = list(range(max(0, f - ns), min(T, f + ns + 1)))
+        out.append((nb, get_ref_index(nb, T, ref_stride, f, ref_num)))
+    return out
+
+
+def inpaint_clip(P, updated_u8, ori_u8, flows_f, flows_b, masks_u8, updated_masks_u8, neighbor_length=10, ref_stride=10, subvideo_length=80,
+                 depths=8, t_dilation=2):
+    """The generator over a whole clip: updated_u8 [T,H,W,3] (frames after the image propagation), ori_u8 the original frames, flows
+    [T-1,2,H,W] completed, masks [T,H,W] u8.  Returns u8 [T,H,W,3]: prediction inside the (dilated) masks, original outside; a frame visited
+    by two windows is the truncated mean of both visits (the reference's uint8 arithmetic)."""
+    T, H, W, _ = updated_u8.shape
+    fr = torch.from_numpy(updated_u8).float().permute(0, 3, 1, 2) / 127.5 - 1.0
+    mi = torch.from_numpy(masks_u8 > 0).float()[:, None]
+    mu = torch.from_numpy(updated_masks_u8 > 0).float()[:, None]
+    comp = [None] * T
+    for nb, ref in window_schedule(T, neighbor_length, ref_stride, subvideo_length):
+        ids = nb + ref
+        with torch.no_grad():
+            pred = generator(P, fr[ids][None], flows_f[nb[:-1]][None], flows_b[nb[:-1]][None], mi[ids][None], mu[ids][None], len(nb), depths, t_dilation)[0]
+        pred = ((pred + 1) / 2).permute(0, 2, 3, 1).numpy() * 255
+        for i, idx in enumerate(nb):
+            bm = (masks_u8[idx] > 0)[..., None].astype(pred.dtype)
+            img = pred[i].astype("uint8") * bm.astype("uint8") + ori_u8[idx] * (1 - bm.astype("uint8"))
+            comp[idx] = img if comp[idx] is None else (comp[idx].astype("float32") * 0.5 + img.astype("float32") * 0.5).astype("uint8")
+    import numpy as np
+    return np.stack(comp)

@@ -88,7 +88,7 @@ EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name
            "vv_mask_collapse_dilate", "vv_resize_bilinear_u8", "vv_resize_nearest_u8", "vv_feather_composite", "vv_chamfer_dt",
            "vv_preprocess", "vv_brushnet_input", "vv_pad_channels", "vv_decode_blend", "vv_blur_compose",
            "vv_avgpool2_f32", "vv_corr_lookup", "vv_raft_ctx_split", "vv_raft_flow_prep", "vv_gru_rh", "vv_gru_update", "vv_add_flow",
-           "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_deform_im2col", "vv_fc_input", "vv_upsample2x_bilinear", "vv_flow_combine", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32", "vv_u8_is_zero",
+           "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_deform_im2col", "vv_fc_input", "vv_upsample2x_bilinear", "vv_flow_combine", "vv_gather_rows", "vv_fold_patches", "vv_flow_down4", "vv_gen_compose", "vv_gen_input", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32", "vv_u8_is_zero",
            "vv_raft_prep", "vv_split_f32", "vv_pad_channels_f32", "vv_window_average",
            "vv_groupnorm_stats", "vv_gn_affine", "vv_motion_module_c320"]
 
@@ -333,6 +333,47 @@ def flow_combine(pred, flow, mask_u8):
     out = torch.empty_like(flow)
     _check(lib().vv_flow_combine(_p(pred), pred.shape[-1], _p(flow), _p(mask_u8), C.c_int64(mask_u8.numel()), _p(out), _stream()), "vv_flow_combine")
     return out
+
+
+def gather_rows(src, idx):
+    """out[i] = src[idx[i]] (idx int32 on the device, < 0 -> zero row); rows must be multiples of 16 bytes."""
+    _need_cuda(src, idx)
+    out = torch.empty((idx.numel(), src.shape[-1]), dtype=src.dtype, device=src.device)
+    _check(lib().vv_gather_rows(_p(src), _p(idx), C.c_int64(idx.numel()), src.shape[-1] * src.element_size(), _p(out), _stream()), "vv_gather_rows")
+    return out
+
+
+def fold_patches(dtype, x, B, fh, fw, Cc, h, w, k=7, stride=3, pad=3, normalise=False, gelu=False, out_dtype=torch.float32):
+    """tap-major patch rows [B*fh*fw, k*k*C] -> [B*h*w, C] (F.fold; optional overlap normalisation and GELU)."""
+    _need_cuda(x)
+    out = torch.empty((B * h * w, Cc), dtype=out_dtype, device=x.device)
+    _check(lib().vv_fold_patches(_p(x), dt_of(x), B, fh, fw, Cc, h, w, k, stride, pad, int(normalise), int(gelu), _p(out), dt_of(out), dtype, _stream()),
+           "vv_fold_patches")
+    return out
+
+
+def flow_down4(flow):
+    """fp32 [T,H,W,2] -> fp32 [T,H/4,W/4,2] (bilinear 1/4, align_corners=False, values / 4)."""
+    _need_cuda(flow)
+    T, H, W, _ = flow.shape
+    out = torch.empty((T, H // 4, W // 4, 2), dtype=torch.float32, device=flow.device)
+    _check(lib().vv_flow_down4(_p(flow), T, H, W, _p(out), _stream()), "vv_flow_down4")
+    return out
+
+
+def gen_input(frames_u8, mask_in_u8, mask_up_u8):
+    """u8 [T,H,W,3] + two u8 [T,H,W] masks -> fp32 [T*H*W, 8] encoder input rows."""
+    _need_cuda(frames_u8, mask_in_u8, mask_up_u8)
+    n = mask_in_u8.numel()
+    out = torch.empty((n, 8), dtype=torch.float32, device=frames_u8.device)
+    _check(lib().vv_gen_input(_p(frames_u8), _p(mask_in_u8), _p(mask_up_u8), C.c_int64(n), _p(out), _stream()), "vv_gen_input")
+    return out
+
+
+def gen_compose(pred, ori_u8, mask_u8, acc, first):
+    _need_cuda(pred, ori_u8, mask_u8, acc)
+    _check(lib().vv_gen_compose(_p(pred), pred.shape[-1], _p(ori_u8), _p(mask_u8), C.c_int64(mask_u8.numel()), _p(acc), int(first), _stream()), "vv_gen_compose")
+    return acc
 
 
 def axpby(x, y, ca, cb, out=None):
