@@ -243,3 +243,22 @@ def test_prior_with_flow_completion_runs_and_keeps_unmasked_pixels(gpu):
     #  the completion network itself is checked against its oracle in tests/test_flowcomplete_gpu.py)
     again = pp.forward(frames, masks, subvideo_length=50)
     assert all(np.array_equal(a, b) for a, b in zip(out, again))
+
+
+def test_full_propainter_pipeline_contract(gpu):
+    """Propainter(flow_completion=True, generator=True): RAFT -> flow completion -> image propagation -> inpainting generator, the complete
+    third-party pipeline the reference calls at diffuerase.py:52-57.  Seeded random weights: contract only (shapes, dtype, untouched pixels
+    outside the masks, holes no longer the mean-colour fill, deterministic)."""
+    from videovanish_amd.propainter import Propainter
+    T, H, W = 6, 64, 96
+    frames, masks = _clip(T, H, W, 91)
+    pp = Propainter(device="cuda:0", flow_completion=True, generator=True)
+    out = pp.forward(frames, masks, ref_stride=2, neighbor_length=4, subvideo_length=50)
+    base = Propainter(device="cuda:0").forward(frames, masks, subvideo_length=50)
+    assert len(out) == T and out[0].shape == (H, W, 3) and out[0].dtype == np.uint8
+    for t in range(T):
+        keep = masks[t] == 0
+        assert np.array_equal(out[t][keep], frames[t][keep])
+        assert not np.array_equal(out[t][~keep], base[t][~keep])
+    again = pp.forward(frames, masks, ref_stride=2, neighbor_length=4, subvideo_length=50)
+    assert all(np.array_equal(a, b) for a, b in zip(out, again))

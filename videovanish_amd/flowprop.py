@@ -86,11 +86,21 @@ def subvideo_ranges(T, subvideo_length, pad_len=5):
     return [(max(0, f - pad_len), min(T, f + L + pad_len), f, min(T, f + L)) for f in range(0, T, L)]
 
 
+def _generator(ctx):
+    key = ("gen", id(ctx))
+    if key not in _cache:
+        from .inpaintgen import InpaintGenerator
+        _cache[key] = InpaintGenerator(ctx)
+    return _cache[key]
+
+
 def flow_propagation_prior(frames, masks, device=None, progress=None, dtype="fp16", weight_seed=0, iters=ITERS, subvideo_length=0,
-                           flow_completion=False):
+                           flow_completion=False, generator=False, ref_stride=10, neighbor_length=10):
     """list of (H0,W0,3) u8 + list of (H0,W0) u8 masks -> list of (H0,W0,3) u8 prior frames.
     subvideo_length > 0: the propagation runs per sub-video as the reference's ProPainter call asks (diffuerase.py:55).
-    flow_completion: complete the RAFT flows inside the holes with the recurrent flow-completion network first (flowcomplete.py)."""
+    flow_completion: complete the RAFT flows inside the holes with the recurrent flow-completion network first (flowcomplete.py).
+    generator: run ProPainter's inpainting generator (inpaintgen.py) over the propagated frames in sliding windows of `neighbor_length`
+    frames with every `ref_stride`-th frame as reference (the last stage of the real ProPainter)."""
     ctx, raft = _model(device, dtype, weight_seed)
     dev = ctx.device
     H0, W0 = frames[0].shape[:2]
@@ -113,12 +123,22 @@ def flow_propagation_prior(frames, masks, device=None, progress=None, dtype="fp1
         progress(40, "running flow prior (propagation)")
     ranges = subvideo_ranges(T, subvideo_length)
     if len(ranges) == 1:
-        out, _ = propagate(fr.contiguous(), mk.contiguous(), fw, bw)
+        out, filled = propagate(fr.contiguous(), mk.contiguous(), fw, bw)
     else:
-        out = torch.empty_like(fr)
+        out, filled = torch.empty_like(fr), torch.empty_like(mk)
         for (s, e, lo, hi) in ranges:
-            sub, _ = propagate(fr[s:e].contiguous(), mk[s:e].contiguous(), fw[s:e - 1], bw[s:e - 1])
-            out[lo:hi] = sub[lo - s: hi - s]
+            sub, fsub = propagate(fr[s:e].contiguous(), mk[s:e].contiguous(), fw[s:e - 1], bw[s:e - 1])
+            out[lo:hi], filled[lo:hi] = sub[lo - s: hi - s], fsub[lo - s: hi - s]
+    if generator and T > 1:
+        if progress is not None:
+            progress(45, "running flow prior (inpainting generator)")
+        from .inpaintgen import inpaint_clip
+        # frames after the image propagation: propagated content inside the holes, mid-grey (0 in the network's [-1, 1] range) where nothing
+        # arrived; the "updated" masks mark what is still open
+        open_mask = ((mk > 0) & (filled == 0)).to(torch.uint8) * 255
+        updated = torch.where(open_mask[..., None] > 0, torch.full_like(out, 127), out)
+        out = inpaint_clip(_generator(ctx), updated.contiguous(), fr.contiguous(), torch.stack(fw), torch.stack(bw), mk.contiguous(), open_mask.contiguous(),
+                           neighbor_length=neighbor_length, ref_stride=ref_stride, subvideo_length=max(int(subvideo_length), 1))
     if (H, W) != (H0, W0):
         out = hip.resize_u8(out.contiguous(), H0, W0, mode="bilinear")
     return list(out.cpu().numpy())
