@@ -143,38 +143,38 @@ def _window_tables(t, fh, fw, ws, pool, T_ind):
     nh, nw = n_wh * wh, n_ww * ww
     ph, pw = nh // pool[0], nw // pool[1]
     e = ((wh + 1) // 2, (ww + 1) // 2)
-    tok = lambda f, y, x: (f * nh + y) * nw + x
+    nwin, L = n_wh * n_ww, wh * ww
     pad_idx = np.full((t, nh, nw), -1, np.int32)
     pad_idx[:, :fh, :fw] = np.arange(t * fh * fw, dtype=np.int32).reshape(t, fh, fw)
+    # window (wy, wx), position (iy, ix) -> padded-grid coordinates
+    wy, wx = np.divmod(np.arange(nwin), n_ww)
+    iy, ix = np.divmod(np.arange(L), ww)
+    oy = (wy[:, None] * wh + iy[None, :])                                    # [nwin, L]
+    ox = (wx[:, None] * ww + ix[None, :])
+    frames = np.arange(t)
+    q_idx = ((frames[None, :, None] * nh + oy[:, None, :]) * nw + ox[:, None, :]).astype(np.int32)        # [nwin, t, L]
+    # rolled neighbour-window keys: torch.roll(k, (sy, sx)) then window partition = token ((y - sy) % nh, (x - sx) % nw); only the
+    # positions that really come from OUTSIDE the window are kept (the reference's four corner masks)
     m_tl = np.ones(ws, bool); m_tl[:-e[0], :-e[1]] = False
     m_tr = np.ones(ws, bool); m_tr[:-e[0], e[1]:] = False
     m_bl = np.ones(ws, bool); m_bl[e[0]:, :-e[1]] = False
     m_br = np.ones(ws, bool); m_br[e[0]:, e[1]:] = False
-    rolls = [((-e[0], -e[1]), m_tl), ((-e[0], e[1]), m_tr), ((e[0], -e[1]), m_bl), ((e[0], e[1]), m_br)]
-    nwin = n_wh * n_ww
-    q_idx = np.empty((nwin, t, wh * ww), np.int32)
-    k_idx = []
-    for wy in range(n_wh):
-        for wx in range(n_ww):
-            wi = wy * n_ww + wx
-            own = [(wy * wh + iy, wx * ww + ix) for iy in range(wh) for ix in range(ww)]
-            for f in range(t):
-                q_idx[wi, f] = [tok(f, y, x) for (y, x) in own]
-            rolled = []
-            for (sy, sx), m in rolls:            # torch.roll: rolled[y, x] = k[(y - sy) % nh, (x - sx) % nw]
-                rolled += [((wy * wh + iy - sy) % nh, (wx * ww + ix - sx) % nw) for iy in range(wh) for ix in range(ww) if m[iy, ix]]
-            rows = []
-            for f in T_ind:
-                rows += [tok(f, y, x) for (y, x) in own] + [tok(f, y, x) for (y, x) in rolled]
-                rows += [t * nh * nw + (f * ph + py) * pw + px for py in range(ph) for px in range(pw)]
-            k_idx.append(rows)
-    k_idx = np.asarray(k_idx, np.int32)
-    # inverse: token (f, y, x) of the UNPADDED grid -> (window, frame, position) slot
-    inv = np.empty((t, fh, fw), np.int32)
-    for f in range(t):
-        for y in range(fh):
-            for x in range(fw):
-                inv[f, y, x] = ((y // wh) * n_ww + x // ww) * (t * wh * ww) + f * (wh * ww) + (y % wh) * ww + (x % ww)
+    ry, rx = [], []
+    for (sy, sx), m in (((-e[0], -e[1]), m_tl), ((-e[0], e[1]), m_tr), ((e[0], -e[1]), m_bl), ((e[0], e[1]), m_br)):
+        sel = np.nonzero(m.reshape(-1))[0]
+        ry.append((oy[:, sel] - sy) % nh)
+        rx.append((ox[:, sel] - sx) % nw)
+    ky = np.concatenate([oy] + ry, 1)                                        # [nwin, L + roll_N]: own window, then the rolled keys
+    kx = np.concatenate([ox] + rx, 1)
+    tf = np.asarray(list(T_ind))
+    tok_k = (tf[None, :, None] * nh + ky[:, None, :]) * nw + kx[:, None, :]                                # [nwin, |T_ind|, L + roll_N]
+    pooled = t * nh * nw + tf[:, None] * (ph * pw) + np.arange(ph * pw)[None, :]                          # [|T_ind|, ph * pw]
+    k_idx = np.concatenate([tok_k, np.broadcast_to(pooled[None], (nwin, len(tf), ph * pw))], 2).reshape(nwin, -1).astype(np.int32)
+    # inverse: token (f, y, x) of the UNPADDED grid -> its slot in the [window][frame][position] output order
+    y, x = np.arange(fh), np.arange(fw)
+    win = (y[:, None] // wh) * n_ww + x[None, :] // ww
+    pos = (y[:, None] % wh) * ww + x[None, :] % ww
+    inv = (win[None] * (t * L) + frames[:, None, None] * L + pos[None]).astype(np.int32)
     return dict(nh=nh, nw=nw, ph=ph, pw=pw, nwin=nwin, n_wh=n_wh, n_ww=n_ww, pad_idx=pad_idx.reshape(-1), q_idx=q_idx, k_idx=k_idx, inv=inv.reshape(-1))
 
 
@@ -293,11 +293,8 @@ class InpaintGenerator:
         col, _, _ = hip.deform_im2col(dt, enc, B=t, H=h, W=w, kh=K7, kw=K7, stride=S3, pad=P3, dil=1, deform_groups=1, offset=zero7)
         tok = self.ss(col, out_dtype=torch.float32)
         # hole mask of the local frames on the token grid (max pool 7/3/3), then per window
-        mp = np.zeros((l_t, fh, fw), bool)
         mpad = np.pad(m_in[:l_t], ((0, 0), (P3, P3), (P3, P3)))
-        for y in range(fh):
-            for x in range(fw):
-                mp[:, y, x] = mpad[:, y * S3:y * S3 + K7, x * S3:x * S3 + K7].reshape(l_t, -1).any(1)
+        mp = np.lib.stride_tricks.sliding_window_view(mpad, (K7, K7), axis=(1, 2))[:, ::S3, ::S3][:, :fh, :fw].any((3, 4))
         wh, ww = self.ws
         per_parity = {}
         for parity in range(self.t_dilation):
