@@ -131,10 +131,11 @@ def synth_clip(T, H, W, seed=1234, t0=0):
     return frames, masks, prior
 
 
-def cpu_baseline(H, W, steps, chunk, overlap, sample_hw=(192, 256), vae_hw=(96, 128)):
-    """The oracle (kind "port": fp32 torch restatement) timed on the host cores on a BOUNDED sample of the same workload:
-    one BrushNet+UNet denoise step on one frame at 256x192 and one VAE encode+decode at 128x96 (full-width architecture,
-    same weights), converted to CPU TFLOP/s with the algorithmic FLOP model and then to frames/s of the 720p/50-step job."""
+def cpu_baseline(H, W, steps, chunk, overlap, sample_hw=(256, 384), vae_hw=(192, 256), sample_frames=4):
+    """The oracle (kind "port": fp32 torch restatement) timed on the host cores on a BOUNDED sample of the same workload (~10-20 s of
+    CPU work): one BrushNet+UNet denoise step on a 4-frame clip at 384x256 (the temporal modules attend over the 4 frames) and one VAE
+    encode+decode at 256x192 (full-width architecture, same weights), converted to CPU TFLOP/s with the algorithmic FLOP model and then
+    to frames/s of the 720p/50-step job."""
     from oracle import model_ref as M
     from videovanish_amd import flops
     from videovanish_amd.config import UNetConfig, VAEConfig
@@ -145,8 +146,8 @@ def cpu_baseline(H, W, steps, chunk, overlap, sample_hw=(192, 256), vae_hw=(96, 
     sh, sw = sample_hw
     h, w = sh // 8, sw // 8
     g = torch.Generator().manual_seed(0)
-    lat = torch.randn(1, 4, h, w, generator=g)
-    x9 = torch.cat([lat, lat, torch.ones(1, 1, h, w)], 1)
+    lat = torch.randn(sample_frames, 4, h, w, generator=g)
+    x9 = torch.cat([lat, lat, torch.ones(sample_frames, 1, h, w)], 1)
     text = M.text_states(P, ucfg)
     img = torch.rand(1, 3, vae_hw[0], vae_hw[1], generator=g) * 2 - 1
     with torch.no_grad():
@@ -162,11 +163,11 @@ def cpu_baseline(H, W, steps, chunk, overlap, sample_hw=(192, 256), vae_hw=(96, 
         M.vae_decode(P, z, vcfg)
         t_vae = time.time() - t0
     enc, dec = flops.vae_per_frame(vae_hw[0], vae_hw[1], vcfg)
-    fl = flops.denoise_step_per_frame(h, w, 1, ucfg) + enc + dec
+    fl = flops.denoise_step_per_frame(h, w, sample_frames, ucfg) * sample_frames + enc + dec
     tfs = fl / (t_step + t_vae) / 1e12
     per_frame = flops.per_output_frame(H, W, chunk, steps, ucfg, vcfg) * chunk / float(chunk - overlap)
     return {"value": tfs * 1e12 / per_frame, "unit": "frames/s", "cores": cores, "kind": "port", "cpu_tflops": round(tfs, 4),
-            "sample": f"1 frame: one denoise step at {sw}x{sh} ({t_step:.1f}s) + VAE encode+decode at {vae_hw[1]}x{vae_hw[0]} ({t_vae:.1f}s), "
+            "sample": f"{sample_frames}-frame clip: one denoise step at {sw}x{sh} ({t_step:.1f}s) + one VAE encode+decode at {vae_hw[1]}x{vae_hw[0]} ({t_vae:.1f}s), "
                       f"{fl / 1e12:.2f} TFLOP; scaled by the algorithmic FLOP model to {steps} steps + 2 enc + 1 dec per {W}x{H} frame, "
                       f"x{chunk / float(chunk - overlap):.2f} chunk overlap"}
 
