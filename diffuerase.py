@@ -24,14 +24,18 @@ propainter = None
 _run_config = None      # set through configure(); None = full SD-1.5 / sd-vae-ft-mse shapes
 _dist = None
 _gather = "all"
+_prior_stages = {}      # configure(prior=...): optional learned stages of the ProPainter prior (flow_completion, generator)
 
 
-def configure(run: RunConfig = None, dist=None, gather="all"):
+def configure(run: RunConfig = None, dist=None, gather="all", prior=None):
     """Select architecture / chunking / dtype for subsequently constructed models (tests use small configs).
     dist = (rank, world) with torch.distributed initialised, one process per GPU (torchrun); gather = "all": every rank returns
-    every frame; "rank0": only rank 0 does (the other ranks get None for frames they do not own and should not write a file)."""
-    global _run_config, _dist, _gather, last_ckpt
+    every frame; "rank0": only rank 0 does (the other ranks get None for frames they do not own and should not write a file).
+    prior = {"flow_completion": bool, "generator": bool}: run the learned stages of the full ProPainter prior (videovanish_amd/propainter.py;
+    off by default -- their trained weights are not reachable from the build image)."""
+    global _run_config, _dist, _gather, last_ckpt, _prior_stages, propainter
     _run_config, _dist, _gather, last_ckpt = run, dist, gather, None
+    _prior_stages, propainter = dict(prior or {}), None
 
 
 def run_infill_on_frames(frames_rgb, mask_frames, mask_dilation_iter=8, ckpt="2-Step",
@@ -57,7 +61,7 @@ def run_infill_on_frames(frames_rgb, mask_frames, mask_dilation_iter=8, ckpt="2-
 
     if propainer_frames is None:                                                # reference :47-57
         if propainter is None:
-            propainter = Propainter("ruffy369/propainter", device=device)
+            propainter = Propainter("ruffy369/propainter", device=device, **_prior_stages)
         if prog is not None: prog(20, "running propainter prior")
         propainer_frames = propainter.forward(frames_rgb, dilated_mask_frames, ref_stride=10, neighbor_length=10,
                                               subvideo_length=50, mask_dilation=0, progress=prog)

@@ -185,6 +185,31 @@ def test_drop_in_computes_flow_prior_when_none_supplied(gpu):
     diffuerase.configure(None)
 
 
+def test_drop_in_with_the_full_propainter_prior(gpu):
+    """configure(prior={"flow_completion": True, "generator": True}): the prior the drop-in computes is the complete ProPainter pipeline
+    (RAFT -> flow completion -> propagation -> inpainting generator with ref_stride = neighbor_length = 10, reference diffuerase.py:52-57)
+    feeding DiffuEraser.  Random weights: contract only -- it runs through the C ABI, honours the progress protocol and returns full-size frames
+    whose unmasked pixels are the originals."""
+    import diffuerase
+    T, H, W = 4, 64, 96
+    frames, masks, _ = _clip(T, H, W, seed=78)
+    run = RunConfig(steps=2, chunk=4, overlap=2, seed=3, dtype="fp16", unet=TINY_UNET, vae=TINY_VAE)
+    diffuerase.configure(run, prior={"flow_completion": True, "generator": True})
+    progs = []
+    out = diffuerase.run_infill_on_frames(frames, masks, mask_dilation_iter=2, max_img_size=960, prog=lambda p, s: progs.append((p, s)),
+                                          num_inference_steps=2, scheduler="ddim")
+    msgs = [m for _, m in progs]
+    assert "running flow prior (flow completion)" in msgs and "running flow prior (inpainting generator)" in msgs
+    assert len(out) == T and all(o.shape == (H, W, 3) and o.dtype == np.uint8 for o in out)
+    from oracle import pipeline_ref as R
+    dil = R.I.collapse_and_dilate(masks, 2)
+    far = np.stack([np.asarray(d) == 0 for d in dil])
+    import scipy.ndimage as ndi
+    far = np.stack([ndi.binary_erosion(f, iterations=6) for f in far])           # away from the feathered seam
+    assert np.array_equal(np.stack(out)[far], np.stack(frames)[far])
+    diffuerase.configure(None)
+
+
 def test_full_architecture_one_step(gpu):
     """The FULL SD-1.5 UNet + BrushNet + motion modules (320/640/1280/1280, 8 heads, d = 40/80/160) and the full SD-VAE
     (128/256/512/512, mid attention d = 512) at a small spatial size, fp16 operands, against the fp32 oracle with the same
