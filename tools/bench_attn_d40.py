@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Spatial attention d = 40 at the pipeline's shape (N = 14400, 8 heads, B frames; head-major QKV, q_prescaled): python tools/bench_attn_d40.py [B] [dtype]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from videovanish_amd import hip
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dname = sys.argv[2] if len(sys.argv) > 2 else "fp16"
+dev = torch.device("cuda:0")
+DT = hip.dtype_id(dname); td = hip.h16(DT)
+heads, N, D = 8, 14400, 40
+C = heads * D
+g = torch.Generator().manual_seed(0)
+qkv = torch.randn(B, 3, heads, N, D, generator=g)
+qkv[:, 0] *= hip.attention_q_scale(D)
+qkv = qkv.to(td).to(dev)
+out = torch.empty(B * N, C, dtype=td, device=dev)
+fn = lambda: hip.attention(DT, qkv, qkv, qkv, out, B=B, heads=heads, Nq=N, Nkv=N, D=D, q_bs=N * 3 * C, k_bs=N * 3 * C, v_bs=N * 3 * C, o_bs=N * C,
+                           q_rs=D, k_rs=D, v_rs=D, o_rs=C, k_off=N * C, v_off=2 * N * C, q_hs=N * D, k_hs=N * D, v_hs=N * D, q_prescaled=True)
+for _ in range(2):
+    fn()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+n = 5
+for _ in range(n):
+    fn()
+e1.record(); torch.cuda.synchronize()
+t = e0.elapsed_time(e1) / n * 1e-3
+print(f"{dname} spatial attention d40 N{N} x{B} frames: {t * 1e3:.3f} ms = {4.0 * B * heads * N * N * D / t / 1e12:.1f} TFLOP/s")
