@@ -57,7 +57,8 @@ __global__ void gn_stats_kernel(const vv_groupnorm_params p, const GNGeom g) {
         for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
         const int rbeg = split * g.rows_per_split;
         const int rend = min(rbeg + g.rows_per_split, p.HW);
-        for (int r = rbeg + r0; r < rend; r += g.krows) {
+        int r = rbeg + r0;
+        for (; r < rend; r += g.krows) {
             float v[8];
             gn_load8<T>(p, (int64_t)f * p.HW + r, chunk, v);
 #pragma unroll
@@ -105,6 +106,33 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const vv_groupnorm_par
     }
 }
 
+// pooled statistics (motion modules: one (mean, rstd) per group over the whole clip): ONE BLOCK PER GROUP sums the F * nsplit partials of its
+// group -- thread t takes partials t, t + 256, ... in double, then a fixed-order LDS tree -- instead of the single block of gn_finalize_kernel
+// walking 4096 partials with 8 lanes per group (0.17 ms of pure latency per launch at level 0).  Same order for every launch: deterministic.
+__global__ __launch_bounds__(256) void gn_finalize_pooled_kernel(const vv_groupnorm_params p, const GNGeom g) {
+    __shared__ double ss[256], sq[256];
+    const int C = p.C0 + p.C1, cpg = C / p.groups, grp = blockIdx.x, t = threadIdx.x;
+    const int nparts = p.F * g.nsplit;
+    double s = 0.0, q = 0.0;
+    for (int i = t; i < nparts; i += 256) {
+        const float* ws = p.stats_ws + ((int64_t)i * p.groups + grp) * 2;
+        s += ws[0]; q += ws[1];
+    }
+    ss[t] = s; sq[t] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) { ss[t] += ss[t + o]; sq[t] += sq[t + o]; }
+        __syncthreads();
+    }
+    const double n = (double)p.F * p.HW * cpg;
+    const double mean = ss[0] / n;
+    double var = sq[0] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    float* fin = p.stats_ws + (int64_t)p.F * g.nsplit * p.groups * 2;
+    for (int f = t; f < p.F; f += 256) { fin[((int64_t)f * p.groups + grp) * 2] = (float)mean; fin[((int64_t)f * p.groups + grp) * 2 + 1] = rstd; }
+}
+
 template <typename T>
 __global__ void gn_apply_kernel(const vv_groupnorm_params p, const GNGeom g) {
     const int t = threadIdx.x, split = blockIdx.x, f = blockIdx.y;
@@ -122,10 +150,7 @@ __global__ void gn_apply_kernel(const vv_groupnorm_params p, const GNGeom g) {
     }
     const int rbeg = split * g.rows_per_split;
     const int rend = min(rbeg + g.rows_per_split, p.HW);
-    for (int r = rbeg + r0; r < rend; r += g.krows) {
-        float v[8];
-        const int64_t pix = (int64_t)f * p.HW + r;
-        gn_load8<T>(p, pix, chunk, v);
+    auto emit = [&](float* v, int64_t pix) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float y = v[e] * a[e] + b[e];
@@ -134,6 +159,12 @@ __global__ void gn_apply_kernel(const vv_groupnorm_params p, const GNGeom g) {
         const int64_t o = pix * C + chunk * 8;
         if (p.out_dtype == VV_F32) { float4* d = (float4*)((float*)p.out + o); d[0] = *(float4*)&v[0]; d[1] = *(float4*)&v[4]; }
         else *(uint4*)((unsigned short*)p.out + o) = pack8<T>(v);
+    };
+    int r = rbeg + r0;
+    for (; r < rend; r += g.krows) {
+        float v[8];
+        gn_load8<T>(p, (int64_t)f * p.HW + r, chunk, v);
+        emit(v, (int64_t)f * p.HW + r);
     }
 }
 
@@ -192,7 +223,8 @@ int gn_launch(const vv_groupnorm_params& p, hipStream_t st, bool apply = true) {
     const GNGeom g = gn_geom(p.HW, C);
     const int threads = (g.threads + 63) / 64 * 64;
     hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), (size_t)2 * g.krows * C * sizeof(float), st, p, g);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.pool_frames ? 1 : p.F), dim3(256), 0, st, p, g);
+    if (p.pool_frames) hipLaunchKernelGGL(gn_finalize_pooled_kernel, dim3(p.groups), dim3(256), 0, st, p, g);
+    else hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.F), dim3(256), 0, st, p, g);
     if (apply) hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
     VV_CHECK_LAUNCH("vv_groupnorm");
     return VV_OK;
