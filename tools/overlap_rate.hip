@@ -55,6 +55,39 @@ template <int MODE, bool AGPR> void run(float* d, const char* name, int wps) {
     const double rounds = (double)wps * iters * (MODE == 3 ? 0.5 : 1.0);
     printf("%-64s %s %d waves/SIMD: %8.1f ns per (16 MFMA | 32 exp + 64 max3) round per SIMD\n", name, AGPR ? "agpr" : "vgpr", wps, ms * 1e6 / rounds);
 }
+// Exact pairing: ONE 512-thread block per CU, waves 0-3 (one per SIMD) run only the MFMA phase, waves 4-7 (the second wave of each SIMD) only the
+// VALU phase, same trip count -- the situation a "ping-pong" kernel with role-split wave groups creates.  MODE 0: both; 1: MFMA waves only (the others
+// exit); 2: VALU waves only.
+template <int MODE>
+__global__ __launch_bounds__(512) void kpair(float* out, int iters) {
+    f4 acc[8]; float a[8];
+    s8 x; for (int i = 0; i < 8; ++i) { x[i] = (short)(threadIdx.x + i); acc[i] = f4{0, 0, 0, 0}; a[i] = threadIdx.x * 0.001f + i; }
+    const bool mrole = threadIdx.x < 256;
+    if ((MODE == 1 && !mrole) || (MODE == 2 && mrole)) return;
+    for (int it = 0; it < iters; ++it) {
+        if (mrole) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %0" : "+v"(acc[i & 7]) : "v"(x));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                asm volatile("v_exp_f32 %0, %0" : "+v"(a[i & 7]));
+                asm volatile("v_max3_f32 %0, %0, %0, %0" : "+v"(a[(i + 1) & 7])); asm volatile("v_max3_f32 %0, %0, %0, %0" : "+v"(a[(i + 2) & 7]));
+            }
+        }
+    }
+    float s = 0; for (int i = 0; i < 8; ++i) s += a[i] + acc[i][0] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int MODE> void runpair(float* d, const char* name) {
+    const int iters = 4000, blocks = 256;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    kpair<MODE><<<blocks, 512>>>(d, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0); kpair<MODE><<<blocks, 512>>>(d, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-72s %8.1f ns per round (16 MFMA on one wave | 32 exp + 64 max3 on the other wave of the SIMD)\n", name, ms * 1e6 / iters);
+}
 int main() {
     float* d; hipMalloc(&d, 256 * 8 * 256 * 4);
     for (int wps : {2, 3, 4, 6}) {
@@ -66,5 +99,8 @@ int main() {
         run<4, false>(d, "interleaved in program order", wps);
         run<4, true>(d, "interleaved in program order", wps);
     }
+    runpair<1>(d, "paired waves: MFMA wave alone");
+    runpair<2>(d, "paired waves: VALU wave alone");
+    runpair<0>(d, "paired waves: MFMA wave + VALU wave on every SIMD");
     return 0;
 }
