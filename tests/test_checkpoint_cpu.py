@@ -101,3 +101,38 @@ def test_vae_legacy_attention_names():
         assert torch.equal(b, sd[f"decoder.mid_block.attentions.0.{old}.bias"])
     with pytest.raises(KeyError):
         ck.linear("vae.encoder.mid_block.attentions.0.to_q", 8, 8)
+
+
+def test_propainter_state_dicts_load_into_the_n1_networks():
+    """ProPainter's own checkpoints (recurrent_flow_completion.pth -> component "fc", ProPainter.pth -> "gen") use the module names that
+    flowcomplete.py / inpaintgen.py ask for; their Conv3d kernels are 5-D ((1,k,k) spatial, (3,1,1) temporal) and are folded to the 2-D / tap
+    forms on load.  Build a state dict in that layout from the oracle's parameters and read it back through CheckpointWeights."""
+    from oracle.model_ref import Params
+    from oracle import flowcomplete_ref as FC
+    P = Params(4)
+    g = torch.Generator().manual_seed(0)
+    fw = torch.randn(1, 2, 2, 16, 16, generator=g)
+    m = torch.zeros(1, 2, 1, 16, 16); m[..., 4:9, 5:11] = 1
+    with torch.no_grad():
+        FC.complete(P, fw * (1 - m), m, width=(8, 16, 32), deform_groups=4)                 # materialises every parameter the network uses
+    sd = {}
+    for key, val in P.cache.items():
+        w, b = val
+        if key.endswith("#t"):                                   # temporal taps [c, c, 3] -> Conv3d (3,1,1)
+            name = key[:-2]
+            sd[name[3:] + ".weight"], sd[name[3:] + ".bias"] = w[:, :, :, None, None].clone(), b.clone()
+        elif ".conv1.0" in key or ".downsample.0" in key or ".mid_dilation." in key:   # Conv3d (1,k,k)
+            sd[key[3:] + ".weight"], sd[key[3:] + ".bias"] = w[:, :, None].clone(), b.clone()
+        else:
+            sd[key[3:] + ".weight"], sd[key[3:] + ".bias"] = w.clone(), b.clone()
+    assert sd["downsample.0.weight"].shape == (8, 3, 1, 5, 5) and sd["encoder1.0.conv2.0.weight"].shape == (8, 8, 3, 1, 1)
+    ck = CheckpointWeights({"fc": sd})
+    w2, b2 = ck.conv("fc.downsample.0", 3, 8, 5)
+    assert torch.equal(w2, P.cache["fc.downsample.0"][0]) and torch.equal(b2, P.cache["fc.downsample.0"][1])
+    wt = ck.normal("fc.encoder1.0.conv2.0.weight", (8, 8, 3))
+    assert torch.equal(wt, P.cache["fc.encoder1.0.conv2.0#t"][0])
+    wd, _ = ck.conv("fc.feat_prop_module.deform_align.backward_", 64, 32, 3)
+    assert torch.equal(wd, P.cache["fc.feat_prop_module.deform_align.backward_"][0])
+    with pytest.raises(ValueError):
+        ck.conv("fc.downsample.0", 3, 8, 3)                      # a kernel of the wrong size is refused, not reshaped
+    assert map_name("gen.transformers.transformer.3.attention.query") == ("gen", "transformers.transformer.3.attention.query")

@@ -1,6 +1,7 @@
 """Real-weight source: serves the same interface as weights.SyntheticWeights from diffusers-format
 state dicts / safetensors files, so the HIP model can be built from the checkpoints the reference names at
-diffuerase.py:41-43,49 (SD-1.5 UNet + motion adapter, BrushNet, sd-vae-ft-mse, RAFT) when they are available locally.
+diffuerase.py:41-43,49 (SD-1.5 UNet + motion adapter, BrushNet, sd-vae-ft-mse, RAFT, and the two ProPainter networks: components "fc" =
+RecurrentFlowCompleteNet, "gen" = InpaintGenerator) when they are available locally.
 
 Internal parameter names are the diffusers names prefixed by a component ("unet.", "brushnet.", "vae.", "raft."); the only
 renames are listed in `map_name`.  No network access is attempted: pass local files or in-memory dicts.
@@ -21,6 +22,8 @@ def map_name(name):
             key = "conv_in_condition" + key[len("conv_in"):]
     elif comp == "raft":
         key = re.sub(r"^update\.", "update_block.", key)      # princeton-vl RAFT: fnet.*, cnet.*, update_block.*
+    elif comp in ("fc", "gen"):
+        pass      # ProPainter's own module names (recurrent_flow_completion.pth / ProPainter.pth): flowcomplete.py and inpaintgen.py use them as they are
     elif comp != "vae":
         raise KeyError(f"unknown component in parameter name {name!r}")
     return comp, key
@@ -64,8 +67,11 @@ class CheckpointWeights:
             n_need = 1
             for d in shape:
                 n_need *= int(d)
+            squeezed = tuple(d for d in t.shape if d != 1) == tuple(int(d) for d in shape if d != 1)
             if t.numel() == n_need and ((len(shape) == 4 and t.dim() == 2) or (len(shape) == 2 and t.dim() == 4 and t.shape[2:] == (1, 1))):
                 t = t.reshape(shape)          # linear-projection checkpoints of 1x1 convs, and 1x1-conv exports of linear projections
+            elif t.numel() == n_need and t.dim() == 5 and squeezed:
+                t = t.reshape(shape)          # ProPainter Conv3d kernels: (1,k,k) -> a 2-D kernel, (3,1,1) -> the three temporal taps
             else:
                 raise ValueError(f"{comp}:{full} has shape {tuple(t.shape)}, the architecture needs {tuple(shape)}")
         return t.contiguous()
