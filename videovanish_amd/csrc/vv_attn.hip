@@ -48,6 +48,8 @@ __device__ __forceinline__ void glds16_asm(const void* gptr, void* lds_wave_base
 // denominator rides the ONES column of V in fp32): a tile whose packed P has any value >= 2.0 -- one OR tree over the packed registers,
 // bit 14 is the top exponent bit of both h16 formats -- takes the slow path (wave-uniform branch: QK^T again, classic maximum, rescale
 // of O^T, new pad slots).  Tile 0 always takes it.  Results equal the classic form up to the rounding of c*q to h16.
+// Range: the reference maximum itself has to fit the h16 format (|c q.k| < 65504 for fp16 operands; bf16 has the fp32 range) -- far beyond what
+// LayerNorm-ed attention inputs produce (|c q.k| of a few tens); the classic kernel (every other head dim) keeps the maximum in fp32.
 template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0, bool LAZY = false, int HACK = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params p, const int nqt) {
     constexpr int DK = (D + 31) / 32 * 32, DKC = DK / 8, KS = DK / 32;
