@@ -315,7 +315,7 @@ def main():
                                f"{args.arch} SD-1.5 UNet+BrushNet+motion / SD-VAE, random-init weights",
                    "frames_per_step": args.chunk, "credited_frames_per_step": stride, "chunks_per_rank": args.steps,
                    "parallelism": f"chunk-dp{world}", "model_build_s": round(t_build, 1), "precise_decoder": bool(args.precise_decoder),
-                   "parity": "per-pixel max-abs vs the fp32 oracle at 50 steps: fp16 + split-precision decoder 5e-4 (tiny/small width), 8.8e-4 (c1, full width); "
+                   "parity": "per-pixel max-abs vs the fp32 oracle at 50 steps: fp16 + split-precision decoder 5e-4 (tiny/small width), 8.9e-4 (c1, full width); "
                              "fp16 1.2e-3 / 2.3e-3; bf16 9.5e-3 (profiles/r2_parity_gpu.txt)"},
         "roofline": roof, "temporal_block": temporal, "cpu_baseline": cpu,
         "job_tflops": round(__import__("videovanish_amd.flops", fromlist=["x"]).per_output_frame(H, W, args.chunk, args.denoise_steps, ucfg, vcfg)
