@@ -102,7 +102,7 @@ def strong_scaling(args, model, dist, rank, world, H, W, ucfg, vcfg):
     fl = flops.per_output_frame(H, W, args.chunk, args.denoise_steps, ucfg, vcfg) * args.chunk * len(plan) * reps
     ideal = len(plan) / max(len(s) for s in shard_chunks(len(plan), world))
     return {
-        "metric": "inpainted frames/sec at 720p, 50 denoise steps", "value": round(T * reps / dt, 5), "unit": "frames/s", "n_gpus": world,
+        "metric": f"inpainted frames/sec at {H}p, {args.denoise_steps} denoise steps", "value": round(T * reps / dt, 5), "unit": "frames/s", "n_gpus": world,
         "steps": reps, "warmup": args.warmup, "ms_per_step": round(dt / reps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{ {720: 'c3', 1080: 'c4', 480: 'c2'}.get(H, 'custom') }: fixed {T}-frame {W}x{H} clip, {args.denoise_steps} DDIM steps, "
@@ -113,6 +113,22 @@ def strong_scaling(args, model, dist, rank, world, H, W, ucfg, vcfg):
         "job_tflops": round(fl / dt / 1e12, 1), "collective_backend": backend,
         "per_rank_seconds": per_rank,
     }
+
+
+def parity_summary():
+    """The measured parity lines of the default precision plan, read from the newest committed GPU parity log
+    (profiles/r*_parity_gpu.txt, written by `VV_PARITY_REPORT=... pytest -m gpu tests/test_configs_gpu.py`): nothing is hard-coded here."""
+    import glob
+    import re
+    logs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_gpu.txt")), key=lambda p: int(re.search(r"r(\d+)_", os.path.basename(p)).group(1)))
+    if not logs:
+        return None
+    keep = {}
+    for line in open(logs[-1]):
+        m = re.match(r"(parity50\[[^\]]*precise-decoder\]|c1_full_width\[[^\]]*\]) pixel max_abs=([0-9.e+-]+)", line)
+        if m:
+            keep[m.group(1)] = float(m.group(2))      # the last occurrence of a key wins (the log is appended per run)
+    return {"source": os.path.relpath(logs[-1], ROOT), "per_pixel_max_abs_vs_fp32_oracle": keep, "bound": 1.0e-3}
 
 
 def synth_clip(T, H, W, seed=1234, t0=0):
@@ -291,7 +307,9 @@ def main():
         except Exception:
             traffic = None
         roof = {"kernel": dom, "bound": "mfma" if mfma else "hbm", "achieved": round(ach, 2), "peak": peak,
-                "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "traffic": traffic, "launches": n,
+                "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                "traffic_source": "profiles/traffic_table.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; gfx950 x2 FETCH correction)" if traffic else None,
+                "launches": n,
                 "avg_launch_ms": round(tsec / n * 1e3, 4), "algorithmic_per_launch": (fl if mfma else by) / n,
                 "share_of_step_time": round(tsec / dt, 3)}
     # ---- the north star's own target: the fused temporal block (21 motion modules) against the MFMA roofline
@@ -315,8 +333,7 @@ def main():
                                f"{args.arch} SD-1.5 UNet+BrushNet+motion / SD-VAE, random-init weights",
                    "frames_per_step": args.chunk, "credited_frames_per_step": stride, "chunks_per_rank": args.steps,
                    "parallelism": f"chunk-dp{world}", "model_build_s": round(t_build, 1), "precise_decoder": bool(args.precise_decoder),
-                   "parity": "per-pixel max-abs vs the fp32 oracle at 50 steps: fp16 + split-precision decoder 5e-4 (tiny/small width), 8.9e-4 (c1, full width); "
-                             "fp16 1.2e-3 / 2.3e-3; bf16 9.5e-3 (profiles/r2_parity_gpu.txt)"},
+                   "parity": parity_summary()},
         "roofline": roof, "temporal_block": temporal, "cpu_baseline": cpu,
         "job_tflops": round(__import__("videovanish_amd.flops", fromlist=["x"]).per_output_frame(H, W, args.chunk, args.denoise_steps, ucfg, vcfg)
                             * args.chunk * args.steps * world / dt / 1e12, 1),

@@ -92,14 +92,25 @@ def run_infill_on_frames(frames_rgb, mask_frames, mask_dilation_iter=8, ckpt="2-
     return inpainted_frames
 
 
+def _frame_io():
+    """The reference's own frame I/O helper `tools` (cv2; reference tools.py:4-45) when the drop-in sits next to the GUI, else the
+    cv2-free FFV1 / Matroska module with the same two functions.  The test is for the API, not for the import: a
+    directory called tools/ next to this file imports as an (empty) namespace package."""
+    try:
+        import tools
+        if callable(getattr(tools, "load_video_frames_from_path", None)) and callable(getattr(tools, "write_video_frames_to_path", None)):
+            return tools
+    except ImportError:
+        pass
+    from videovanish_amd import frameio
+    return frameio
+
+
 # =============================
 # CLI entry point (reference diffuerase.py:121-155)
 # =============================
 def main():
-    try:
-        import tools  # the reference's own frame I/O helper (cv2), when the drop-in sits next to the GUI
-    except ImportError:
-        from videovanish_amd import frameio as tools   # cv2-free FFV1 / Matroska I/O with the same two functions
+    tools = _frame_io()
     ap = argparse.ArgumentParser(description="Remove masked objects from a video (DiffuEraser hot path on MI355X).")
     ap.add_argument("--color_video", required=True, type=str, help="Input color video path.")
     ap.add_argument("--mask_video", required=True, type=str, help="Input mask video path.")

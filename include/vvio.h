@@ -24,8 +24,10 @@ int vvio_ffv1_config_record(int num_v_slices, uint8_t* out, int cap);
 int vvio_ffv1_encode_frame(const uint8_t* rgb, int W, int H, int num_v_slices, uint8_t* out, int cap);
 
 /* FFV1 packet + configuration record -> RGB24 (W*H*3 bytes).  Accepts what this encoder writes and the subset of FFV1 v3 streams with the
- * same parameters (8-bit RGB, Golomb-Rice sample coding = coder_type 0, any slice grid, 3- or 5-input quantisation tables, CRC on or off;
- * range-coded sample data is refused with an error).
+ * same colour model: 8-bit RGB (JPEG 2000 RCT), with or without an extra (alpha) plane (decoded and dropped); Golomb-Rice (coder_type 0)
+ * or range-coded samples with the default (coder_type 1) or a custom (coder_type 2) state-transition table; any num_h_slices x num_v_slices
+ * grid; up to 8 quantisation-table sets with 3 or 5 context inputs; CRC on or off.  Refused with an error code: YCbCr streams, > 8 bits per
+ * sample, coded initial states, inter (non-key) frames, and any header field outside its range (the stream is untrusted input).
  * 0 = ok, negative = error code.  Replaces VideoCapture.read (reference tools.py:17-21). */
 int vvio_ffv1_decode_frame(const uint8_t* cfg, int cfglen, const uint8_t* data, int len, int W, int H, uint8_t* rgb);
 

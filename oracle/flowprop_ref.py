@@ -252,7 +252,7 @@ def propagate(frames_u8, masks_u8, flows_fw, flows_bw):
     return res, (fa | fb).numpy()
 
 
-def subvideo_ranges(T, subvideo_length, pad_len=5):
+def subvideo_ranges(T, subvideo_length, pad_len=10):
     """Sub-video schedule of ProPainter's image propagation ([UNVERIFIED-3P], public inference script): sub-videos of
     min(100, subvideo_length) frames, each propagated together with pad_len frames of context on both sides; only the inner
     frames are kept.  Returns [(s_f, e_f, keep_lo, keep_hi)] in frame indices."""

@@ -89,6 +89,8 @@ def denoise_chunk(P, img, m, prior, noise, steps, ucfg, vcfg, scheduler="ddim", 
     if trace is not None:
         trace.update(lat_final=lat.clone())
     dec = M.vae_decode(P, lat, vcfg)
+    if trace is not None:
+        trace.update(decoded_raw=dec.clone())      # before the clamp to [0,1]: the tests also bound the error of the unclamped decode
     return (dec / 2 + 0.5).clamp(0, 1)
 
 

@@ -20,5 +20,5 @@ def run():
     got, _ = DiffuEraserHIP(run_cfg).forward(frames, m2d, prior, return_float=True)
     ref = R.diffueraser_forward(frames, m2d, prior, steps=2, chunk=4, overlap=2, seed=5, ucfg=TINY_UNET, vcfg=TINY_VAE, return_float=True)
     err = float(np.abs(got - ref).max())
-    assert np.isfinite(got).all() and err <= 1.5e-3, f"smoke parity failed: max-abs {err}"
+    assert np.isfinite(got).all() and err <= 1.0e-3, f"smoke parity failed: max-abs {err}"
     print(f"smoke ok: 4-frame 32x40 clip, 2 DDIM steps on {torch.cuda.get_device_name(0)}; max-abs vs oracle {err:.2e} (fp16 operands, split-precision VAE decoder)")

@@ -206,20 +206,21 @@ def test_subvideo_propagation_matches_oracle(gpu):
         m = np.zeros((H, W), np.uint8)
         m[H // 4: 3 * H // 4, W // 4: 3 * W // 4] = 255      # static hole + sub-pixel flows: filling it needs long-range propagation
         masks.append(m)
-    assert flowprop.subvideo_ranges(T, 4) == FP.subvideo_ranges(T, 4) == [(0, 9, 0, 4), (0, 13, 4, 8), (3, 13, 8, 12), (7, 13, 12, 13)]
-    assert flowprop.subvideo_ranges(60, 50) == [(0, 55, 0, 50), (45, 60, 50, 60)] and flowprop.subvideo_ranges(50, 50) == [(0, 50, 0, 50)]
+    assert flowprop.subvideo_ranges(T, 4, 3) == FP.subvideo_ranges(T, 4, 3) == [(0, 7, 0, 4), (1, 11, 4, 8), (5, 13, 8, 12), (9, 13, 12, 13)]
+    # defaults: 10 frames of context on both sides of a sub-video (the reference passes subvideo_length=50, diffuerase.py:54)
+    assert flowprop.subvideo_ranges(60, 50) == FP.subvideo_ranges(60, 50) == [(0, 60, 0, 50), (40, 60, 50, 60)] and flowprop.subvideo_ranges(50, 50) == [(0, 50, 0, 50)]
     g = torch.Generator().manual_seed(3)
     fw = [torch.randn(2, H, W, generator=g) * 0.4 for _ in range(T - 1)]
     bw = [-f + 0.05 * torch.randn(2, H, W, generator=g) for f in fw]
     ref = [None] * T
-    for (s, e, lo, hi) in FP.subvideo_ranges(T, 4):
+    for (s, e, lo, hi) in FP.subvideo_ranges(T, 4, 3):
         sub, _ = FP.propagate(np.stack(frames[s:e]), np.stack(masks[s:e]), fw[s:e - 1], bw[s:e - 1])
         for t in range(lo, hi):
             ref[t] = sub[t - s]
     to_dev = lambda f: f.permute(1, 2, 0).contiguous().to(gpu)
     fr, mk = torch.from_numpy(np.stack(frames)).to(gpu), torch.from_numpy(np.stack(masks)).to(gpu)
     out = torch.empty_like(fr)
-    for (s, e, lo, hi) in flowprop.subvideo_ranges(T, 4):
+    for (s, e, lo, hi) in flowprop.subvideo_ranges(T, 4, 3):
         sub, _ = flowprop.propagate(fr[s:e].contiguous(), mk[s:e].contiguous(), [to_dev(f) for f in fw[s:e - 1]], [to_dev(f) for f in bw[s:e - 1]])
         out[lo:hi] = sub[lo - s: hi - s]
     assert np.array_equal(out.cpu().numpy(), np.stack(ref))

@@ -25,7 +25,8 @@ def _case(T, H, W, seed):
     return fw, bw, m
 
 
-@pytest.mark.parametrize("dname,tol", [("fp16", 4e-3), ("bf16", 3e-2)])
+# tolerances = 2 x the measured error (tools/n1_margins.py: fp16 1.0e-3, bf16 1.1e-2)
+@pytest.mark.parametrize("dname,tol", [("fp16", 2e-3), ("bf16", 2.2e-2)])
 def test_flow_completion_matches_oracle(gpu, dname, tol):
     from oracle import flowcomplete_ref as FC
     from oracle.model_ref import Params

@@ -116,3 +116,89 @@ def test_cli_end_to_end_with_own_frame_io(tmp_path, monkeypatch):
     diffuerase.main()
     out, fps = FIO.load_video_frames_from_path(color + "_vanished.mkv")
     assert abs(fps - 25.0) < 1e-3 and len(out) == T and all(np.array_equal(o, 255 - f) for o, f in zip(out, frames))
+
+
+def test_cli_frame_io_selection_without_stub(tmp_path, monkeypatch):
+    """from the repo root `import tools` SUCCEEDS (the repo's tools/ directory of bench scripts is a namespace package without
+    the two I/O functions), so the CLI must test for the API, not for the import.  No sys.modules stub here."""
+    import importlib
+    import os
+    import sys
+    import diffuerase
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.chdir(root)
+    monkeypatch.delitem(sys.modules, "tools", raising=False)
+    if root not in sys.path:
+        monkeypatch.syspath_prepend(root)
+    t = importlib.import_module("tools")                          # the namespace package: importable, but no frame I/O in it
+    assert not hasattr(t, "load_video_frames_from_path")
+    assert diffuerase._frame_io() is FIO
+    T, H, W = 3, 16, 24
+    frames = _frames(T, H, W, 2, "smooth")
+    masks = [np.zeros((H, W, 3), np.uint8) for _ in range(T)]
+    color, mask = str(tmp_path / "c.mkv"), str(tmp_path / "m.mkv")
+    FIO.write_video_frames_to_path(color, frames, 24.0, H, W)
+    FIO.write_video_frames_to_path(mask, masks, 24.0, H, W)
+    monkeypatch.setattr(diffuerase, "run_infill_on_frames", lambda fr, mk, **kw: [f[::-1].copy() for f in fr])
+    monkeypatch.setattr(sys, "argv", ["diffuerase.py", "--color_video", color, "--mask_video", mask])
+    diffuerase.main()
+    out, _ = FIO.load_video_frames_from_path(color + "_vanished.mkv")
+    assert len(out) == T and all(np.array_equal(o, f[::-1]) for o, f in zip(out, frames))
+
+
+# ---- independent fixtures: packets written by a SECOND encoder (pure Python, from RFC 9043: tests/ffv1_pyenc.py) in the forms
+#      libavcodec emits by default and the C encoder cannot produce: range-coded samples, a 2 x 2 slice grid, two quantisation-table
+#      sets (one with 5 context inputs), the alternative state-transition table (coder_type 2), an extra (alpha) plane, no CRC
+@pytest.mark.parametrize("coder,nh,nv,alpha,ec", [(1, 2, 2, False, 1), (2, 1, 3, False, 0), (1, 3, 1, True, 1), (2, 2, 2, True, 1)])
+def test_ffv1_decodes_range_coded_packets_of_an_independent_encoder(coder, nh, nv, alpha, ec):
+    from tests import ffv1_pyenc as PY
+    H, W = 13, 18
+    rng = np.random.default_rng(coder * 10 + nh)
+    f = _frames(1, H, W, 3 + coder, "smooth")[0]
+    f[2:5, 3:9] = (250, 3, 128)                                   # a flat patch and a few outliers: large and zero residuals
+    f[7, 11] = (0, 255, 0)
+    a = rng.integers(0, 256, (H, W), dtype=np.uint8) if alpha else None
+    cfg = PY.config_record(coder, nh, nv, alpha=alpha, ec=ec)
+    pkt = PY.encode_frame(f, coder, nh, nv, alpha=a, ec=ec)
+    assert np.array_equal(FIO.ffv1_decode(cfg, pkt, W, H), f)
+    # and the noise image (every context, long symbols)
+    g = _frames(1, H, W, 9, "noise")[0]
+    assert np.array_equal(FIO.ffv1_decode(cfg, PY.encode_frame(g, coder, nh, nv, alpha=a, ec=ec), W, H), g)
+
+
+def test_ffv1_default_state_transition_is_rfc9043_table():
+    """RFC 9043 3.8.1.5 default_state_transition, first and last rows of the published listing, against the Python construction the
+    fixture encoder uses (the C decoder builds the same table: a packet coded with it decodes, test above)."""
+    from tests import ffv1_pyenc as PY
+    t = PY.default_state_transition()
+    assert t[:16] == [0, 0, 0, 0, 0, 0, 0, 0, 20, 21, 22, 23, 24, 25, 26, 27]
+    assert t[16:32] == [28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 37, 38, 39, 40, 41, 42]
+    assert t[240:] == [241, 242, 243, 244, 245, 246, 247, 248, 248, 0, 0, 0, 0, 0, 0, 0]
+    assert all(t[i] > i for i in range(8, 248)) and t[248] == 248
+
+
+def test_ffv1_decoder_rejects_crafted_headers():
+    """header symbols come from a user-supplied file.  Out-of-range slice positions, table-set indices, slice grids and
+    over-long symbols must be refused, not used as array indices."""
+    from tests import ffv1_pyenc as PY
+    H, W = 8, 8
+    f = _frames(1, H, W, 1, "smooth")[0]
+
+    def packet(sx, sy, sw1, sh1, q0, q1):
+        rc = PY.RangeEncoder()
+        rc.put([128], 0, 1)
+        st = [128] * 32
+        for v in (sx, sy, sw1, sh1, q0, q1, 3, 0, 0):
+            rc.put_symbol(st, v, False)
+        body = rc.terminate() + bytes(64)
+        sl = bytearray(body) + len(body).to_bytes(3, "big") + b"\x00"
+        return bytes(sl + PY.crc32_mpeg(bytes(sl)).to_bytes(4, "big"))
+    cfg = PY.config_record(1, 2, 2)
+    for bad in [(2, 0, 0, 0, 0, 1), (0, 2, 0, 0, 0, 1), (0, 0, 2, 0, 0, 1), (0, 0, 0, 2, 0, 1), (0, 0, 0, 0, 2, 1), (0, 0, 0, 0, 0, 5),
+                (1, 1, 1, 0, 0, 1), (0, 0, (1 << 31) - 2, 0, 0, 1), (0, 0, 0, 0, (1 << 32) - 1, 0)]:
+        with pytest.raises(RuntimeError):
+            FIO.ffv1_decode(cfg, packet(*bad), W, H)
+    good = PY.encode_frame(f, 1, 2, 2)
+    assert np.array_equal(FIO.ffv1_decode(cfg, good, W, H), f)
+    with pytest.raises(RuntimeError):                             # a slice grid of 2^20 x 1 in the configuration record
+        FIO.ffv1_decode(PY.config_record(1, 1 << 20, 1), good, W, H)

@@ -29,13 +29,14 @@ def _case(t, lt, H, W, seed):
     return frames, m_in, m_up, ff, fb
 
 
-@pytest.mark.parametrize("dname,tol", [("fp16", 1.5e-2), ("bf16", 8e-2)])
-def test_generator_matches_oracle(gpu, dname, tol):
+# tolerances = 2 x the measured error (tools/n1_margins.py, profiles/r3_n1_margins.txt: fp16 1.8e-3, bf16 1.25e-2 at 2 blocks)
+@pytest.mark.parametrize("dname,tol,depths", [("fp16", 3.6e-3, 2), ("bf16", 2.5e-2, 2), ("fp16", 6e-3, 8)])
+def test_generator_matches_oracle(gpu, dname, tol, depths):
     from oracle import inpaintgen_ref as G
     from oracle.model_ref import Params
     from videovanish_amd import nn
     from videovanish_amd.inpaintgen import InpaintGenerator
-    t, lt, H, W, depths = 5, 3, 80, 144, 2
+    t, lt, H, W = 5, 3, 80, 144                 # depths = 8: the published ProPainter depth (all 8 sparse-window transformer blocks)
     frames, m_in, m_up, ff, fb = _case(t, lt, H, W, 4)
     P = Params(21)
     fr = torch.from_numpy(frames).float().permute(0, 3, 1, 2)[None] / 127.5 - 1.0

@@ -6,9 +6,12 @@
  *   version 3, micro_version 4; coder_type 0 (Golomb-Rice sample coding, range coder for the headers); colorspace_type 1
  *   (RGB through the reversible JPEG 2000 RCT, planes G, B-G, R-G coded with 9 bits); no alpha; num_h_slices = 1,
  *   num_v_slices >= 1 (horizontal bands); ec = 1 (CRC-32 per slice and on the configuration record); intra = 1.
- * The decoder additionally accepts any quantisation-table set with 3 or 5 context inputs and states_coded = 0.
- * Range-coded sample data (coder_type 1/2) is refused: it needs RFC 9043's default_state_transition table, which this file
- * does not carry.
+ * The decoder additionally accepts: any quantisation-table set with 3 or 5 context inputs (states_coded = 0); num_h_slices > 1
+ * (the 2 x 2 slice grid libavcodec picks by default); range-coded sample data -- coder_type 1 (RFC 9043 3.8.1.5
+ * default_state_transition = the table build_rac_states() computes, checked against the RFC's listing in the tests) and
+ * coder_type 2 (custom table: deltas to the default in the configuration record); an extra (alpha) plane, decoded and dropped.
+ * Refused with an error code: YCbCr streams (colorspace_type 0), more than 8 bits per sample, coded initial states, inter
+ * (non-key) frames.  Every header field read from the file is range-checked before it is used.
  *
  * PARITY UNPINNED against a real FFV1 decoder (no ffmpeg / cv2 in the build image): restated from RFC 9043 and the public
  * libavcodec ffv1 sources; pinned here only by lossless round trips and structural checks (tests/test_frameio_cpu.py).
@@ -159,6 +162,7 @@ static int get_symbol(RangeCoder* c, uint8_t* state, int is_signed, int* err) {
     while (get_rac(c, state + 1 + (e < 9 ? e : 9))) { if (++e > 31) { *err = 1; return 0; } }
     for (i = e - 1; i >= 0; i--) a += a + get_rac(c, state + 22 + (i < 9 ? i : 9));
     int s = -(is_signed && get_rac(c, state + 11 + (e < 10 ? e : 10)));
+    if (a > 0x7FFFFFFFu) { *err = 1; return 0; }       /* e == 31: does not fit an int (a crafted header) */
     return (int)((a ^ (unsigned)s) - (unsigned)s);
 }
 
@@ -288,6 +292,7 @@ static int read_quant_table(RangeCoder* c, int16_t* tab, int scale) {
 /* ----------------------------------------------------------------------------------------------- configuration record */
 typedef struct {
     int version, micro, coder, colorspace, bits, chroma_planes, hshift, vshift, alpha, nh, nv, nsets, ec, intra;
+    uint8_t one_state[256];           /* coder_type 2: the custom state transition table (RFC 9043 4.2.3 state_transition_delta) */
     QuantSet sets[8];
 } Config;
 
@@ -333,7 +338,14 @@ static int parse_config(const uint8_t* rec, int len, Config* cf) {
     if (cf->version < 3) return -2;
     cf->micro = get_symbol(&c, state, 0, &err);
     cf->coder = get_symbol(&c, state, 0, &err);
-    if (cf->coder != 0) return -3;             /* range-coded samples need the static default_state_transition table */
+    if (err || cf->coder < 0 || cf->coder > 2) return -3;
+    if (cf->coder == 2) {                      /* custom table = default_state_transition (what build_rac_states made) + coded deltas */
+        for (int i = 1; i < 256; ++i) {
+            const int v = get_symbol(&c, state, 1, &err) + c.one_state[i];
+            if (err || v < 1 || v > 255) return -3;
+            cf->one_state[i] = (uint8_t)v;
+        }
+    }
     cf->colorspace = get_symbol(&c, state, 0, &err);
     cf->bits = get_symbol(&c, state, 0, &err);
     cf->chroma_planes = get_rac(&c, state);
@@ -360,7 +372,8 @@ static int parse_config(const uint8_t* rec, int len, Config* cf) {
     cf->ec = get_symbol(&c, state, 0, &err);
     if (cf->version > 2 && cf->micro > 2) cf->intra = get_symbol(&c, state, 0, &err);
     if (err) return -7;
-    if (cf->colorspace != 1 || cf->bits > 8 || cf->alpha || cf->nh != 1) return -8;
+    if (cf->colorspace != 1 || (cf->bits != 0 && cf->bits != 8)) return -8;       /* 8-bit RGB (JPEG 2000 RCT) only */
+    if (cf->nh < 1 || cf->nv < 1 || cf->nh > 64 || cf->nv > 64 || cf->ec < 0 || cf->ec > 2) return -8;
     return 0;
 }
 
@@ -475,81 +488,117 @@ static int decode_slice(const Config* cf, const uint8_t* data, int len, int firs
     RangeCoder c;
     uint8_t state[CONTEXT_SIZE];
     int err = 0;
+    const int ac = cf->coder != 0;                     /* sample data range coded (coder_type 1 / 2) instead of Golomb-Rice */
+    const int nplanes = 3 + (cf->alpha ? 1 : 0);       /* G, B-G, R-G (JPEG 2000 RCT) [, alpha: decoded, dropped] */
+    const int nqi = 1 + (cf->chroma_planes ? 1 : 0) + (cf->alpha ? 1 : 0);
     rc_init_dec(&c, data, len);
     if (first) { uint8_t keystate = 128; if (!get_rac(&c, &keystate)) return -20; }    /* intra-only streams: every frame is a key frame */
+    if (cf->coder == 2)                                /* custom state transitions: from here on (libavcodec ff_ffv1_init_slice_state) */
+        for (int i = 1; i < 256; ++i) { c.one_state[i] = cf->one_state[i]; c.zero_state[256 - i] = (uint8_t)(256 - cf->one_state[i]); }
     memset(state, 128, sizeof(state));
     const int sx = get_symbol(&c, state, 0, &err), sy = get_symbol(&c, state, 0, &err);
     const int sw = get_symbol(&c, state, 0, &err) + 1, sh = get_symbol(&c, state, 0, &err) + 1;
-    const int qi0 = get_symbol(&c, state, 0, &err), qi1 = get_symbol(&c, state, 0, &err);
+    int qi[3] = {0, 0, 0};
+    for (int i = 0; i < nqi; ++i) qi[i] = get_symbol(&c, state, 0, &err);
+    if (!cf->chroma_planes) { qi[2] = qi[1]; qi[1] = qi[0]; }
     (void)get_symbol(&c, state, 0, &err); (void)get_symbol(&c, state, 0, &err); (void)get_symbol(&c, state, 0, &err);
-    if (err || sx != 0 || sw != 1 || sy < 0 || sy + sh > cf->nv || qi0 >= cf->nsets || qi1 >= cf->nsets) return -21;
-    if (cf->micro > 1) { uint8_t st = 129; (void)get_rac(&c, &st); }
-    const int ac_bytes = (int)(c.ptr - c.start) - 1;
-    if (ac_bytes < 0 || ac_bytes > len) return -22;
-    BitR br = {data + ac_bytes, (int64_t)(len - ac_bytes) * 8, 0, 0};
+    /* every field came from the file: refuse anything outside the slice grid / the table sets before it indexes memory */
+    if (err || sx < 0 || sy < 0 || sw < 1 || sh < 1 || sx > cf->nh - sw || sy > cf->nv - sh) return -21;
+    for (int i = 0; i < 3; ++i) if (qi[i] < 0 || qi[i] >= cf->nsets) return -21;
     const int y0 = (int)((int64_t)sy * H / cf->nv), h = (int)((int64_t)(sy + sh) * H / cf->nv) - y0;
-    const QuantSet* qs[2] = {&cf->sets[qi0], &cf->sets[qi1]};
-    VlcState* vlc[2];
-    for (int p = 0; p < 2; ++p) {
-        vlc[p] = (VlcState*)malloc(sizeof(VlcState) * (size_t)qs[p]->context_count);
-        if (!vlc[p]) return -23;
-        for (int i = 0; i < qs[p]->context_count; ++i) { vlc[p][i].drift = 0; vlc[p][i].error_sum = 4; vlc[p][i].bias = 0; vlc[p][i].count = 1; }
+    const int x0 = (int)((int64_t)sx * W / cf->nh), w = (int)((int64_t)(sx + sw) * W / cf->nh) - x0;
+    if (w < 1 || h < 1 || x0 + w > W || y0 + h > H) return -21;
+    BitR br = {data, 0, 0, 0};
+    if (!ac) {
+        if (cf->micro > 1) { uint8_t st = 129; (void)get_rac(&c, &st); }
+        const int ac_bytes = (int)(c.ptr - c.start) - 1;
+        if (ac_bytes < 0 || ac_bytes > len) return -22;
+        br.buf = data + ac_bytes; br.nbits = (int64_t)(len - ac_bytes) * 8;
     }
-    const int LW = W + 6;
-    int16_t* lines = (int16_t*)calloc((size_t)3 * 3 * LW, sizeof(int16_t));
-    if (!lines) { free(vlc[0]); free(vlc[1]); return -23; }
+    const QuantSet* qs[3] = {&cf->sets[qi[0]], &cf->sets[qi[1]], &cf->sets[qi[2]]};
+    VlcState* vlc[3] = {0, 0, 0};
+    uint8_t* rst[3] = {0, 0, 0};                       /* range-coder mode: CONTEXT_SIZE adaptive states per context, initial value 128 */
+    int fail = 0;
+    for (int p = 0; p < 3; ++p) {
+        const int n = qs[p]->context_count;
+        if (n < 1 || n > MAX_CTX) { fail = 1; break; }
+        if (ac) {
+            rst[p] = (uint8_t*)malloc((size_t)n * CONTEXT_SIZE);
+            if (!rst[p]) { fail = 1; break; }
+            memset(rst[p], 128, (size_t)n * CONTEXT_SIZE);
+        } else {
+            vlc[p] = (VlcState*)malloc(sizeof(VlcState) * (size_t)n);
+            if (!vlc[p]) { fail = 1; break; }
+            for (int i = 0; i < n; ++i) { vlc[p][i].drift = 0; vlc[p][i].error_sum = 4; vlc[p][i].bias = 0; vlc[p][i].count = 1; }
+        }
+    }
+    const int LW = w + 6;
+    int16_t* lines = fail ? 0 : (int16_t*)calloc((size_t)4 * 3 * LW, sizeof(int16_t));
+    if (!lines) { for (int p = 0; p < 3; ++p) { free(vlc[p]); free(rst[p]); } return -23; }
     int run_index = 0;
-    for (int y = 0; y < h; ++y) {
-        int16_t* s[3][3];
-        for (int p = 0; p < 3; ++p)
+    for (int y = 0; y < h && !err; ++y) {
+        int16_t* s[4][3];
+        for (int p = 0; p < 4; ++p)
             for (int i = 0; i < 3; ++i) s[p][i] = lines + ((size_t)p * 3 + (size_t)((y + 3 - i) % 3)) * LW + 3;
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < nplanes; ++p) {
             int16_t *cur = s[p][0], *last = s[p][1], *last2 = s[p][2];
-            const QuantSet* q = qs[(p + 1) / 2];
-            VlcState* vs = vlc[(p + 1) / 2];
+            const int set = (p + 1) / 2;               /* plane -> context set: 0, 1, 1, 2 */
+            const QuantSet* q = qs[set];
             if (y == 0) { memset(last - 3, 0, sizeof(int16_t) * LW); memset(last2 - 3, 0, sizeof(int16_t) * LW); }
             else if (y == 1) memset(last2 - 3, 0, sizeof(int16_t) * LW);
-            cur[-1] = last[0]; last[W] = last[W - 1];
+            cur[-1] = last[0]; last[w] = last[w - 1];
             cur[-2] = cur[-1];
             int run_count = 0, run_mode = 0;
-            for (int x = 0; x < W; ++x) {
+            for (int x = 0; x < w; ++x) {
                 int context = get_context(q, cur + x, last + x, last2 + x), sign = 0, diff;
                 if (context < 0) { context = -context; sign = 1; }
-                if (context == 0 && run_mode == 0) run_mode = 1;
-                if (run_mode) {
-                    if (run_count == 0 && run_mode == 1) {
-                        if (br_get1(&br)) {
-                            run_count = 1 << log2_run[run_index];
-                            if (x + run_count <= W) run_index++;
-                        } else {
-                            run_count = log2_run[run_index] ? (int)br_get(&br, log2_run[run_index]) : 0;
-                            if (run_index) run_index--;
-                            run_mode = 2;
-                        }
-                    }
-                    run_count--;
-                    if (run_count < 0) {
-                        run_mode = 0; run_count = 0;
-                        diff = get_vlc_symbol(&br, &vs[context], 9);
-                        if (diff >= 0) diff++;
-                    } else {
-                        diff = 0;
-                    }
+                if (context >= q->context_count) { err = 1; break; }      /* inconsistent (crafted) quantisation tables */
+                if (ac) {
+                    diff = get_symbol(&c, rst[set] + (size_t)context * CONTEXT_SIZE, 1, &err);
+                    if (err) break;
                 } else {
-                    diff = get_vlc_symbol(&br, &vs[context], 9);
+                    VlcState* vs = vlc[set];
+                    if (context == 0 && run_mode == 0) run_mode = 1;
+                    if (run_mode) {
+                        if (run_count == 0 && run_mode == 1) {
+                            if (br_get1(&br)) {
+                                run_count = 1 << log2_run[run_index];
+                                if (x + run_count <= w) run_index++;
+                            } else {
+                                run_count = log2_run[run_index] ? (int)br_get(&br, log2_run[run_index]) : 0;
+                                if (run_index) run_index--;
+                                run_mode = 2;
+                            }
+                        }
+                        run_count--;
+                        if (run_count < 0) {
+                            run_mode = 0; run_count = 0;
+                            diff = get_vlc_symbol(&br, &vs[context], 9);
+                            if (diff >= 0) diff++;
+                        } else {
+                            diff = 0;
+                        }
+                    } else {
+                        diff = get_vlc_symbol(&br, &vs[context], 9);
+                    }
                 }
                 if (sign) diff = -diff;
                 cur[x] = (int16_t)((mid_pred(cur[x - 1], cur[x - 1] + last[x] - last[x - 1], last[x]) + diff) & 0x1FF);
             }
+            if (err) break;
         }
-        uint8_t* row = rgb + (size_t)(y0 + y) * W * 3;
-        for (int x = 0; x < W; ++x) {
+        if (err) break;
+        uint8_t* row = rgb + ((size_t)(y0 + y) * W + x0) * 3;
+        for (int x = 0; x < w; ++x) {
             int g = s[0][0][x], b = s[1][0][x], r = s[2][0][x];
             b -= 256; r -= 256; g -= (b + r) >> 2; b += g; r += g;
             row[3 * x] = (uint8_t)r; row[3 * x + 1] = (uint8_t)g; row[3 * x + 2] = (uint8_t)b;
         }
     }
-    free(lines); free(vlc[0]); free(vlc[1]);
+    free(lines);
+    for (int p = 0; p < 3; ++p) { free(vlc[p]); free(rst[p]); }
+    if (err) return -25;
+    if (ac) return c.overflow > 2 ? -24 : 0;           /* the range decoder legitimately reads up to two bytes past the coded data */
     return br.overflow ? -24 : 0;
 }
 

@@ -77,9 +77,10 @@ def propagate(frames_u8, masks_u8, fw, bw):
     return out, filled
 
 
-def subvideo_ranges(T, subvideo_length, pad_len=5):
+def subvideo_ranges(T, subvideo_length, pad_len=10):
     """Sub-video schedule of ProPainter's image propagation (third-party, restated from the public inference script): sub-videos
-    of min(100, subvideo_length) frames propagated with pad_len frames of context on both sides, inner frames kept."""
+    of min(100, subvideo_length) frames propagated with pad_len frames of context on both sides, inner frames kept.
+    pad_len = 10 for the image propagation [UNVERIFIED-3P: recalled from the public script; 5 is what its flow-completion sub-videos use]."""
     L = min(100, int(subvideo_length))
     if L <= 0 or T <= L:
         return [(0, T, 0, T)]

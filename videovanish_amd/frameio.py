@@ -63,8 +63,9 @@ def ffv1_decode(config, packet, W, H):
     pkt = (C.c_uint8 * len(packet)).from_buffer_copy(packet)
     r = _io().vvio_ffv1_decode_frame(cfg, len(config), pkt, len(packet), W, H, out.ctypes.data_as(C.c_void_p))
     if r != 0:
-        reasons = {-10: "configuration record CRC mismatch", -2: "FFV1 version < 3", -3: "range-coded samples (coder_type != 0) are not supported",
-                   -6: "coded initial states are not supported", -8: "only 8-bit RGB without alpha / a single slice column is supported",
+        reasons = {-10: "configuration record CRC mismatch", -2: "FFV1 version < 3", -3: "bad coder_type / state-transition table",
+                   -6: "coded initial states are not supported", -8: "only 8-bit RGB streams (colorspace_type 1) are supported", -21: "slice header out of range",
+                   -25: "corrupt sample data",
                    -13: "slice CRC mismatch", -20: "not a key frame"}
         raise RuntimeError(f"FFV1 decode failed ({r}): {reasons.get(r, 'malformed stream')}")
     return out

@@ -303,9 +303,15 @@ class DiffuEraserHIP:
         if self.run.windowing == "reference":
             if dist is not None and dist[1] > 1:
                 raise RuntimeError('windowing="reference" couples every frame at every step and does not shard: run it on one GPU')
-            if scheduler != "ddim":
+            if scheduler not in (None, "ddim"):
                 raise RuntimeError('windowing="reference" is implemented for the DDIM scheduler')
-            return self.forward_reference_windows(frames, masks2d, priori, max_img_size=max_img_size, steps=steps, return_float=return_float)
+            # same contract as the chunked path: (array, (lo, hi)) with return_float, `timings` filled, `progress` called per step
+            res = self.forward_reference_windows(frames, masks2d, priori, max_img_size=max_img_size, steps=steps, return_float=return_float,
+                                                 progress=progress)
+            if timings is not None:
+                torch.cuda.synchronize()
+                timings.update(upload_s=0.0, compute_s=time.time() - t_0, exchange_blend_s=0.0, gather_download_s=0.0)
+            return (res, (0, len(frames))) if return_float else res
         run, dev = self.run, self.ctx.device
         T = len(frames)
         H0, W0 = frames[0].shape[:2]
@@ -360,7 +366,7 @@ class DiffuEraserHIP:
     # -- reference temporal windowing: windows of 22 frames shifted by half a window on odd steps, value/count
     #    averaging of the noise prediction, key-frame pre-inference for long clips.  Single GPU ("replicas only": the windows couple
     #    all frames at every step, so this mode does not shard); the default chunked mode is the multi-GPU path.
-    def _denoise_windows(self, lat, cond, mask_u8, ts, steps, H, W, nframes, overlap):
+    def _denoise_windows(self, lat, cond, mask_u8, ts, steps, H, W, nframes, overlap, progress=None):
         n, h, w, _ = lat.shape
         ctxs, swap = reference_contexts(n, nframes, overlap)
         for i, t in enumerate(ts):
@@ -377,6 +383,8 @@ class DiffuEraserHIP:
             prev = t - 1000 // steps
             a_p = float(self.ac[prev]) if prev >= 0 else float(self.ac[0])
             lat = hip.sched_step(lat, eps_all, None, a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5)
+            if progress is not None:
+                progress(i + 1, len(ts))
         return lat
 
     def _to_pix01(self, dec):
@@ -384,7 +392,8 @@ class DiffuEraserHIP:
         acc = torch.zeros((F, H, W, 3), dtype=torch.float32, device=dec.device)
         return hip.decode_blend(dec.contiguous(), torch.ones(F, dtype=torch.float32, device=dec.device), acc)
 
-    def forward_reference_windows(self, frames, masks2d, priori, max_img_size=960, steps=None, nframes=22, overlap=4, return_float=False):
+    def forward_reference_windows(self, frames, masks2d, priori, max_img_size=960, steps=None, nframes=22, overlap=4, return_float=False,
+                                  progress=None):
         """The third-party pipeline's own temporal scheme instead of independent chunks (DDIM; one GPU).  Same I/O as forward()."""
         run, dev = self.run, self.ctx.device
         steps = steps or run.steps
@@ -426,7 +435,7 @@ class DiffuEraserHIP:
         reps = (T + nframes - 1) // nframes
         noise = noise_pre.repeat(reps, 1, 1, 1)[:T].contiguous()
         lat = hip.axpby(prior_lat.contiguous(), noise, a0 ** 0.5, (1 - a0) ** 0.5)
-        lat = self._denoise_windows(lat, cond_lat.contiguous(), mk, ts, steps, H, W, nframes, overlap)
+        lat = self._denoise_windows(lat, cond_lat.contiguous(), mk, ts, steps, H, W, nframes, overlap, progress=progress)
         pix = self._to_pix01(self.decode(lat, T, h, w))
         if return_float:
             return pix.cpu().numpy()
