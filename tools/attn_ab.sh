@@ -1,40 +1,9 @@
-for v in ${VARIANTS:-0 30}; do echo "== VV_ATTN_VARIANT=$v"; VV_ATTN_VARIANT=$v python - <<'PY'
-import sys, os
-sys.path.insert(0, os.getcwd())
-import torch
-from videovanish_amd import hip
-dev = torch.device("cuda:0")
-def timeit(fn, n=5, warm=2):
-    for _ in range(warm): fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e-3
-for dname in ("bf16", "fp16"):
-    DT = hip.dtype_id(dname); td = hip.h16(DT)
-    B, heads, N, D = 8, 8, 14400, 40
-    C = heads * D
-    g = torch.Generator().manual_seed(0)
-    qkv = (torch.randn(B, 3, heads, N, D, generator=g) * float(os.environ.get("QSCALE", "1.0"))).to(td).to(dev)       # head-major layout as the pipeline uses it
-    out = torch.empty(B * N, C, dtype=td, device=dev)
-    fn = lambda: hip.attention(DT, qkv, qkv, qkv, out, B=B, heads=heads, Nq=N, Nkv=N, D=D, q_bs=N * 3 * C, k_bs=N * 3 * C, v_bs=N * 3 * C,
-                               o_bs=N * C, q_rs=D, k_rs=D, v_rs=D, o_rs=C, k_off=N * C, v_off=2 * N * C, q_hs=N * D, k_hs=N * D, v_hs=N * D)
-    t = timeit(fn)
-    # reference on a slice: frame 0, head 3, first 256 queries
-    q = qkv[0, 0, 3, :256].float(); k = qkv[0, 1, 3].float(); v = qkv[0, 2, 3].float()
-    ref = torch.softmax(q @ k.t() * D ** -0.5, -1) @ v
-    got = out.view(B, N, heads, D)[0, :256, 3].float()
-    print(f"{dname} spatial d40 N14400 x8f: {t*1e3:8.3f} ms {4.0*B*heads*N*N*D/t/1e12:7.1f} TF/s  maxerr vs torch {float((got-ref).abs().max()):.2e}")
-    # ragged check: N = 14400 - 37 keys
-    N2 = 1000 - 37
-    qkv2 = torch.randn(1, 3, heads, N2, D, generator=g).to(td).to(dev)
-    out2 = torch.empty(N2, C, dtype=td, device=dev)
-    hip.attention(DT, qkv2, qkv2, qkv2, out2, B=1, heads=heads, Nq=N2, Nkv=N2, D=D, q_bs=N2 * 3 * C, k_bs=N2 * 3 * C, v_bs=N2 * 3 * C,
-                  o_bs=N2 * C, q_rs=D, k_rs=D, v_rs=D, o_rs=C, k_off=N2 * C, v_off=2 * N2 * C, q_hs=N2 * D, k_hs=N2 * D, v_hs=N2 * D)
-    q = qkv2[0, 0, 5].float(); k = qkv2[0, 1, 5].float(); v = qkv2[0, 2, 5].float()
-    ref = torch.softmax(q @ k.t() * D ** -0.5, -1) @ v
-    print(f"   ragged N={N2}: maxerr {float((out2.view(N2, heads, D)[:, 5].float()-ref).abs().max()):.2e}")
-PY
+#!/bin/bash
+# A/B of the d = 40 spatial attention variants (lab build: VV_AB=1 videovanish_amd/csrc/build.sh), interleaved rounds on ONE device.
+# usage: tools/attn_ab.sh "50 51 52" [frames] [rounds]
+VARS=${1:-"50 51"}; B=${2:-8}; R=${3:-3}
+for r in $(seq 1 $R); do
+  for v in $VARS; do
+    echo -n "round $r variant $v: "; VV_ATTN_VARIANT=$v python tools/bench_attn_d40.py $B fp16 2>&1 | tail -1
+  done
 done

@@ -713,6 +713,303 @@ int attn_pipe_launch(const vv_attn_params& p, hipStream_t st) {
     return VV_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// d = 40 spatial self-attention on the FULL-SIZE matrix instruction (v_mfma_f32_32x32x16): the dominant kernel of the denoise step.
+//
+// Why another kernel: on the 16x16x32 form an MFMA occupies the SIMD's vector-issue port for 8 of its 16 cycles, and the 28 MFMAs of a
+// 32-query x 64-key tile then take as much issue time as the 32 v_exp_f32 the tile also needs -- the kernel above is issue bound at ~48 % matrix
+// pipe.  A 32x32x16 MFMA does twice the work per issue (8 of 32 cycles), and its K step of 16 pads d = 40 + the two lazy-maximum slots to 48
+// instead of 64: QK^T is 6 MFMAs per tile instead of 16, PV 8 (M = d padded to 64) instead of 12, with 6 + 16 LDS fragment reads instead of 8 + 12.
+//
+// Per wave: 32 queries (lane & 31 = the query, like the kernel above a lane owns its query's softmax row; lane >> 5 = h splits the keys).
+//   S^T[32 keys][32 q] = K Q^T:  A = K rows (ds_read_b128, 16 B = k slots 16s + 8h .. +7), B = Q in registers (3 k steps: 40 data + slots 40,41 =
+//   -m hi/lo against 1.0 in K + 6 zeros).  Accumulator register i of a lane holds key (i & 3) + 8 (i >> 2) + 4 h.
+//   P = exp2(S^T) packed pairwise IS the B operand of O^T += V^T P^T (k order of step s': key 16 s' + 8 (j >> 2) + 4 h + (j & 3), j = 0..7):
+//   no cross-lane movement; the A operand V^T comes through ds_read_b64_tr_b16 with exactly that key order (two reads of 4 consecutive keys).
+//   O^T rows 0..39 = the output, row 40 = sum_k P (ONES column of V), rows 41..63 padding.
+// LDS images (both 96-byte rows, filled by LDS-DMA, every wave instruction a whole KB):
+//   K: row = key, 16-byte chunk c stored at position c ^ ((row >> 3) & 1)  -> ds_read_b128 of 16 rows x one chunk is conflict free;
+//   V: key 8 g + 4 b + q stored at row 8 g + 2 q + b                      -> the 4 rows of a transposed read are 2 apart: conflict free.
+// Lazy reference maximum, slow path, ragged last tile: as in attn_kernel<LAZY>.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <typename T> struct Mfma32;
+template <> struct Mfma32<BF16> {
+    static __device__ __forceinline__ f32x16 run(uint4 a, uint4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mfma32<F16> {
+    static __device__ __forceinline__ f32x16 run(uint4 a, uint4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+// OPTIMISTIC reference (this kernel) instead of the lazy running one: the softmax reference m of a query is fixed ONCE, before the key loop, from
+// the exact maximum of its scores against a 64-key sample spread over the whole sequence (+ MARGIN), and rides in the pad slots as before.  The
+// loop body then has no maximum, no rescale, no overflow test and NO BRANCH: scores -> exp2 -> pack -> PV, software pipelined one tile deep
+// (the QK^T MFMAs of tile t+1 are independent of the exponentials of tile t, so the matrix pipe and the VALU work side by side inside the wave's own
+// instruction stream -- the only place where they overlap well on this chip, profiles/r2_attn_lazy_ab.txt).  P = 2^(s - m) may exceed 1: h16 keeps its
+// relative precision up to 2^16 (fp16) and the sums are fp32, so a later score may beat the sample maximum by up to 16 + MARGIN binary orders before
+// anything is lost.  Beyond that P overflows to inf, the denominator (row 40 of O^T) comes out non-finite, and the BLOCK repeats its keys once with the
+// exact maximum (a QK^T-only sweep first): correct for any input, slow only for the blocks that hit it.  bf16 cannot overflow at all.
+template <typename T, int NW, int OCC, bool RAGGED, int HACK = 0>
+__global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_params p, const int nqt) {
+    constexpr int D = 40, KVT = 64, PR = 96, NCH = 6;         // 96-byte rows = 6 chunks of 8 h16: 5 data + 1 constant
+    constexpr int NT = NW * 64, BQ = NW * 32;
+    constexpr int NS = KVT * NCH;                             // 16-byte slots per tile (384 = 6 KB)
+    constexpr int NP = (NS + NT - 1) / NT;                    // DMA passes
+    constexpr float MARGIN = 4.0f;
+    static_assert(NS % 64 == 0, "tile must be whole 1 KB wave blocks");
+    __shared__ __attribute__((aligned(1024))) unsigned char dK0[KVT * PR];
+    __shared__ __attribute__((aligned(1024))) unsigned char dK1[KVT * PR];
+    __shared__ __attribute__((aligned(1024))) unsigned char dV0[KVT * PR + 64];      // (+64: the duplicate-address lanes of the second d block stay inside)
+    __shared__ __attribute__((aligned(1024))) unsigned char dV1[KVT * PR + 64];
+
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int qt, hd, b;
+    {
+        const int nbh = p.B * p.heads;
+        const int full = (nbh / 8) * 8;
+        const int bid = blockIdx.x;
+        int bh;
+        if (bid < full * nqt) { const int xcd = bid & 7, idx = bid >> 3; bh = (idx / nqt) * 8 + xcd; qt = idx % nqt; }
+        else { const int rr = bid - full * nqt; bh = full + rr / nqt; qt = rr % nqt; }
+        hd = bh % p.heads; b = bh / p.heads;
+    }
+    const unsigned short* Q = (const unsigned short*)p.q + (int64_t)b * p.q_bs + (int64_t)hd * (p.q_hs ? p.q_hs : D);
+    const unsigned short* Kp = (const unsigned short*)p.k + (int64_t)b * p.k_bs + (int64_t)hd * (p.k_hs ? p.k_hs : D);
+    const unsigned short* Vp = (const unsigned short*)p.v + (int64_t)b * p.v_bs + (int64_t)hd * (p.v_hs ? p.v_hs : D);
+    unsigned short* O = (unsigned short*)p.o + (int64_t)b * p.o_bs + (int64_t)hd * D;
+
+    // ---- Q fragments: lane (r, h) holds Q[q0 + r][16 s + 8 h .. +7]; chunk 5 (s = 2, h = 1) is the pad chunk: slots 40, 41 = -m (hi, lo)
+    const int q0 = qt * BQ + wave * 32;
+    uint4 qf[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int q = q0 + r, d0 = 16 * s + 8 * h;
+        qf[s] = (q < p.Nq && d0 < D) ? *(const uint4*)(Q + (int64_t)q * p.q_rs + d0) : make_uint4(0, 0, 0, 0);
+        if (!p.q_prescaled) {
+            float qv[8];
+            unpack8<T>(qf[s], qv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qv[e] *= p.scale * 1.4426950408889634f;
+            qf[s] = pack8<T>(qv);
+        }
+    }
+
+    // ---- per-thread DMA slots (pass i, thread t) <-> LDS slot sidx = i * NT + t = row * 6 + position
+    unsigned koff[NP], voff[NP];
+    bool kdata[NP], vdata[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int sidx = i * NT + t, row = sidx / NCH, pos = sidx - row * NCH;
+        const int kc = pos ^ ((row >> 3) & 1);                                 // K: logical chunk stored at this position
+        kdata[i] = kc < 5 && sidx < NS;
+        koff[i] = (unsigned)(row * (int)p.k_rs + kc * 8) * 2u;
+        const int key = (row & ~7) + 4 * (row & 1) + ((row & 7) >> 1);         // V: key stored at this row
+        vdata[i] = pos < 5 && sidx < NS;
+        voff[i] = (unsigned)(key * (int)p.v_rs + pos * 8) * 2u;
+        if (sidx < NS) {
+            const unsigned one = (unsigned)T::from_f32(1.0f);
+            const uint4 kfill = make_uint4(kc == 5 ? one * 0x10001u : 0u, 0, 0, 0);      // K[key][40] = K[key][41] = 1
+            const uint4 vfill = make_uint4(pos == 5 ? one : 0u, 0, 0, 0);                // V[key][40] = 1: O^T row 40 accumulates sum_k P
+            *(uint4*)(dK0 + sidx * 16) = kfill; *(uint4*)(dK1 + sidx * 16) = kfill;
+            *(uint4*)(dV0 + sidx * 16) = vfill; *(uint4*)(dV1 + sidx * 16) = vfill;
+        }
+    }
+    if (t < 4) { *(uint4*)(dV0 + KVT * PR + t * 16) = make_uint4(0, 0, 0, 0); *(uint4*)(dV1 + KVT * PR + t * 16) = make_uint4(0, 0, 0, 0); }
+    __syncthreads();
+    const int ntiles = (p.Nkv + KVT - 1) / KVT;
+    const int nlast = p.Nkv - (ntiles - 1) * KVT;             // keys in the last tile (KVT unless RAGGED)
+    const unsigned kstep = (unsigned)(KVT * (int)p.k_rs * 2), vstep = (unsigned)(KVT * (int)p.v_rs * 2);
+    // K tile `it` -> bK (stride = 1), or the 64-key SAMPLE (keys 0, stride, 2 stride, ...: it = 0, stride = Nkv / 64)
+    auto dma_k = [&](const int it, unsigned char* bK, const unsigned stride) {
+        const unsigned char* kt = (const unsigned char*)Kp + (size_t)it * kstep;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (NS % NT == 0 || i * NT + wave * 64 < NS) {
+                const int row = (i * NT + t) / NCH;
+                bool on = kdata[i];
+                if (RAGGED) on = on && (it + 1 < ntiles || stride != 1 || row < nlast);      // ragged last tile: rows past Nkv keep stale, finite data
+                const unsigned off = stride == 1 ? koff[i] : (unsigned)(row * (int)p.k_rs * 2) * (stride - 1) + koff[i];
+                if (on) glds16(kt + off, bK + (i * NT + wave * 64) * 16);
+            }
+        }
+    };
+    auto dma_v = [&](const int it, unsigned char* bV) {
+        const unsigned char* vt = (const unsigned char*)Vp + (size_t)it * vstep;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (NS % NT == 0 || i * NT + wave * 64 < NS) {
+                bool on = vdata[i];
+                if (RAGGED) { const int row = (i * NT + t) / NCH, key = (row & ~7) + 4 * (row & 1) + ((row & 7) >> 1); on = on && (it + 1 < ntiles || key < nlast); }
+                if (on) glds16(vt + voff[i], bV + (i * NT + wave * 64) * 16);
+            }
+        }
+    };
+
+    // ---- lane-constant LDS read offsets
+    const int kswz = (r >> 3) & 1;                               // K: chunk c of row r sits at position c ^ kswz
+    // transposed V read: 16-lane group g = lane >> 4 (g & 1 = which 16 columns, g >> 1 = h), lane 4 q + pp in the group addresses row q, columns 4 pp ..
+    const int vq = (lane >> 2) & 3, vpp = lane & 3, vcb = (lane >> 4) & 1;
+    const int vro = (2 * vq + h) * PR + (16 * vcb + 4 * vpp) * 2;           // + 8-key group * 8 rows * PR
+    const int vro1 = (2 * vq + h) * PR + (4 * vpp) * 2 + 64;                // second d block (columns 32..47 exist): the lanes of columns 48.. re-read 32..
+
+    // S^T = K Q^T for the 64 keys of one LDS tile (2 key blocks x 3 k steps)
+    auto qk = [&](const unsigned char* sK, f32x16 (&sacc)[2]) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const uint4 kf = *(const uint4*)(sK + (kb * 32 + r) * PR + (((2 * s + h) ^ kswz) * 16));
+                if (HACK == 4) sacc[kb][0] += __builtin_bit_cast(float, kf.x ^ qf[s].x) * 1e-30f; else sacc[kb] = Mfma32<T>::run(kf, qf[s], sacc[kb]);
+            }
+        }
+    };
+    auto mask_last = [&](f32x16 (&sacc)[2]) {                     // keys past Nkv of the ragged last tile: -inf scores (P = 0)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= nlast) sacc[kb][i] = -1e30f;
+    };
+    auto row_max = [&](const f32x16 (&sacc)[2]) {
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kb][i]);
+        return fmaxf(mx, __shfl_xor(mx, 32));
+    };
+    auto set_reference = [&](const float target) {                // pad slots 40, 41 of Q <- -target as the nearest h16 hi + lo pair
+        const unsigned short hi = T::from_f32(-target);
+        const unsigned short lo = T::from_f32(-target - T::to_f32(hi));
+        qf[2].x = h == 1 ? ((unsigned)hi | ((unsigned)lo << 16)) : qf[2].x;
+    };
+
+    f32x16 oacc[2];
+    float l = 0.f;
+#pragma nounroll
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // ---- reference: attempt 0 = maximum over the 64-key sample + MARGIN; attempt 1 (after an overflow) = the exact maximum over all keys
+        f32x16 sA[2], sB[2];
+        if (attempt == 0) {
+            dma_k(0, dK1, (unsigned)(p.Nkv / KVT));
+            dma_k(0, dK0, 1u);
+            dma_v(0, dV0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            qk(dK1, sA);
+            set_reference(row_max(sA) + MARGIN);
+        } else {
+            qf[2].x = h == 1 ? 0u : qf[2].x;                      // plain scores again
+            float mx = -1e30f;
+            __syncthreads();
+            dma_k(0, dK0, 1u);
+            for (int it = 0; it < ntiles; ++it) {
+                unsigned char* cK = (it & 1) ? dK1 : dK0;
+                unsigned char* nK = (it & 1) ? dK0 : dK1;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (it + 1 < ntiles) dma_k(it + 1, nK, 1u);
+                qk(cK, sA);
+                if (RAGGED && it + 1 == ntiles) mask_last(sA);
+                mx = fmaxf(mx, row_max(sA));
+            }
+            set_reference(mx);
+            __syncthreads();
+            dma_k(0, dK0, 1u);
+            dma_v(0, dV0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                          // everybody is done with the sample (the last sweep tile) in dK1
+        if (ntiles > 1) dma_k(1, dK1, 1u);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[m][i] = 0.f;
+        qk(dK0, sA);
+        if (RAGGED && ntiles == 1) mask_last(sA);
+
+        // one pipeline step: S_next = K(it+1) Q^T  |  P = exp2(S_cur), packed  |  O^T += V(it)^T P^T     -- ONE basic block, no branch
+        auto body = [&](const unsigned char* nK, const unsigned char* cV, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
+            qk(nK, sn);
+            uint4 pb[2][2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sc[kb][i] = HACK == 2 ? sc[kb][i] * 0.01f : __builtin_amdgcn_exp2f(sc[kb][i]);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    pb[kb][s2] = make_uint4(pack2<T>(sc[kb][8 * s2 + 0], sc[kb][8 * s2 + 1]), pack2<T>(sc[kb][8 * s2 + 2], sc[kb][8 * s2 + 3]),
+                                            pack2<T>(sc[kb][8 * s2 + 4], sc[kb][8 * s2 + 5]), pack2<T>(sc[kb][8 * s2 + 6], sc[kb][8 * s2 + 7]));
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    // keys 32 kb + 16 s2 + 4 h + {0..3} (elements 0..3) and + 8 (elements 4..7) = 8-key groups 4 kb + 2 s2 and + 1
+                    const unsigned char* g0 = cV + (4 * kb + 2 * s2) * 8 * PR;
+                    {
+                        const uint2 lo = ds_read_tr16(g0 + vro), hi = ds_read_tr16(g0 + 8 * PR + vro);
+                        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                        if (HACK == 3) oacc[0][0] += __builtin_bit_cast(float, vf.x ^ pb[kb][s2].x); else oacc[0] = Mfma32<T>::run(vf, pb[kb][s2], oacc[0]);
+                    }
+                    {
+                        const uint2 lo = ds_read_tr16(g0 + vro1), hi = ds_read_tr16(g0 + 8 * PR + vro1);
+                        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                        if (HACK == 3) oacc[1][0] += __builtin_bit_cast(float, vf.x ^ pb[kb][s2].x); else oacc[1] = Mfma32<T>::run(vf, pb[kb][s2], oacc[1]);
+                    }
+                }
+        };
+        // step `it`: K(it+1) and V(it) have landed (issued one step ago); issue K(it+2) over K(it) and V(it+1) over V(it-1)
+        auto step = [&](const int it, unsigned char* kA, unsigned char* kB, unsigned char* vA, unsigned char* vB, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (HACK != 1) __syncthreads();
+            if (HACK != 5) {
+                if (it + 2 < ntiles) dma_k(it + 2, kA, 1u);
+                if (it + 1 < ntiles) dma_v(it + 1, vB);
+            }
+            body(kB, vA, sc, sn);                                 // (the last step computes scores of a tile that does not exist: stale K, never used)
+            if (RAGGED && it + 2 == ntiles) mask_last(sn);
+        };
+        for (int it = 0; it < ntiles; it += 2) {
+            step(it, dK0, dK1, dV0, dV1, sA, sB);
+            if (it + 1 < ntiles) step(it + 1, dK1, dK0, dV1, dV0, sB, sA);
+        }
+        // ---- denominator = O^T row 40 = d block 1, register 4, lanes with h = 0.  Non-finite (some P overflowed) or zero: repeat with the exact maximum
+        l = __shfl(oacc[1][4], r);
+        const bool bad = !(l > 0.f && l < 3.0e38f);
+        if (attempt == 1 || !__syncthreads_or(bad ? 1 : 0)) break;
+    }
+    // ---- finalize: O[q][d] = O^T[d][q] / l.  Register i of d block m on lane (r, h): d = 32 m + (i & 3) + 8 (i >> 2) + 4 h
+    const float inv = 1.0f / l;
+    const int q = q0 + r;
+    if (q < p.Nq) {
+        unsigned short* orow = O + (int64_t)q * p.o_rs;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(uint2*)(orow + 8 * g + 4 * h) = make_uint2(pack2<T>(oacc[0][4 * g] * inv, oacc[0][4 * g + 1] * inv), pack2<T>(oacc[0][4 * g + 2] * inv, oacc[0][4 * g + 3] * inv));
+        *(uint2*)(orow + 32 + 4 * h) = make_uint2(pack2<T>(oacc[1][0] * inv, oacc[1][1] * inv), pack2<T>(oacc[1][2] * inv, oacc[1][3] * inv));
+    }
+}
+
+template <typename T, int NW, int OCC, int HACK = 0>
+int attn40_launch(const vv_attn_params& p, hipStream_t st) {
+    constexpr int BQ = NW * 32;
+    const int nqt = (p.Nq + BQ - 1) / BQ;
+    const int64_t nblk = (int64_t)p.B * p.heads * nqt;
+    if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_attention: grid too large");
+    if (p.Nkv % 64) hipLaunchKernelGGL((attn40_kernel<T, NW, OCC, true, HACK>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p, nqt);
+    else hipLaunchKernelGGL((attn40_kernel<T, NW, OCC, false, HACK>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p, nqt);
+    VV_CHECK_LAUNCH("vv_attention(d40, 32x32x16)");
+    return VV_OK;
+}
+
 template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0, bool LAZY = false, int HACK = 0>
 int attn_launch(const vv_attn_params& p, hipStream_t st) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
@@ -783,6 +1080,19 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
                 if (var == 34) return attn_launch<T, D, 2, 32, 4, false, 4, true, 0, true>(p, st);      // lazy, 32-key tiles, 128-VGPR cap (4 waves/SIMD)
                 if (var == 33) return attn_launch<T, D, 2, 64, 2, false, 6, true, 0, true>(p, st);      // lazy, 2-wave blocks (6 blocks per CU)
 #endif
+#ifdef VV_AB
+                if (var == 50) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true>(p, st);      // round-2 default: lazy, 16x16x32 MFMAs
+                if (var == 51) return attn40_launch<T, 4, 3>(p, st);                                    // 32x32x16, capped at 168 VGPRs (3 waves/SIMD)
+                if (var == 52) return attn40_launch<T, 4, 2>(p, st);                                    // ... 2 waves/SIMD
+                if (var == 53) return attn40_launch<T, 8, 2>(p, st);                                    // ... 8-wave blocks
+                if (var == 54) return attn40_launch<T, 2, 4>(p, st);                                    // ... 2-wave blocks
+                if (var == 61) return attn40_launch<T, 4, 2, 1>(p, st);      // timing probes (WRONG results): no barrier
+                if (var == 62) return attn40_launch<T, 4, 2, 2>(p, st);      // ... no exp
+                if (var == 63) return attn40_launch<T, 4, 2, 3>(p, st);      // ... no PV MFMAs
+                if (var == 64) return attn40_launch<T, 4, 2, 4>(p, st);      // ... no QK MFMAs
+                if (var == 65) return attn40_launch<T, 4, 2, 5>(p, st);      // ... no DMA
+#endif
+                if (!cross && p.Nkv >= 64) return attn40_launch<T, 4, 2>(p, st);      // 32x32x16 MFMAs, optimistic reference, 2 waves/SIMD
                 if (!cross) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true>(p, st);
             }
             if (D <= 64) return cross ? attn_launch<T, D, 2, 64, 4, false, 3, true, 1>(p, st) : attn_launch<T, D, 2, 64, 4, false, 3, true, 0>(p, st);
