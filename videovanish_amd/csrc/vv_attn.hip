@@ -755,16 +755,24 @@ template <> struct Mfma32<F16> {
 // exact maximum (a QK^T-only sweep first): correct for any input, slow only for the blocks that hit it.  bf16 cannot overflow at all.
 template <typename T, int NW, int OCC, bool RAGGED, int HACK = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_params p, const int nqt) {
-    constexpr int D = 40, KVT = 64, PR = 96, NCH = 6;         // 96-byte rows = 6 chunks of 8 h16: 5 data + 1 constant
+    // LDS: dense 80-byte rows (5 chunks of 8 h16) -- a K or V tile is exactly 5 KB = 5 LDS-DMA wave instructions with EVERY lane active (no
+    // exec masking, no pad slots), 10 per 64-key tile.  The constant operand slots come from a region of 1.0 instead of from the rows:
+    //   K slots 40..47 (Q carries -m hi, -m lo, 0 x 6 there)  and  V columns 40..43 (O^T rows 40.. = sum_k P, the softmax denominator).
+    // Row orders: K natural (80-byte pitch: 16 consecutive rows x one chunk hit 16 different 16-byte bank slots);
+    //             V key 16 g + 4 j + q at row 16 g + 4 q + j (the 4 rows of one transposed read are 4 apart: conflict free at 80 bytes).
+    constexpr int D = 40, KVT = 64, PR = 80, NCH = 5;
     constexpr int NT = NW * 64, BQ = NW * 32;
-    constexpr int NS = KVT * NCH;                             // 16-byte slots per tile (384 = 6 KB)
-    constexpr int NP = (NS + NT - 1) / NT;                    // DMA passes
+    constexpr int TILE = KVT * PR;                            // 5120
+    constexpr int NPC = 2 * TILE / 1024;                      // 10 DMA pieces (1 KB each) per tile: 0..4 = K, 5..9 = V
+    constexpr int PPW = (NPC + NW - 1) / NW;                  // pieces per wave (piece j -> wave j % NW)
+    constexpr int KONES = 32 * PR + 64, VONES = 4096 + 64;   // bytes of 1.0 behind each tile buffer (reached with the key-block / k-step immediates)
     constexpr float MARGIN = 4.0f;
-    static_assert(NS % 64 == 0, "tile must be whole 1 KB wave blocks");
-    __shared__ __attribute__((aligned(1024))) unsigned char dK0[KVT * PR];
-    __shared__ __attribute__((aligned(1024))) unsigned char dK1[KVT * PR];
-    __shared__ __attribute__((aligned(1024))) unsigned char dV0[KVT * PR + 64];      // (+64: the duplicate-address lanes of the second d block stay inside)
-    __shared__ __attribute__((aligned(1024))) unsigned char dV1[KVT * PR + 64];
+    // FOUR arrays, not one: hipcc drains vmcnt(0) in front of a ds_read that may alias an LDS-DMA in flight, and tells buffers apart only as
+    // distinct __shared__ objects (the DMA of step `it` targets the buffers the step does not read)
+    __shared__ __attribute__((aligned(1024))) unsigned char dK0[TILE + KONES];
+    __shared__ __attribute__((aligned(1024))) unsigned char dK1[TILE + KONES];
+    __shared__ __attribute__((aligned(1024))) unsigned char dV0[TILE + VONES];
+    __shared__ __attribute__((aligned(1024))) unsigned char dV1[TILE + VONES];
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -779,8 +787,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
         hd = bh % p.heads; b = bh / p.heads;
     }
     const unsigned short* Q = (const unsigned short*)p.q + (int64_t)b * p.q_bs + (int64_t)hd * (p.q_hs ? p.q_hs : D);
-    const unsigned short* Kp = (const unsigned short*)p.k + (int64_t)b * p.k_bs + (int64_t)hd * (p.k_hs ? p.k_hs : D);
-    const unsigned short* Vp = (const unsigned short*)p.v + (int64_t)b * p.v_bs + (int64_t)hd * (p.v_hs ? p.v_hs : D);
+    const unsigned char* Kp = (const unsigned char*)((const unsigned short*)p.k + (int64_t)b * p.k_bs + (int64_t)hd * (p.k_hs ? p.k_hs : D));
+    const unsigned char* Vp = (const unsigned char*)((const unsigned short*)p.v + (int64_t)b * p.v_bs + (int64_t)hd * (p.v_hs ? p.v_hs : D));
     unsigned short* O = (unsigned short*)p.o + (int64_t)b * p.o_bs + (int64_t)hd * D;
 
     // ---- Q fragments: lane (r, h) holds Q[q0 + r][16 s + 8 h .. +7]; chunk 5 (s = 2, h = 1) is the pad chunk: slots 40, 41 = -m (hi, lo)
@@ -798,66 +806,55 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
             qf[s] = pack8<T>(qv);
         }
     }
-
-    // ---- per-thread DMA slots (pass i, thread t) <-> LDS slot sidx = i * NT + t = row * 6 + position
-    unsigned koff[NP], voff[NP];
-    bool kdata[NP], vdata[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int sidx = i * NT + t, row = sidx / NCH, pos = sidx - row * NCH;
-        const int kc = pos ^ ((row >> 3) & 1);                                 // K: logical chunk stored at this position
-        kdata[i] = kc < 5 && sidx < NS;
-        koff[i] = (unsigned)(row * (int)p.k_rs + kc * 8) * 2u;
-        const int key = (row & ~7) + 4 * (row & 1) + ((row & 7) >> 1);         // V: key stored at this row
-        vdata[i] = pos < 5 && sidx < NS;
-        voff[i] = (unsigned)(key * (int)p.v_rs + pos * 8) * 2u;
-        if (sidx < NS) {
-            const unsigned one = (unsigned)T::from_f32(1.0f);
-            const uint4 kfill = make_uint4(kc == 5 ? one * 0x10001u : 0u, 0, 0, 0);      // K[key][40] = K[key][41] = 1
-            const uint4 vfill = make_uint4(pos == 5 ? one : 0u, 0, 0, 0);                // V[key][40] = 1: O^T row 40 accumulates sum_k P
-            *(uint4*)(dK0 + sidx * 16) = kfill; *(uint4*)(dK1 + sidx * 16) = kfill;
-            *(uint4*)(dV0 + sidx * 16) = vfill; *(uint4*)(dV1 + sidx * 16) = vfill;
-        }
+    // ---- constant regions (written once): 1.0 everywhere; the tile buffers start as zeros (rows of a ragged tile that are never loaded stay finite)
+    {
+        const unsigned one2 = (unsigned)T::from_f32(1.0f) * 0x10001u;
+        const uint4 ones = make_uint4(one2, one2, one2, one2), zero = make_uint4(0, 0, 0, 0);
+        for (int i = t; i < (TILE + KONES) / 16; i += NT) { *(uint4*)(dK0 + i * 16) = i < TILE / 16 ? zero : ones; *(uint4*)(dK1 + i * 16) = i < TILE / 16 ? zero : ones; }
+        for (int i = t; i < (TILE + VONES) / 16; i += NT) { *(uint4*)(dV0 + i * 16) = i < TILE / 16 ? zero : ones; *(uint4*)(dV1 + i * 16) = i < TILE / 16 ? zero : ones; }
     }
-    if (t < 4) { *(uint4*)(dV0 + KVT * PR + t * 16) = make_uint4(0, 0, 0, 0); *(uint4*)(dV1 + KVT * PR + t * 16) = make_uint4(0, 0, 0, 0); }
     __syncthreads();
+
+    // ---- this wave's DMA pieces: piece j = wave + NW * i; slot = (j % 5) * 64 + lane = row * 5 + chunk of the K (j < 5) or V tile
+    unsigned doff[PPW];          // byte offset of the slot's source inside a tile (K: key = row; V: key = 16 g + 4 (row & 3) + ((row >> 2) & 3))
+    int dkey[PPW];               // key index inside the tile (ragged last tile)
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int j = wave + NW * i, slot = (j % 5) * 64 + lane, row = slot / NCH, ch = slot - row * NCH;
+        const bool isv = j >= 5;
+        const int key = isv ? (row & ~15) + 4 * (row & 3) + ((row >> 2) & 3) : row;
+        dkey[i] = key;
+        doff[i] = (unsigned)(key * (int)(isv ? p.v_rs : p.k_rs) + ch * 8) * 2u;
+    }
     const int ntiles = (p.Nkv + KVT - 1) / KVT;
     const int nlast = p.Nkv - (ntiles - 1) * KVT;             // keys in the last tile (KVT unless RAGGED)
     const unsigned kstep = (unsigned)(KVT * (int)p.k_rs * 2), vstep = (unsigned)(KVT * (int)p.v_rs * 2);
-    // K tile `it` -> bK (stride = 1), or the 64-key SAMPLE (keys 0, stride, 2 stride, ...: it = 0, stride = Nkv / 64)
-    auto dma_k = [&](const int it, unsigned char* bK, const unsigned stride) {
-        const unsigned char* kt = (const unsigned char*)Kp + (size_t)it * kstep;
+    // K part (kind 0), V part (kind 1) of tile `it` -> LDS buffer at byte offset `dst`; stride > 1: the 64-key SAMPLE (keys 0, stride, 2 stride, ..)
+    auto dma = [&](const int kind, const int it, unsigned char* dst, const unsigned stride) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            if (NS % NT == 0 || i * NT + wave * 64 < NS) {
-                const int row = (i * NT + t) / NCH;
-                bool on = kdata[i];
-                if (RAGGED) on = on && (it + 1 < ntiles || stride != 1 || row < nlast);      // ragged last tile: rows past Nkv keep stale, finite data
-                const unsigned off = stride == 1 ? koff[i] : (unsigned)(row * (int)p.k_rs * 2) * (stride - 1) + koff[i];
-                if (on) glds16(kt + off, bK + (i * NT + wave * 64) * 16);
-            }
-        }
-    };
-    auto dma_v = [&](const int it, unsigned char* bV) {
-        const unsigned char* vt = (const unsigned char*)Vp + (size_t)it * vstep;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            if (NS % NT == 0 || i * NT + wave * 64 < NS) {
-                bool on = vdata[i];
-                if (RAGGED) { const int row = (i * NT + t) / NCH, key = (row & ~7) + 4 * (row & 1) + ((row & 7) >> 1); on = on && (it + 1 < ntiles || key < nlast); }
-                if (on) glds16(vt + voff[i], bV + (i * NT + wave * 64) * 16);
+        for (int i = 0; i < PPW; ++i) {
+            const int j = wave + NW * i;                          // wave-uniform
+            if (j < NPC && (j >= 5) == (kind == 1)) {
+                const unsigned char* src = kind ? Vp + (size_t)it * vstep : Kp + (size_t)it * kstep;
+                unsigned off = doff[i];
+                if (stride != 1) off += (unsigned)(dkey[i] * (int)p.k_rs * 2) * (stride - 1);
+                if (RAGGED && it + 1 == ntiles && stride == 1) { if (dkey[i] < nlast) glds16(src + off, dst + (j % 5) * 1024); }
+                else glds16(src + off, dst + (j % 5) * 1024);
             }
         }
     };
 
-    // ---- lane-constant LDS read offsets
-    const int kswz = (r >> 3) & 1;                               // K: chunk c of row r sits at position c ^ kswz
-    // transposed V read: 16-lane group g = lane >> 4 (g & 1 = which 16 columns, g >> 1 = h), lane 4 q + pp in the group addresses row q, columns 4 pp ..
+    // ---- lane-constant LDS read addresses (byte offsets into a tile buffer; the key block / k step are instruction immediates)
+    const int ka0 = r * PR + 16 * h;                             // K chunks h (s = 0) and 2 + h (s = 1: + 32)
+    const int ka2 = h ? TILE : r * PR + 64;                     // s = 2: chunk 4 for h = 0, the constant chunk (1.0: slots 40..47) for h = 1
+    // transposed V read: 16-lane group g = lane >> 4 (g & 1 = cb: which 16 columns, g >> 1 = h); lane 4 q + pp of the group addresses row q, columns 4 pp ..
     const int vq = (lane >> 2) & 3, vpp = lane & 3, vcb = (lane >> 4) & 1;
-    const int vro = (2 * vq + h) * PR + (16 * vcb + 4 * vpp) * 2;           // + 8-key group * 8 rows * PR
-    const int vro1 = (2 * vq + h) * PR + (4 * vpp) * 2 + 64;                // second d block (columns 32..47 exist): the lanes of columns 48.. re-read 32..
+    const int va0 = (4 * vq + h) * PR + (16 * vcb + 4 * vpp) * 2;             // d block 0; + (16 (2 kb + s2) + 2 j4) rows
+    // d block 1: columns 32..39 are data (pp = 0, 1 of cb = 0), 40..43 the constant (pp = 2: 1.0 -> O^T rows 40..43 = sum_k P); every other lane
+    // only feeds O^T rows that are never read: it repeats a data address
+    const int va1 = (vcb == 0 && vpp == 2) ? TILE : (4 * vq + h) * PR + 64 + 8 * (vpp & 1);
 
-    // S^T = K Q^T for the 64 keys of one LDS tile (2 key blocks x 3 k steps)
+    // S^T = K Q^T for the 64 keys of the K tile at byte offset kb0 (2 key blocks x 3 k steps)
     auto qk = [&](const unsigned char* sK, f32x16 (&sacc)[2]) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -865,7 +862,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
             for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
-                const uint4 kf = *(const uint4*)(sK + (kb * 32 + r) * PR + (((2 * s + h) ^ kswz) * 16));
+                const uint4 kf = s < 2 ? *(const uint4*)(sK + kb * 32 * PR + ka0 + 32 * s) : *(const uint4*)(sK + kb * 32 * PR + ka2);
                 if (HACK == 4) sacc[kb][0] += __builtin_bit_cast(float, kf.x ^ qf[s].x) * 1e-30f; else sacc[kb] = Mfma32<T>::run(kf, qf[s], sacc[kb]);
             }
         }
@@ -898,9 +895,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
         // ---- reference: attempt 0 = maximum over the 64-key sample + MARGIN; attempt 1 (after an overflow) = the exact maximum over all keys
         f32x16 sA[2], sB[2];
         if (attempt == 0) {
-            dma_k(0, dK1, (unsigned)(p.Nkv / KVT));
-            dma_k(0, dK0, 1u);
-            dma_v(0, dV0);
+            dma(0, 0, dK1, (unsigned)(p.Nkv / KVT));
+            dma(0, 0, dK0, 1u);
+            dma(1, 0, dV0, 1u);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             qk(dK1, sA);
@@ -909,25 +906,23 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
             qf[2].x = h == 1 ? 0u : qf[2].x;                      // plain scores again
             float mx = -1e30f;
             __syncthreads();
-            dma_k(0, dK0, 1u);
+            dma(0, 0, dK0, 1u);
             for (int it = 0; it < ntiles; ++it) {
-                unsigned char* cK = (it & 1) ? dK1 : dK0;
-                unsigned char* nK = (it & 1) ? dK0 : dK1;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (it + 1 < ntiles) dma_k(it + 1, nK, 1u);
-                qk(cK, sA);
+                if (it + 1 < ntiles) { if (it & 1) dma(0, it + 1, dK0, 1u); else dma(0, it + 1, dK1, 1u); }
+                if (it & 1) qk(dK1, sA); else qk(dK0, sA);
                 if (RAGGED && it + 1 == ntiles) mask_last(sA);
                 mx = fmaxf(mx, row_max(sA));
             }
             set_reference(mx);
             __syncthreads();
-            dma_k(0, dK0, 1u);
-            dma_v(0, dV0);
+            dma(0, 0, dK0, 1u);
+            dma(1, 0, dV0, 1u);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __syncthreads();                                          // everybody is done with the sample (the last sweep tile) in dK1
-        if (ntiles > 1) dma_k(1, dK1, 1u);
+        __syncthreads();                                          // everybody is done with the sample (the last sweep tile) in K buffer 1
+        if (ntiles > 1) dma(0, 1, dK1, 1u);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -952,27 +947,45 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    // keys 32 kb + 16 s2 + 4 h + {0..3} (elements 0..3) and + 8 (elements 4..7) = 8-key groups 4 kb + 2 s2 and + 1
-                    const unsigned char* g0 = cV + (4 * kb + 2 * s2) * 8 * PR;
+                    // keys 32 kb + 16 s2 + 8 j4 + 4 h + q, j4 = 0 (elements 0..3), 1 (elements 4..7): rows 16 (2 kb + s2) + 4 q + 2 j4 + h
+                    const int g0 = 16 * (2 * kb + s2) * PR;
                     {
-                        const uint2 lo = ds_read_tr16(g0 + vro), hi = ds_read_tr16(g0 + 8 * PR + vro);
+                        const uint2 lo = ds_read_tr16(cV + g0 + va0), hi = ds_read_tr16(cV + g0 + 2 * PR + va0);
                         const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
                         if (HACK == 3) oacc[0][0] += __builtin_bit_cast(float, vf.x ^ pb[kb][s2].x); else oacc[0] = Mfma32<T>::run(vf, pb[kb][s2], oacc[0]);
                     }
                     {
-                        const uint2 lo = ds_read_tr16(g0 + vro1), hi = ds_read_tr16(g0 + 8 * PR + vro1);
+                        const uint2 lo = ds_read_tr16(cV + g0 + va1), hi = ds_read_tr16(cV + g0 + 2 * PR + va1);
                         const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
                         if (HACK == 3) oacc[1][0] += __builtin_bit_cast(float, vf.x ^ pb[kb][s2].x); else oacc[1] = Mfma32<T>::run(vf, pb[kb][s2], oacc[1]);
                     }
                 }
+            if (HACK == 0) {
+                // requested issue order (the block has 14 MFMAs, 32 v_exp, 16 v_cvt_pk, 6 + 16 LDS reads): K fragments and the first V fragments up
+                // front, every further V read five MFMAs ahead of its use, and the exponentials / conversions of this tile spread evenly over
+                // the MFMA shadows (2-3 v_exp + 1-2 v_cvt_pk per MFMA: ~36 issue cycles against the MFMA's 32)
+#define VV_SGB_STEP(NE, NC, ND) \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
+                if (NE) __builtin_amdgcn_sched_group_barrier(0x400, NE, 0); \
+                if (NC) __builtin_amdgcn_sched_group_barrier(0x002, NC, 0); \
+                if (ND) __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);      // (exponentials first: they do not wait for the LDS reads just issued)
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                VV_SGB_STEP(3, 2, 1) VV_SGB_STEP(2, 1, 1) VV_SGB_STEP(2, 1, 1) VV_SGB_STEP(3, 2, 1) VV_SGB_STEP(2, 1, 1) VV_SGB_STEP(2, 1, 1)
+                VV_SGB_STEP(3, 1, 1) VV_SGB_STEP(2, 1, 1) VV_SGB_STEP(2, 1, 1) VV_SGB_STEP(3, 2, 1) VV_SGB_STEP(2, 1, 1) VV_SGB_STEP(2, 1, 1)
+                VV_SGB_STEP(0, 0, 0) VV_SGB_STEP(0, 0, 0)
+#undef VV_SGB_STEP
+            }
         };
         // step `it`: K(it+1) and V(it) have landed (issued one step ago); issue K(it+2) over K(it) and V(it+1) over V(it-1)
         auto step = [&](const int it, unsigned char* kA, unsigned char* kB, unsigned char* vA, unsigned char* vB, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (HACK != 1) __syncthreads();
             if (HACK != 5) {
-                if (it + 2 < ntiles) dma_k(it + 2, kA, 1u);
-                if (it + 1 < ntiles) dma_v(it + 1, vB);
+                if (it + 2 < ntiles) dma(0, it + 2, kA, 1u);
+                if (it + 1 < ntiles) dma(1, it + 1, vB, 1u);
             }
             body(kB, vA, sc, sn);                                 // (the last step computes scores of a tile that does not exist: stale K, never used)
             if (RAGGED && it + 2 == ntiles) mask_last(sn);
@@ -1086,6 +1099,7 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
                 if (var == 52) return attn40_launch<T, 4, 2>(p, st);                                    // ... 2 waves/SIMD
                 if (var == 53) return attn40_launch<T, 8, 2>(p, st);                                    // ... 8-wave blocks
                 if (var == 54) return attn40_launch<T, 2, 4>(p, st);                                    // ... 2-wave blocks
+                if (var == 55) return attn40_launch<T, 4, 2, 6>(p, st);                                 // ... the compiler's own issue order (no sched_group_barrier pipeline)
                 if (var == 61) return attn40_launch<T, 4, 2, 1>(p, st);      // timing probes (WRONG results): no barrier
                 if (var == 62) return attn40_launch<T, 4, 2, 2>(p, st);      // ... no exp
                 if (var == 63) return attn40_launch<T, 4, 2, 3>(p, st);      // ... no PV MFMAs
