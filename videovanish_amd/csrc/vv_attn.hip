@@ -850,9 +850,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
     // transposed V read: 16-lane group g = lane >> 4 (g & 1 = cb: which 16 columns, g >> 1 = h); lane 4 q + pp of the group addresses row q, columns 4 pp ..
     const int vq = (lane >> 2) & 3, vpp = lane & 3, vcb = (lane >> 4) & 1;
     const int va0 = (4 * vq + h) * PR + (16 * vcb + 4 * vpp) * 2;             // d block 0; + (16 (2 kb + s2) + 2 j4) rows
-    // d block 1: columns 32..39 are data (pp = 0, 1 of cb = 0), 40..43 the constant (pp = 2: 1.0 -> O^T rows 40..43 = sum_k P); every other lane
-    // only feeds O^T rows that are never read: it repeats a data address
-    const int va1 = (vcb == 0 && vpp == 2) ? TILE : (4 * vq + h) * PR + 64 + 8 * (vpp & 1);
+    // d block 1 = columns 32..47 on the 16x16x32 form (k group g = lane >> 4 holds keys 32 kb + 16 (g & 1) + 4 (g >> 1) + {0..3, 8..11}): columns 32..39
+    // are data (pp = 0, 1), 40..43 the constant (pp = 2: 1.0 -> O^T rows 40..43 = sum_k P), pp = 3 feeds rows that are never read (repeats pp = 1)
+    const int va1 = vpp == 2 ? TILE : (16 * vcb + 4 * vq + h) * PR + 64 + 8 * (vpp & 1);
 
     // S^T = K Q^T for the 64 keys of the K tile at byte offset kb0 (2 key blocks x 3 k steps)
     auto qk = [&](const unsigned char* sK, f32x16 (&sacc)[2]) {
@@ -888,8 +888,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
         qf[2].x = h == 1 ? ((unsigned)hi | ((unsigned)lo << 16)) : qf[2].x;
     };
 
-    f32x16 oacc[2];
-    float l = 0.f;
+    f32x16 oacc;              // O^T rows 0..31 (32x32x16 layout: lane = query, registers + h = d)
+    f32x4 o2[2];              // O^T rows 32..47 for the queries 0..15 / 16..31 of the wave (16x16x32 layout: lane & 15 = query, 4 (lane >> 4) + reg = d - 32)
+    float la = 0.f, lb = 0.f;
 #pragma nounroll
     for (int attempt = 0; attempt < 2; ++attempt) {
         // ---- reference: attempt 0 = maximum over the 64-key sample + MARGIN; attempt 1 (after an overflow) = the exact maximum over all keys
@@ -924,9 +925,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
         __syncthreads();                                          // everybody is done with the sample (the last sweep tile) in K buffer 1
         if (ntiles > 1) dma(0, 1, dK1, 1u);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[m][i] = 0.f;
+        for (int i = 0; i < 16; ++i) oacc[i] = 0.f;
+        o2[0] = f32x4{0.f, 0.f, 0.f, 0.f}; o2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         qk(dK0, sA);
         if (RAGGED && ntiles == 1) mask_last(sA);
 
@@ -944,23 +944,33 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
                                             pack2<T>(sc[kb][8 * s2 + 4], sc[kb][8 * s2 + 5]), pack2<T>(sc[kb][8 * s2 + 6], sc[kb][8 * s2 + 7]));
             }
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    // keys 32 kb + 16 s2 + 8 j4 + 4 h + q, j4 = 0 (elements 0..3), 1 (elements 4..7): rows 16 (2 kb + s2) + 4 q + 2 j4 + h
+                    // rows 0..31 of O^T: keys 32 kb + 16 s2 + 8 j4 + 4 h + q, j4 = 0 (elements 0..3), 1 (elements 4..7): V rows 16 (2 kb + s2) + 4 q + 2 j4 + h
                     const int g0 = 16 * (2 * kb + s2) * PR;
-                    {
-                        const uint2 lo = ds_read_tr16(cV + g0 + va0), hi = ds_read_tr16(cV + g0 + 2 * PR + va0);
-                        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                        if (HACK == 3) oacc[0][0] += __builtin_bit_cast(float, vf.x ^ pb[kb][s2].x); else oacc[0] = Mfma32<T>::run(vf, pb[kb][s2], oacc[0]);
-                    }
-                    {
-                        const uint2 lo = ds_read_tr16(cV + g0 + va1), hi = ds_read_tr16(cV + g0 + 2 * PR + va1);
-                        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                        if (HACK == 3) oacc[1][0] += __builtin_bit_cast(float, vf.x ^ pb[kb][s2].x); else oacc[1] = Mfma32<T>::run(vf, pb[kb][s2], oacc[1]);
-                    }
+                    const uint2 lo = ds_read_tr16(cV + g0 + va0), hi = ds_read_tr16(cV + g0 + 2 * PR + va0);
+                    const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    if (HACK == 3) oacc[0] += __builtin_bit_cast(float, vf.x ^ pb[kb][s2].x); else oacc = Mfma32<T>::run(vf, pb[kb][s2], oacc);
                 }
-            if (HACK == 0) {
+                // rows 32..47 on the 16x16x32 form (M = 16 instead of a second, three-quarters empty 32-row block): v_permlane16_swap turns the
+                // (s2 = 0, s2 = 1) dword pairs of P -- rows {q 0..15 | q 16..31} x {h = 0 | h = 1} -- into the B operands of the two query tiles:
+                // every 16-lane row then holds queries 0..15 (resp. 16..31) and k group g = (h, s2) = keys 32 kb + 16 s2 + 4 h + {0..3, 8..11}
+                uint4 pa, pq;
+                {
+                    auto s0 = __builtin_amdgcn_permlane16_swap(pb[kb][0].x, pb[kb][1].x, false, false);
+                    auto s1 = __builtin_amdgcn_permlane16_swap(pb[kb][0].y, pb[kb][1].y, false, false);
+                    auto s2_ = __builtin_amdgcn_permlane16_swap(pb[kb][0].z, pb[kb][1].z, false, false);
+                    auto s3 = __builtin_amdgcn_permlane16_swap(pb[kb][0].w, pb[kb][1].w, false, false);
+                    pa = make_uint4(s0[0], s1[0], s2_[0], s3[0]);
+                    pq = make_uint4(s0[1], s1[1], s2_[1], s3[1]);
+                }
+                const uint2 lo = ds_read_tr16(cV + kb * 32 * PR + va1), hi = ds_read_tr16(cV + kb * 32 * PR + 2 * PR + va1);
+                const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                if (HACK == 3) { o2[0][0] += __builtin_bit_cast(float, vf.x ^ pa.x); o2[1][0] += __builtin_bit_cast(float, vf.x ^ pq.x); }
+                else { o2[0] = T::mfma(vf, pa, o2[0]); o2[1] = T::mfma(vf, pq, o2[1]); }
+            }
+            if (HACK == 7) {
                 // requested issue order (the block has 14 MFMAs, 32 v_exp, 16 v_cvt_pk, 6 + 16 LDS reads): K fragments and the first V fragments up
                 // front, every further V read five MFMAs ahead of its use, and the exponentials / conversions of this tile spread evenly over
                 // the MFMA shadows (2-3 v_exp + 1-2 v_cvt_pk per MFMA: ~36 issue cycles against the MFMA's 32)
@@ -994,20 +1004,31 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
             step(it, dK0, dK1, dV0, dV1, sA, sB);
             if (it + 1 < ntiles) step(it + 1, dK1, dK0, dV1, dV0, sB, sA);
         }
-        // ---- denominator = O^T row 40 = d block 1, register 4, lanes with h = 0.  Non-finite (some P overflowed) or zero: repeat with the exact maximum
-        l = __shfl(oacc[1][4], r);
-        const bool bad = !(l > 0.f && l < 3.0e38f);
+        // ---- denominator = O^T row 40 = register 0 of the row-32.. tiles on the lanes 32..47 (k group 2).  Non-finite (some P overflowed) or zero:
+        // the block repeats its keys with the exact maximum
+        la = __shfl(o2[0][0], 32 + (lane & 15));
+        lb = __shfl(o2[1][0], 32 + (lane & 15));
+        const bool bad = !(la > 0.f && la < 3.0e38f && lb > 0.f && lb < 3.0e38f);
         if (attempt == 1 || !__syncthreads_or(bad ? 1 : 0)) break;
     }
-    // ---- finalize: O[q][d] = O^T[d][q] / l.  Register i of d block m on lane (r, h): d = 32 m + (i & 3) + 8 (i >> 2) + 4 h
-    const float inv = 1.0f / l;
-    const int q = q0 + r;
-    if (q < p.Nq) {
-        unsigned short* orow = O + (int64_t)q * p.o_rs;
+    // ---- finalize: O[q][d] = O^T[d][q] / l.  Rows 0..31: register i on lane (r, h) is d = (i & 3) + 8 (i >> 2) + 4 h of query r
+    {
+        const float inv = 1.0f / (r < 16 ? la : lb);
+        const int q = q0 + r;
+        if (q < p.Nq) {
+            unsigned short* orow = O + (int64_t)q * p.o_rs;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *(uint2*)(orow + 8 * g + 4 * h) = make_uint2(pack2<T>(oacc[0][4 * g] * inv, oacc[0][4 * g + 1] * inv), pack2<T>(oacc[0][4 * g + 2] * inv, oacc[0][4 * g + 3] * inv));
-        *(uint2*)(orow + 32 + 4 * h) = make_uint2(pack2<T>(oacc[1][0] * inv, oacc[1][1] * inv), pack2<T>(oacc[1][2] * inv, oacc[1][3] * inv));
+            for (int g = 0; g < 4; ++g)
+                *(uint2*)(orow + 8 * g + 4 * h) = make_uint2(pack2<T>(oacc[4 * g] * inv, oacc[4 * g + 1] * inv), pack2<T>(oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv));
+        }
+    }
+    // rows 32..39: query tile qt, lane (c = lane & 15, g = lane >> 4 < 2): d = 32 + 4 g + reg of query 16 qt + c
+#pragma unroll
+    for (int qt2 = 0; qt2 < 2; ++qt2) {
+        const float inv = 1.0f / (qt2 ? lb : la);
+        const int q = q0 + 16 * qt2 + (lane & 15);
+        if (q < p.Nq && (lane >> 4) < 2)
+            *(uint2*)(O + (int64_t)q * p.o_rs + 32 + 4 * (lane >> 4)) = make_uint2(pack2<T>(o2[qt2][0] * inv, o2[qt2][1] * inv), pack2<T>(o2[qt2][2] * inv, o2[qt2][3] * inv));
     }
 }
 
@@ -1106,7 +1127,7 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
                 if (var == 64) return attn40_launch<T, 4, 2, 4>(p, st);      // ... no QK MFMAs
                 if (var == 65) return attn40_launch<T, 4, 2, 5>(p, st);      // ... no DMA
 #endif
-                if (!cross && p.Nkv >= 64) return attn40_launch<T, 4, 2>(p, st);      // 32x32x16 MFMAs, optimistic reference, 2 waves/SIMD
+                if (!cross && p.Nkv >= 64) return attn40_launch<T, 4, 3>(p, st);      // 32x32x16 / 16x16x32 hybrid, optimistic reference, 3 waves/SIMD
                 if (!cross) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true>(p, st);
             }
             if (D <= 64) return cross ? attn_launch<T, D, 2, 64, 4, false, 3, true, 1>(p, st) : attn_launch<T, D, 2, 64, 4, false, 3, true, 0>(p, st);
