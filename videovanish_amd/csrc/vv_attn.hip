@@ -1032,6 +1032,283 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
     }
 }
 
+template <typename T, int NW, int OCC, bool RAGGED, int HACK = 0>
+__global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_params p, const int nqt) {
+    // TWO 32-query blocks per wave (a, b): every K / V fragment read from LDS and every LDS-DMA piece serves 64 queries -- half the LDS and L2 -> LDS
+    // bytes per FLOP of attn40_kernel (the chip is power limited on this kernel: fewer bytes moved = a higher clock).  Not pipelined across
+    // tiles; the two blocks overlap each other instead: QK_a, QK_b | exp_a, PV_a | exp_b, PV_b in ONE basic block per tile.
+    // LDS: dense 80-byte rows (5 chunks of 8 h16) -- a K or V tile is exactly 5 KB = 5 LDS-DMA wave instructions with EVERY lane active (no
+    // exec masking, no pad slots), 10 per 64-key tile.  The constant operand slots come from a region of 1.0 instead of from the rows:
+    //   K slots 40..47 (Q carries -m hi, -m lo, 0 x 6 there)  and  V columns 40..43 (O^T rows 40.. = sum_k P, the softmax denominator).
+    // Row orders: K natural (80-byte pitch: 16 consecutive rows x one chunk hit 16 different 16-byte bank slots);
+    //             V key 16 g + 4 j + q at row 16 g + 4 q + j (the 4 rows of one transposed read are 4 apart: conflict free at 80 bytes).
+    constexpr int D = 40, KVT = 64, PR = 80, NCH = 5;
+    constexpr int NT = NW * 64, QB = 2, BQ = NW * 32 * QB;
+    constexpr int TILE = KVT * PR;                            // 5120
+    constexpr int NPC = 2 * TILE / 1024;                      // 10 DMA pieces (1 KB each) per tile: 0..4 = K, 5..9 = V
+    constexpr int PPW = (NPC + NW - 1) / NW;                  // pieces per wave (piece j -> wave j % NW)
+    constexpr int KONES = 32 * PR + 64, VONES = 4096 + 64;   // bytes of 1.0 behind each tile buffer (reached with the key-block / k-step immediates)
+    constexpr float MARGIN = 4.0f;
+    // FOUR arrays, not one: hipcc drains vmcnt(0) in front of a ds_read that may alias an LDS-DMA in flight, and tells buffers apart only as
+    // distinct __shared__ objects (the DMA of step `it` targets the buffers the step does not read)
+    __shared__ __attribute__((aligned(1024))) unsigned char dK0[TILE + KONES];
+    __shared__ __attribute__((aligned(1024))) unsigned char dK1[TILE + KONES];
+    __shared__ __attribute__((aligned(1024))) unsigned char dV0[TILE + VONES];
+    __shared__ __attribute__((aligned(1024))) unsigned char dV1[TILE + VONES];
+
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int qt, hd, b;
+    {
+        const int nbh = p.B * p.heads;
+        const int full = (nbh / 8) * 8;
+        const int bid = blockIdx.x;
+        int bh;
+        if (bid < full * nqt) { const int xcd = bid & 7, idx = bid >> 3; bh = (idx / nqt) * 8 + xcd; qt = idx % nqt; }
+        else { const int rr = bid - full * nqt; bh = full + rr / nqt; qt = rr % nqt; }
+        hd = bh % p.heads; b = bh / p.heads;
+    }
+    const unsigned short* Q = (const unsigned short*)p.q + (int64_t)b * p.q_bs + (int64_t)hd * (p.q_hs ? p.q_hs : D);
+    const unsigned char* Kp = (const unsigned char*)((const unsigned short*)p.k + (int64_t)b * p.k_bs + (int64_t)hd * (p.k_hs ? p.k_hs : D));
+    const unsigned char* Vp = (const unsigned char*)((const unsigned short*)p.v + (int64_t)b * p.v_bs + (int64_t)hd * (p.v_hs ? p.v_hs : D));
+    unsigned short* O = (unsigned short*)p.o + (int64_t)b * p.o_bs + (int64_t)hd * D;
+
+    // ---- Q fragments: lane (r, h) holds Q[q0 + r][16 s + 8 h .. +7]; chunk 5 (s = 2, h = 1) is the pad chunk: slots 40, 41 = -m (hi, lo)
+    const int q0 = qt * BQ + wave * 32 * QB;
+    uint4 qf[QB][3];
+#pragma unroll
+    for (int x = 0; x < QB; ++x)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int q = q0 + 32 * x + r, d0 = 16 * s + 8 * h;
+        qf[x][s] = (q < p.Nq && d0 < D) ? *(const uint4*)(Q + (int64_t)q * p.q_rs + d0) : make_uint4(0, 0, 0, 0);
+        if (!p.q_prescaled) {
+            float qv[8];
+            unpack8<T>(qf[x][s], qv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qv[e] *= p.scale * 1.4426950408889634f;
+            qf[x][s] = pack8<T>(qv);
+        }
+    }
+    // ---- constant regions (written once): 1.0 everywhere; the tile buffers start as zeros (rows of a ragged tile that are never loaded stay finite)
+    {
+        const unsigned one2 = (unsigned)T::from_f32(1.0f) * 0x10001u;
+        const uint4 ones = make_uint4(one2, one2, one2, one2), zero = make_uint4(0, 0, 0, 0);
+        for (int i = t; i < (TILE + KONES) / 16; i += NT) { *(uint4*)(dK0 + i * 16) = i < TILE / 16 ? zero : ones; *(uint4*)(dK1 + i * 16) = i < TILE / 16 ? zero : ones; }
+        for (int i = t; i < (TILE + VONES) / 16; i += NT) { *(uint4*)(dV0 + i * 16) = i < TILE / 16 ? zero : ones; *(uint4*)(dV1 + i * 16) = i < TILE / 16 ? zero : ones; }
+    }
+    __syncthreads();
+
+    // ---- this wave's DMA pieces: piece j = wave + NW * i; slot = (j % 5) * 64 + lane = row * 5 + chunk of the K (j < 5) or V tile
+    unsigned doff[PPW];          // byte offset of the slot's source inside a tile (K: key = row; V: key = 16 g + 4 (row & 3) + ((row >> 2) & 3))
+    int dkey[PPW];               // key index inside the tile (ragged last tile)
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int j = wave + NW * i, slot = (j % 5) * 64 + lane, row = slot / NCH, ch = slot - row * NCH;
+        const bool isv = j >= 5;
+        const int key = isv ? (row & ~15) + 4 * (row & 3) + ((row >> 2) & 3) : row;
+        dkey[i] = key;
+        doff[i] = (unsigned)(key * (int)(isv ? p.v_rs : p.k_rs) + ch * 8) * 2u;
+    }
+    const int ntiles = (p.Nkv + KVT - 1) / KVT;
+    const int nlast = p.Nkv - (ntiles - 1) * KVT;             // keys in the last tile (KVT unless RAGGED)
+    const unsigned kstep = (unsigned)(KVT * (int)p.k_rs * 2), vstep = (unsigned)(KVT * (int)p.v_rs * 2);
+    // K part (kind 0), V part (kind 1) of tile `it` -> LDS buffer at byte offset `dst`; stride > 1: the 64-key SAMPLE (keys 0, stride, 2 stride, ..)
+    auto dma = [&](const int kind, const int it, unsigned char* dst, const unsigned stride) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int j = wave + NW * i;                          // wave-uniform
+            if (j < NPC && (j >= 5) == (kind == 1)) {
+                const unsigned char* src = kind ? Vp + (size_t)it * vstep : Kp + (size_t)it * kstep;
+                unsigned off = doff[i];
+                if (stride != 1) off += (unsigned)(dkey[i] * (int)p.k_rs * 2) * (stride - 1);
+                if (RAGGED && it + 1 == ntiles && stride == 1) { if (dkey[i] < nlast) glds16(src + off, dst + (j % 5) * 1024); }
+                else glds16(src + off, dst + (j % 5) * 1024);
+            }
+        }
+    };
+
+    // ---- lane-constant LDS read addresses (byte offsets into a tile buffer; the key block / k step are instruction immediates)
+    const int ka0 = r * PR + 16 * h;                             // K chunks h (s = 0) and 2 + h (s = 1: + 32)
+    const int ka2 = h ? TILE : r * PR + 64;                     // s = 2: chunk 4 for h = 0, the constant chunk (1.0: slots 40..47) for h = 1
+    // transposed V read: 16-lane group g = lane >> 4 (g & 1 = cb: which 16 columns, g >> 1 = h); lane 4 q + pp of the group addresses row q, columns 4 pp ..
+    const int vq = (lane >> 2) & 3, vpp = lane & 3, vcb = (lane >> 4) & 1;
+    const int va0 = (4 * vq + h) * PR + (16 * vcb + 4 * vpp) * 2;             // d block 0; + (16 (2 kb + s2) + 2 j4) rows
+    // d block 1 = columns 32..47 on the 16x16x32 form (k group g = lane >> 4 holds keys 32 kb + 16 (g & 1) + 4 (g >> 1) + {0..3, 8..11}): columns 32..39
+    // are data (pp = 0, 1), 40..43 the constant (pp = 2: 1.0 -> O^T rows 40..43 = sum_k P), pp = 3 feeds rows that are never read (repeats pp = 1)
+    const int va1 = vpp == 2 ? TILE : (16 * vcb + 4 * vq + h) * PR + 64 + 8 * (vpp & 1);
+
+    // S^T = K Q^T for the 64 keys of the K tile at byte offset kb0 (2 key blocks x 3 k steps)
+    auto qk = [&](const unsigned char* sK, const int x, f32x16 (&sacc)[2]) {      // (the second block's fragment reads are the first block's: CSE'd)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const uint4 kf = s < 2 ? *(const uint4*)(sK + kb * 32 * PR + ka0 + 32 * s) : *(const uint4*)(sK + kb * 32 * PR + ka2);
+                sacc[kb] = Mfma32<T>::run(kf, qf[x][s], sacc[kb]);
+            }
+        }
+    };
+    auto mask_last = [&](f32x16 (&sacc)[2]) {                     // keys past Nkv of the ragged last tile: -inf scores (P = 0)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= nlast) sacc[kb][i] = -1e30f;
+    };
+    auto row_max = [&](const f32x16 (&sacc)[2]) {
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kb][i]);
+        return fmaxf(mx, __shfl_xor(mx, 32));
+    };
+    auto set_reference = [&](const int x, const float target) {   // pad slots 40, 41 of Q <- -target as the nearest h16 hi + lo pair
+        const unsigned short hi = T::from_f32(-target);
+        const unsigned short lo = T::from_f32(-target - T::to_f32(hi));
+        qf[x][2].x = h == 1 ? ((unsigned)hi | ((unsigned)lo << 16)) : qf[x][2].x;
+    };
+
+    f32x16 oacc[QB];          // O^T rows 0..31 per query block (32x32x16 layout: lane = query, registers + h = d)
+    f32x4 o2[QB][2];          // O^T rows 32..47 for the queries 0..15 / 16..31 of each block (16x16x32 layout)
+    float la[QB], lb[QB];
+#pragma nounroll
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // ---- reference: attempt 0 = maximum over the 64-key sample + MARGIN; attempt 1 (after an overflow) = the exact maximum over all keys
+        f32x16 sc[QB][2];
+        if (attempt == 0) {
+            dma(0, 0, dK1, (unsigned)(p.Nkv / KVT));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#pragma unroll
+            for (int x = 0; x < QB; ++x) { qk(dK1, x, sc[x]); set_reference(x, row_max(sc[x]) + MARGIN); }
+        } else {
+            float mx[QB];
+#pragma unroll
+            for (int x = 0; x < QB; ++x) { qf[x][2].x = h == 1 ? 0u : qf[x][2].x; mx[x] = -1e30f; }      // plain scores again
+            __syncthreads();
+            dma(0, 0, dK0, 1u);
+            for (int it = 0; it < ntiles; ++it) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (it + 1 < ntiles) { if (it & 1) dma(0, it + 1, dK0, 1u); else dma(0, it + 1, dK1, 1u); }
+#pragma unroll
+                for (int x = 0; x < QB; ++x) {
+                    if (it & 1) qk(dK1, x, sc[x]); else qk(dK0, x, sc[x]);
+                    if (RAGGED && it + 1 == ntiles) mask_last(sc[x]);
+                    mx[x] = fmaxf(mx[x], row_max(sc[x]));
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < QB; ++x) set_reference(x, mx[x]);
+        }
+        __syncthreads();                                          // everybody is done with the sample (the last sweep tile)
+        dma(0, 0, dK0, 1u);
+        dma(1, 0, dV0, 1u);
+#pragma unroll
+        for (int x = 0; x < QB; ++x) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[x][i] = 0.f;
+            o2[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o2[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // one tile: scores of both blocks, then per block  P = exp2(S) packed, O^T += V^T P^T   -- ONE basic block, no branch
+        auto body = [&](const unsigned char* cK, const unsigned char* cV, const bool last) {
+#pragma unroll
+            for (int x = 0; x < QB; ++x) { qk(cK, x, sc[x]); if (RAGGED && last) mask_last(sc[x]); }
+#pragma unroll
+            for (int x = 0; x < QB; ++x) {
+                uint4 pb[2][2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sc[x][kb][i] = HACK == 2 ? sc[x][kb][i] * 0.01f : __builtin_amdgcn_exp2f(sc[x][kb][i]);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+                        pb[kb][s2] = make_uint4(pack2<T>(sc[x][kb][8 * s2 + 0], sc[x][kb][8 * s2 + 1]), pack2<T>(sc[x][kb][8 * s2 + 2], sc[x][kb][8 * s2 + 3]),
+                                                pack2<T>(sc[x][kb][8 * s2 + 4], sc[x][kb][8 * s2 + 5]), pack2<T>(sc[x][kb][8 * s2 + 6], sc[x][kb][8 * s2 + 7]));
+                }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const int g0 = 16 * (2 * kb + s2) * PR;
+                        const uint2 lo = ds_read_tr16(cV + g0 + va0), hi = ds_read_tr16(cV + g0 + 2 * PR + va0);
+                        oacc[x] = Mfma32<T>::run(make_uint4(lo.x, lo.y, hi.x, hi.y), pb[kb][s2], oacc[x]);
+                    }
+                    uint4 pa, pq;
+                    {
+                        auto s0 = __builtin_amdgcn_permlane16_swap(pb[kb][0].x, pb[kb][1].x, false, false);
+                        auto s1 = __builtin_amdgcn_permlane16_swap(pb[kb][0].y, pb[kb][1].y, false, false);
+                        auto s2_ = __builtin_amdgcn_permlane16_swap(pb[kb][0].z, pb[kb][1].z, false, false);
+                        auto s3 = __builtin_amdgcn_permlane16_swap(pb[kb][0].w, pb[kb][1].w, false, false);
+                        pa = make_uint4(s0[0], s1[0], s2_[0], s3[0]);
+                        pq = make_uint4(s0[1], s1[1], s2_[1], s3[1]);
+                    }
+                    const uint2 lo = ds_read_tr16(cV + kb * 32 * PR + va1), hi = ds_read_tr16(cV + kb * 32 * PR + 2 * PR + va1);
+                    const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    o2[x][0] = T::mfma(vf, pa, o2[x][0]); o2[x][1] = T::mfma(vf, pq, o2[x][1]);
+                }
+            }
+        };
+        // step `it`: tile `it` (K and V) has landed; issue tile it+1 into the other buffers
+        auto step = [&](const int it, unsigned char* cK, unsigned char* cV, unsigned char* nK, unsigned char* nV) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (HACK != 1) __syncthreads();
+            if (it + 1 < ntiles && HACK != 5) { dma(0, it + 1, nK, 1u); dma(1, it + 1, nV, 1u); }
+            body(cK, cV, it + 1 == ntiles);
+        };
+        for (int it = 0; it < ntiles; it += 2) {
+            step(it, dK0, dV0, dK1, dV1);
+            if (it + 1 < ntiles) step(it + 1, dK1, dV1, dK0, dV0);
+        }
+        // ---- denominators (O^T row 40 = register 0 of the row-32.. tiles on the lanes 32..47); non-finite or zero: repeat with the exact maximum
+        bool bad = false;
+#pragma unroll
+        for (int x = 0; x < QB; ++x) {
+            la[x] = __shfl(o2[x][0][0], 32 + (lane & 15));
+            lb[x] = __shfl(o2[x][1][0], 32 + (lane & 15));
+            bad = bad || !(la[x] > 0.f && la[x] < 3.0e38f && lb[x] > 0.f && lb[x] < 3.0e38f);
+        }
+        if (attempt == 1 || !__syncthreads_or(bad ? 1 : 0)) break;
+    }
+    // ---- finalize: O[q][d] = O^T[d][q] / l
+#pragma unroll
+    for (int x = 0; x < QB; ++x) {
+        {
+            const float inv = 1.0f / (r < 16 ? la[x] : lb[x]);
+            const int q = q0 + 32 * x + r;
+            if (q < p.Nq) {
+                unsigned short* orow = O + (int64_t)q * p.o_rs;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(uint2*)(orow + 8 * g + 4 * h) = make_uint2(pack2<T>(oacc[x][4 * g] * inv, oacc[x][4 * g + 1] * inv), pack2<T>(oacc[x][4 * g + 2] * inv, oacc[x][4 * g + 3] * inv));
+            }
+        }
+#pragma unroll
+        for (int qt2 = 0; qt2 < 2; ++qt2) {
+            const float inv = 1.0f / (qt2 ? lb[x] : la[x]);
+            const int q = q0 + 32 * x + 16 * qt2 + (lane & 15);
+            if (q < p.Nq && (lane >> 4) < 2)
+                *(uint2*)(O + (int64_t)q * p.o_rs + 32 + 4 * (lane >> 4)) = make_uint2(pack2<T>(o2[x][qt2][0] * inv, o2[x][qt2][1] * inv), pack2<T>(o2[x][qt2][2] * inv, o2[x][qt2][3] * inv));
+        }
+    }
+}
+
+template <typename T, int NW, int OCC, int HACK = 0>
+int attn40q2_launch(const vv_attn_params& p, hipStream_t st) {
+    constexpr int BQ = NW * 64;
+    const int nqt = (p.Nq + BQ - 1) / BQ;
+    const int64_t nblk = (int64_t)p.B * p.heads * nqt;
+    if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_attention: grid too large");
+    if (p.Nkv % 64) hipLaunchKernelGGL((attn40q2_kernel<T, NW, OCC, true, HACK>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p, nqt);
+    else hipLaunchKernelGGL((attn40q2_kernel<T, NW, OCC, false, HACK>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p, nqt);
+    VV_CHECK_LAUNCH("vv_attention(d40, 64 queries per wave)");
+    return VV_OK;
+}
+
 template <typename T, int NW, int OCC, int HACK = 0>
 int attn40_launch(const vv_attn_params& p, hipStream_t st) {
     constexpr int BQ = NW * 32;
@@ -1120,6 +1397,9 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
                 if (var == 52) return attn40_launch<T, 4, 2>(p, st);                                    // ... 2 waves/SIMD
                 if (var == 53) return attn40_launch<T, 8, 2>(p, st);                                    // ... 8-wave blocks
                 if (var == 54) return attn40_launch<T, 2, 4>(p, st);                                    // ... 2-wave blocks
+                if (var == 56) return attn40q2_launch<T, 4, 2>(p, st);                                  // 64 queries per wave, 2 waves/SIMD
+                if (var == 57) return attn40q2_launch<T, 2, 2>(p, st);                                  // ... 2-wave blocks
+                if (var == 58) return attn40q2_launch<T, 4, 1>(p, st);                                  // ... 1 wave/SIMD (512 registers)
                 if (var == 55) return attn40_launch<T, 4, 2, 6>(p, st);                                 // ... the compiler's own issue order (no sched_group_barrier pipeline)
                 if (var == 61) return attn40_launch<T, 4, 2, 1>(p, st);      // timing probes (WRONG results): no barrier
                 if (var == 62) return attn40_launch<T, 4, 2, 2>(p, st);      // ... no exp
