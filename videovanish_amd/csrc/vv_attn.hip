@@ -1407,7 +1407,8 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
                 if (var == 64) return attn40_launch<T, 4, 2, 4>(p, st);      // ... no QK MFMAs
                 if (var == 65) return attn40_launch<T, 4, 2, 5>(p, st);      // ... no DMA
 #endif
-                if (!cross && p.Nkv >= 64) return attn40_launch<T, 4, 3>(p, st);      // 32x32x16 / 16x16x32 hybrid, optimistic reference, 3 waves/SIMD
+                // 32x32x16 / 16x16x32 hybrid, optimistic reference: 64 queries per wave (2 waves/SIMD) on long sequences, 32 (3 waves/SIMD) below
+                if (!cross && p.Nkv >= 64) return p.Nq >= 1024 ? attn40q2_launch<T, 4, 2>(p, st) : attn40_launch<T, 4, 3>(p, st);
                 if (!cross) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true>(p, st);
             }
             if (D <= 64) return cross ? attn_launch<T, D, 2, 64, 4, false, 3, true, 1>(p, st) : attn_launch<T, D, 2, 64, 4, false, 3, true, 0>(p, st);
