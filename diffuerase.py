@@ -25,17 +25,42 @@ _run_config = None      # set through configure(); None = full SD-1.5 / sd-vae-f
 _dist = None
 _gather = "all"
 _prior_stages = {}      # configure(prior=...): optional learned stages of the ProPainter prior (flow_completion, generator)
+_weights = None         # configure(weights=...) / $VV_WEIGHTS_DIR: a local model store (videovanish_amd/modelhub.py) or a CheckpointWeights
+_loaded = None          # (CheckpointWeights, prior stages) resolved from _weights, cached until configure() is called again
 
 
-def configure(run: RunConfig = None, dist=None, gather="all", prior=None):
+def configure(run: RunConfig = None, dist=None, gather="all", prior=None, weights=None):
     """Select architecture / chunking / dtype for subsequently constructed models (tests use small configs).
     dist = (rank, world) with torch.distributed initialised, one process per GPU (torchrun); gather = "all": every rank returns
     every frame; "rank0": only rank 0 does (the other ranks get None for frames they do not own and should not write a file).
-    prior = {"flow_completion": bool, "generator": bool}: run the learned stages of the full ProPainter prior (videovanish_amd/propainter.py;
-    off by default -- their trained weights are not reachable from the build image)."""
-    global _run_config, _dist, _gather, last_ckpt, _prior_stages, propainter
+    prior = {"flow_completion": bool, "generator": bool}: run the learned stages of the full ProPainter prior (videovanish_amd/propainter.py).
+    weights = a directory holding the four checkpoints the reference names (reference :41-43,49; layout: videovanish_amd/modelhub.py), or a
+    checkpoint.CheckpointWeights.  Without it (and without $VV_WEIGHTS_DIR) the models are seeded random-init of the same architecture.
+    With it every tensor is checked against the architecture first, the empty prompt is CLIP-encoded once, the PCM "2-Step" LoRA is merged,
+    and the learned ProPainter stages switch ON when their files are present (unless `prior` says otherwise)."""
+    global _run_config, _dist, _gather, last_ckpt, _prior_stages, propainter, _weights, _loaded
     _run_config, _dist, _gather, last_ckpt = run, dist, gather, None
     _prior_stages, propainter = dict(prior or {}), None
+    _weights, _loaded = weights, None
+
+
+def _resolve_weights(ckpt):
+    """(weight source | None, prior stages) for the configured / environment-named model store."""
+    global _loaded
+    src = _weights if _weights is not None else os.environ.get("VV_WEIGHTS_DIR")
+    if src is None:
+        return None, dict(_prior_stages)
+    if _loaded is None:
+        if isinstance(src, (str, os.PathLike)):
+            from videovanish_amd import modelhub
+            run = _run_config or RunConfig()
+            _loaded = modelhub.load(os.fspath(src), ckpt=ckpt, ucfg=run.unet, vcfg=run.vae)
+        else:
+            _loaded = (src, {"flow_completion": "fc" in src.components, "generator": "gen" in src.components and "fc" in src.components})
+    w, stages = _loaded
+    stages = dict(stages)
+    stages.update(_prior_stages)            # an explicit configure(prior=...) wins
+    return w, stages
 
 
 def run_infill_on_frames(frames_rgb, mask_frames, mask_dilation_iter=8, ckpt="2-Step",
@@ -57,11 +82,13 @@ def run_infill_on_frames(frames_rgb, mask_frames, mask_dilation_iter=8, ckpt="2-
         ckpt = "2-Step"
         last_ckpt = ckpt
         video_inpainting_sd = DiffuEraser(device, "stable-diffusion-v1-5/stable-diffusion-v1-5", "stabilityai/sd-vae-ft-mse",
-                                          "lixiaowen/diffuEraser", ckpt=ckpt, run=_run_config, dist=_dist, gather=_gather)
+                                          "lixiaowen/diffuEraser", ckpt=ckpt, run=_run_config, dist=_dist, gather=_gather,
+                                          weights=_resolve_weights(ckpt)[0])
 
     if propainer_frames is None:                                                # reference :47-57
         if propainter is None:
-            propainter = Propainter("ruffy369/propainter", device=device, **_prior_stages)
+            w, stages = _resolve_weights("2-Step")
+            propainter = Propainter("ruffy369/propainter", device=device, weights=w if (w is not None and "raft" in w.components) else None, **stages)
         if prog is not None: prog(20, "running propainter prior")
         propainer_frames = propainter.forward(frames_rgb, dilated_mask_frames, ref_stride=10, neighbor_length=10,
                                               subvideo_length=50, mask_dilation=0, progress=prog)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VV_ABI_VERSION 6
+#define VV_ABI_VERSION 7
 
 enum { VV_BF16 = 0, VV_F16 = 1, VV_F32 = 2, VV_U8 = 3 };
 enum { VV_OK = 0, VV_E_ARG = -1, VV_E_UNSUPPORTED = -2, VV_E_LAUNCH = -3 };
@@ -299,6 +299,10 @@ int vv_pad_channels_f32(const float* x, int64_t rows, int cin, int cpad, float s
 /* split precision operands for the 3-pass "precise" convolutions (VAE decoder): hi = h16(x), lo = h16((x - hi) * lo_scale);
  * x*w ~= hi*wh + (lo*wh)/lo_scale + hi*wl/w_scale, each product one vv_conv_gemm launch accumulated through res0/out_scale */
 int vv_split_f32(const float* x, int64_t n, float lo_scale, void* hi16, void* lo16, int dtype, void* stream);
+/* the K-concatenated form used by the split-precision ("precise") layers since ABI 7: x [rows][C] (fp32, or h16 = its own hi part) ->
+ * out [rows][3C] h16 = [ hi | (x - hi) * 2^4 | hi * 2^-10 ].  With the weights packed as [ wh | wh * 2^-4 | (w - wh) * 2^10 ] over 3C input
+ * channels ONE vv_conv_gemm launch accumulates hi*wh + lo*wh + hi*wl in fp32 (was: three launches through res0 / out_scale) */
+int vv_split3(const void* x, int x_dtype, int64_t rows, int C, void* out16, int dtype, void* stream);
 /* decoded [T][H][W][ld] fp32 (first 3 channels) -> pix01 = clamp(x/2+0.5,0,1) blended into acc:
  * acc = acc*(1-w[t]) + pix*w[t]  (separately rounded fp32 products, no FMA contraction) */
 int vv_decode_blend(const float* dec, int ld, const float* w, int T, int64_t HW, float* acc, void* stream);

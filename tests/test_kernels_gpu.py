@@ -307,16 +307,18 @@ def test_attention_online_softmax_rescale(gpu):
     assert (got - ref).abs().max().item() <= 2 ** -6 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("N", [64 * 9 - 37, 64 * 18 - 37, 64 * 17])      # 32 queries per wave (N < 1024) / 64 queries per wave, ragged and whole last tile
 @pytest.mark.parametrize("dname,td,ulp", [("bf16", torch.bfloat16, 2 ** -8), ("fp16", torch.float16, 2 ** -11)])
-def test_attention_d40_lazy_reference_maximum(gpu, dname, td, ulp):
-    """The d = 40 spatial kernel subtracts a LAZY reference maximum on the matrix pipe (vv_attn.hip, LAZY): exercise what that adds --
-    q_prescaled (scale * log2 e folded into q before its one rounding), maxima that creep up by less than the lag the kernel tolerates,
-    maxima that jump by hundreds in a late tile, a first tile far BELOW the rest (the reference must still be set from it and then
-    rise), a ragged last tile, and rows past Nq."""
+def test_attention_d40_lazy_reference_maximum(gpu, dname, td, ulp, N):
+    """The d = 40 spatial kernels subtract a softmax reference ON THE MATRIX PIPE (vv_attn.hip attn40_kernel / attn40q2_kernel: the reference is
+    fixed once from a 64-key sample, P may exceed 1, a block whose denominator overflows repeats its keys with the exact maximum): exercise
+    what that adds -- q_prescaled (scale * log2 e folded into q before its one rounding), maxima that creep up tile after tile, maxima that
+    jump by hundreds in a late tile (fp16: overflow -> the exact-maximum repeat), a first tile far BELOW the rest, a ragged last tile,
+    rows past Nq."""
     from videovanish_amd import hip
     dt = hip.dtype_id(dname)
     g = torch.Generator().manual_seed(11)
-    B, heads, N, D = 2, 8, 64 * 9 - 37, 40
+    B, heads, D = 2, 8, 40
     C = heads * D
     c = hip.attention_q_scale(D)
     q = torch.randn(B, N, heads, D, generator=g)
@@ -432,7 +434,7 @@ def test_image_kernels_bit_exact(gpu):
 
 @pytest.mark.parametrize("dname,tol", [("fp16", 3e-6), ("bf16", 1.5e-4)])
 def test_precise_split_conv_and_linear(gpu, dname, tol):
-    """Split-precision layers (nn._precise_gemm: hi*wh + lo*wh + hi*wl in three MFMA launches) against an fp64 reference on
+    """Split-precision layers (hi*wh + lo*wh + hi*wl as ONE K-concatenated MFMA launch: hip.split3 / nn.split3_weight) against an fp64 reference on
     UN-rounded fp32 operands: the error must sit orders of magnitude below the one-pass h16 layer (5e-4 fp16 / 4e-3 bf16)."""
     from videovanish_amd import nn as vnn
     g = torch.Generator().manual_seed(31)

@@ -364,3 +364,82 @@ def test_checkpoint_weight_source_round_trip(gpu):
     ck = CheckpointWeights(rec.components, text_states=rec.text_states)
     b, _ = DiffuEraserHIP(run, weights=ck).forward(frames, m2d, prior, return_float=True)
     assert np.array_equal(a, b)
+
+
+def test_weights_directory_through_the_drop_in(gpu, tmp_path):
+    """SURVEY 8f row n2 end to end: a store laid out like the reference's four hub ids (modelhub.py) -> diffuerase.configure(weights=dir) ->
+    run_infill_on_frames.  The store holds the synthetic model exported under its checkpoint names (+ a zero PCM LoRA, + the text states),
+    so the result must equal the run on the generator itself bit for bit; a store with a mis-shaped tensor must be refused by name."""
+    import diffuerase
+    from safetensors.torch import save_file
+    from videovanish_amd import modelhub
+    from videovanish_amd.checkpoint import RecordingWeights
+    from videovanish_amd.pipeline import DiffuEraserHIP
+    from videovanish_amd.weights import SyntheticWeights
+    T, H, W = 3, 32, 40
+    frames, masks, prior = _clip(T, H, W, seed=6)
+    run = RunConfig(steps=2, chunk=4, overlap=2, seed=2, dtype="fp16", unet=TINY_UNET, vae=TINY_VAE)
+    rec = RecordingWeights(SyntheticWeights(0))
+    DiffuEraserHIP(run, weights=rec)                                          # constructing the model serves (and records) every tensor
+    root = str(tmp_path / "store")
+    paths = modelhub.component_paths(root)
+    for comp in ("unet", "brushnet", "vae"):
+        os.makedirs(os.path.dirname(paths[comp]), exist_ok=True)
+        save_file({k: v.contiguous() for k, v in rec.components[comp].items()}, paths[comp])
+    save_file({"text_states": rec.text_states.contiguous()}, os.path.join(root, "text_states.safetensors"))
+    layer = "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q"
+    C = rec.components["unet"][layer + ".weight"].shape[0]
+    lp = os.path.join(root, modelhub.PCM_LORA["2-Step"])
+    os.makedirs(os.path.dirname(lp), exist_ok=True)
+    save_file({f"unet.{layer}.lora_A.weight": torch.randn(2, C), f"unet.{layer}.lora_B.weight": torch.zeros(C, 2)}, lp)      # up = 0: merging is the identity
+    try:
+        diffuerase.configure(run)
+        a = diffuerase.run_infill_on_frames(frames, masks, mask_dilation_iter=2, propainer_frames=prior, max_img_size=64, num_inference_steps=2, scheduler="ddim")
+        diffuerase.configure(run, weights=root)
+        b = diffuerase.run_infill_on_frames(frames, masks, mask_dilation_iter=2, propainer_frames=prior, max_img_size=64, num_inference_steps=2, scheduler="ddim")
+        assert len(a) == len(b) == T and all(np.array_equal(x, y) for x, y in zip(a, b))
+        # a tensor of the wrong shape: refused before anything is uploaded, named
+        sd = dict(rec.components["vae"])
+        sd["decoder.conv_out.bias"] = torch.zeros(7)
+        save_file({k: v.contiguous() for k, v in sd.items()}, paths["vae"])
+        diffuerase.configure(run, weights=root)
+        with pytest.raises(ValueError, match="decoder.conv_out.bias"):
+            diffuerase.run_infill_on_frames(frames, masks, propainer_frames=prior, max_img_size=64)
+    finally:
+        diffuerase.configure(None)
+
+
+def test_cli_main_on_the_hip_path(gpu, tmp_path, monkeypatch):
+    """reference diffuerase.py:121-155 end to end on the GPU: FFV1 / Matroska files in (reference tools.py:4-28) -> main() -> run_infill_on_frames
+    on the HIP kernels (tiny width, the reference's own 2-step TCD default, prior computed by the RAFT propagation) -> FFV1 / Matroska out
+    (tools.py:30-45); the decoded output equals a direct run_infill_on_frames call on the same frames."""
+    import sys
+    import diffuerase
+    from videovanish_amd import frameio as FIO
+    T, H, W = 4, 64, 96
+    frames, masks, _ = _clip(T, H, W, seed=8)
+    color, mask = str(tmp_path / "color.mkv"), str(tmp_path / "mask.mkv")
+    FIO.write_video_frames_to_path(color, frames, 24.0, H, W)
+    FIO.write_video_frames_to_path(mask, masks, 24.0, H, W)
+    run = RunConfig(steps=2, chunk=4, overlap=2, seed=4, dtype="fp16", unet=TINY_UNET, vae=TINY_VAE)
+    monkeypatch.delitem(sys.modules, "tools", raising=False)
+    try:
+        diffuerase.configure(run)
+        monkeypatch.setattr(sys, "argv", ["diffuerase.py", "--color_video", color, "--mask_video", mask])
+        diffuerase.main()
+        out, fps = FIO.load_video_frames_from_path(color + "_vanished.mkv")
+        assert abs(fps - 24.0) < 1e-3 and len(out) == T and all(o.shape == (H, W, 3) and o.dtype == np.uint8 for o in out)
+        diffuerase.configure(run)
+        ref = diffuerase.run_infill_on_frames(frames, masks)                 # every other argument at its default, as main() calls it (:150)
+        assert all(np.array_equal(o, r) for o, r in zip(out, ref))
+        inside = np.stack([m[..., 0] for m in masks]) > 0
+        assert (np.stack(out)[inside] != np.stack(frames)[inside]).mean() > 0.5          # the hole was repainted
+        # --start_frame / --max_frames (reference :127-128): frames 1..2 only
+        monkeypatch.setattr(sys, "argv", ["diffuerase.py", "--color_video", color, "--mask_video", mask, "--start_frame", "1", "--max_frames", "2",
+                                          "--out", str(tmp_path / "part.mkv")])
+        diffuerase.configure(run)
+        diffuerase.main()
+        part, _ = FIO.load_video_frames_from_path(str(tmp_path / "part.mkv"))
+        assert len(part) == 2
+    finally:
+        diffuerase.configure(None)

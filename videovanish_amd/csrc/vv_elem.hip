@@ -209,6 +209,51 @@ extern "C" int vv_split_f32(const float* x, int64_t n, float lo_scale, void* hi,
     return VV_OK;
 }
 
+// split precision, K-concatenated form: out[row] = [ hi | (x - hi) * 2^4 | hi * 2^-10 ] (three C-channel groups, h16): against weights packed as
+// [ wh | wh * 2^-4 | (w - wh) * 2^10 ] ONE GEMM over 3 C input channels accumulates hi*wh + lo*wh + hi*wl in its fp32 accumulator (the power-of-two
+// scales only keep the small parts out of the fp16 subnormal range).  x: fp32 or h16 (h16 is its own hi: the lo group is zero).
+template <typename T, typename IN>
+__global__ void split3_kernel(const IN* x, int64_t rows, int C, unsigned short* out) {
+    const int c4 = C / 4;
+    const int64_t n4 = rows * c4;
+    for (int64_t i = blockIdx.x * (int64_t)EB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EB) {
+        const int64_t row = i / c4;
+        const int c = (int)(i - row * c4) * 4;
+        float a[4];
+        if constexpr (sizeof(IN) == 4) { const float4 v = *(const float4*)(x + row * C + c); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
+        else { const uint2 v = *(const uint2*)(x + row * C + c); a[0] = T::to_f32(v.x & 0xffff); a[1] = T::to_f32(v.x >> 16); a[2] = T::to_f32(v.y & 0xffff); a[3] = T::to_f32(v.y >> 16); }
+        unsigned short h[4], l[4], g[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = T::from_f32(a[e]);
+            const float hf = T::to_f32(h[e]);
+            l[e] = T::from_f32((a[e] - hf) * 16.0f);
+            g[e] = T::from_f32(hf * 0.0009765625f);
+        }
+        unsigned short* o = out + row * 3 * C + c;
+        *(uint2*)o = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+        *(uint2*)(o + C) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+        *(uint2*)(o + 2 * C) = make_uint2(g[0] | ((unsigned)g[1] << 16), g[2] | ((unsigned)g[3] << 16));
+    }
+}
+
+extern "C" int vv_split3(const void* x, int x_dtype, int64_t rows, int C, void* out, int dtype, void* stream) {
+    if (!x || !out || rows <= 0 || C <= 0 || (C & 3)) VV_FAIL(VV_E_ARG, "vv_split3: bad args (C must be a positive multiple of 4)");
+    if (dtype != VV_BF16 && dtype != VV_F16) VV_FAIL(VV_E_ARG, "vv_split3: bad dtype");
+    if (x_dtype != VV_F32 && x_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_split3: input must be fp32 or the operand dtype");
+    const auto g = grid_for(rows * (C / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VV_BF16) {
+        if (x_dtype == VV_F32) hipLaunchKernelGGL((split3_kernel<BF16, float>), g, dim3(EB), 0, st, (const float*)x, rows, C, (unsigned short*)out);
+        else hipLaunchKernelGGL((split3_kernel<BF16, unsigned short>), g, dim3(EB), 0, st, (const unsigned short*)x, rows, C, (unsigned short*)out);
+    } else {
+        if (x_dtype == VV_F32) hipLaunchKernelGGL((split3_kernel<F16, float>), g, dim3(EB), 0, st, (const float*)x, rows, C, (unsigned short*)out);
+        else hipLaunchKernelGGL((split3_kernel<F16, unsigned short>), g, dim3(EB), 0, st, (const unsigned short*)x, rows, C, (unsigned short*)out);
+    }
+    VV_CHECK_LAUNCH("vv_split3");
+    return VV_OK;
+}
+
 extern "C" int vv_pad_channels(const float* x, int64_t rows, int cin, int cpad, float scale, void* out, int dtype, void* stream) {
     if (!x || !out || rows <= 0 || cin <= 0 || cpad < cin) VV_FAIL(VV_E_ARG, "vv_pad_channels: bad args");
     const int64_t n = rows * cpad;

@@ -12,10 +12,10 @@ from .raft import ITERS, RAFT
 _cache = {}
 
 
-def _model(device, dtype, weight_seed):
-    key = (str(device) if device is not None else "cuda:%d" % torch.cuda.current_device(), dtype, weight_seed)
+def _model(device, dtype, weight_seed, weights=None):
+    key = (str(device) if device is not None else "cuda:%d" % torch.cuda.current_device(), dtype, weight_seed, id(weights) if weights is not None else None)
     if key not in _cache:
-        ctx = Ctx(normalize_device(device), dtype, weight_seed)
+        ctx = Ctx(normalize_device(device), dtype, weight_seed, weights=weights)
         _cache[key] = (ctx, RAFT(ctx))
     return _cache[key]
 
@@ -96,13 +96,13 @@ def _generator(ctx):
 
 
 def flow_propagation_prior(frames, masks, device=None, progress=None, dtype="fp16", weight_seed=0, iters=ITERS, subvideo_length=0,
-                           flow_completion=False, generator=False, ref_stride=10, neighbor_length=10):
+                           flow_completion=False, generator=False, ref_stride=10, neighbor_length=10, weights=None):
     """list of (H0,W0,3) u8 + list of (H0,W0) u8 masks -> list of (H0,W0,3) u8 prior frames.
     subvideo_length > 0: the propagation runs per sub-video as the reference's ProPainter call asks (diffuerase.py:55).
     flow_completion: complete the RAFT flows inside the holes with the recurrent flow-completion network first (flowcomplete.py).
     generator: run ProPainter's inpainting generator (inpaintgen.py) over the propagated frames in sliding windows of `neighbor_length`
     frames with every `ref_stride`-th frame as reference (the last stage of the real ProPainter)."""
-    ctx, raft = _model(device, dtype, weight_seed)
+    ctx, raft = _model(device, dtype, weight_seed, weights)
     dev = ctx.device
     H0, W0 = frames[0].shape[:2]
     H, W = max(64, H0 // 8 * 8), max(64, W0 // 8 * 8)

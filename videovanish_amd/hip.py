@@ -11,7 +11,7 @@ import torch
 BF16, F16, F32, U8 = 0, 1, 2, 3
 EPI_NONE, EPI_GEGLU = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 6
+ABI_VERSION = 7
 _DT = {"bf16": BF16, "fp16": F16}
 _TORCH_H16 = {BF16: torch.bfloat16, F16: torch.float16}
 
@@ -90,7 +90,7 @@ EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name
            "vv_avgpool2_f32", "vv_corr_lookup", "vv_raft_ctx_split", "vv_raft_flow_prep", "vv_gru_rh", "vv_gru_update", "vv_add_flow",
            "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_deform_im2col", "vv_fc_input", "vv_upsample2x_bilinear", "vv_flow_combine", "vv_gather_rows", "vv_fold_patches", "vv_flow_down4", "vv_gen_compose", "vv_gen_input", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32", "vv_u8_is_zero",
            "vv_raft_prep", "vv_split_f32", "vv_pad_channels_f32", "vv_window_average",
-           "vv_groupnorm_stats", "vv_gn_affine", "vv_motion_module_c320"]
+           "vv_groupnorm_stats", "vv_gn_affine", "vv_motion_module_c320", "vv_split3"]
 
 
 def lib():
@@ -496,6 +496,17 @@ def split_f32(dtype, x, lo_scale):
     lo = torch.empty(x.shape, dtype=h16(dtype), device=x.device)
     _check(lib().vv_split_f32(_p(x), C.c_int64(x.numel()), C.c_float(lo_scale), _p(hi), _p(lo), dtype, _stream()), "vv_split_f32")
     return hi, lo
+
+
+def split3(dtype, x):
+    """[M, C] fp32 (or h16) -> [M, 3C] h16 = [hi | (x - hi) * 2^4 | hi * 2^-10]: the A operand of a K-concatenated split-precision GEMM (vv_split3)."""
+    _need_cuda(x)
+    assert x.dim() == 2 and x.is_contiguous()
+    M, Cc = x.shape
+    out = torch.empty((M, 3 * Cc), dtype=h16(dtype), device=x.device)
+    with _Prof("split3", 0.0, x.numel() * (x.element_size() + 6)):
+        _check(lib().vv_split3(_p(x), dt_of(x), C.c_int64(M), Cc, _p(out), dtype, _stream()), "vv_split3")
+    return out
 
 
 def decode_blend(dec, w, acc):

@@ -44,32 +44,20 @@ class Ctx:
 
 
 # ---- split precision ("precise" layers: the VAE decoder, RunConfig.precise_decoder) --------------------------------------
-# A 16-bit operand keeps 11 (fp16) / 8 (bf16) significant bits; x = hi + lo / LO_SCALE and w = wh + wl / W_SCALE keep ~2x that.
-# x*w ~= hi*wh + (lo*wh) / LO_SCALE + (hi*wl) / W_SCALE: three launches of the SAME MFMA kernel, accumulated in fp32 through
-# the epilogue (out_scale, res0); the dropped lo*wl term is ~2^-22 relative.  The power-of-two scales keep lo / wl out of the
-# fp16 subnormal range.  Cost: 3x the layer's FLOPs -- used only where the emulation (tools/parity_emulate.py) shows the error
-# budget is spent: the VAE decoder (its rounding errors go straight to the pixels).
-LO_SCALE = 256.0
-W_SCALE = 1024.0
+# A 16-bit operand keeps 11 (fp16) / 8 (bf16) significant bits; x = hi + lo and w = wh + wl keep ~2x that, and
+# x*w ~= hi*wh + lo*wh + hi*wl (the dropped lo*wl term is ~2^-22 relative).  Since round 3 the three products are ONE launch of the MFMA kernel
+# over a K-concatenated operand pair (3x the input channels): activations [hi | lo * 2^4 | hi * 2^-10] (hip.split3) against weights
+# [wh | wh * 2^-4 | wl * 2^10], all three accumulated in the same fp32 accumulator and finished by one epilogue -- round 2 ran three launches
+# that read-modify-wrote the fp32 output twice.  The power-of-two scales keep the small parts out of the fp16 subnormal range.
+# Cost: 3x the layer's FLOPs -- used only where the emulation (tools/parity_emulate.py) shows the error budget is spent: the VAE decoder
+# (its rounding errors go straight to the pixels).
+LO_UP, LO_DOWN, WL_UP = 16.0, 1.0 / 16.0, 1024.0
 
 
-def _precise_gemm(ctx, launch, x0, x1, w_hi, w_lo, bias, res0, res1, scale, out):
-    """launch(x0, x1, weight, bias, res0, res1, out_scale, out) runs one vv_conv_gemm with the layer's geometry (fp32 `out`)."""
-    def halves(x):
-        if x is None:
-            return None, None
-        if x.dtype == torch.float32:
-            return hip.split_f32(ctx.dt, x, LO_SCALE)
-        return x, None                      # already h16: exactly representable, no lo part
-    h0, l0 = halves(x0)
-    h1, l1 = halves(x1)
-    y = launch(h0, h1, w_hi, bias, res0, res1, scale, out)
-    if l0 is not None or l1 is not None:
-        if x1 is not None and (l0 is None or l1 is None):
-            raise RuntimeError("precise conv: both concat sources must be fp32 (or both h16)")
-        launch(l0, l1, w_hi, None, y, None, scale / LO_SCALE, y)
-    launch(h0, h1, w_lo, None, y, None, scale / W_SCALE, y)
-    return y
+def split3_weight(w, h16, cdim=1):
+    """fp32 weight -> the K-concatenated split-precision weight: [wh | wh * 2^-4 | (w - wh) * 2^10] along the input-channel dimension."""
+    wh = w.to(h16).float()
+    return torch.cat([wh, wh * LO_DOWN, (w.float() - wh) * WL_UP], cdim)
 
 
 class Conv:
@@ -87,11 +75,13 @@ class Conv:
         if geglu:
             w2, bias_t = packing.geglu_interleave(weight.reshape(weight.shape[0], -1), bias_t)
             wp, self.K = packing.pack_matrix(w2, ctx.h16, geglu=True), w2.shape[1]
+        elif precise:
+            cp = weight.shape[1] if cin_pad is None else cin_pad            # pad the input channels first: the three groups are cp channels each
+            wpad = torch.zeros((weight.shape[0], cp) + tuple(weight.shape[2:]), dtype=torch.float32)
+            wpad[:, :weight.shape[1]] = weight.float()
+            wp, self.K = packing.pack_conv(split3_weight(wpad, ctx.h16), ctx.h16)
         else:
             wp, self.K = packing.pack_conv(weight, ctx.h16, cin_pad)
-            if precise:
-                wl = (weight.float() - weight.to(ctx.h16).float()) * W_SCALE
-                self.w_lo = ctx.dev(packing.pack_conv(wl, ctx.h16, cin_pad)[0])
         if precise and geglu:
             raise RuntimeError("precise GEGLU layers are not supported")
         self.geglu = geglu
@@ -109,12 +99,12 @@ class Conv:
             Wout = (Wv + 2 * pad - k) // stride + 1
         b = bias_override if bias_override is not None else (self.b if bias else None)
         if self.precise:
-            if rowvec is not None or out_dtype != torch.float32:
-                raise RuntimeError("precise conv: fp32 output, no rowvec")
-            def launch(a0, a1, w, bb, r0, r1, sc, o):
-                return hip.conv_gemm(self.ctx.dt, a0, w, self.cout, self.K, x1=a1, F=F, Hin=H, Win=W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout, ksize=k,
-                                     stride=stride, pad_t=pad, pad_l=pad, bias=bb, res0=r0, res1=r1, out=o, out_dtype=torch.float32, out_scale=sc)
-            return _precise_gemm(self.ctx, launch, x0, x1, self.w, self.w_lo, b, res0, res1, scale, out), Hout, Wout
+            if rowvec is not None or out_dtype != torch.float32 or x1 is not None:
+                raise RuntimeError("precise conv: one source, fp32 output, no rowvec")
+            x3 = hip.split3(self.ctx.dt, x0)                      # [M, 3 C]: hi | lo | hi' -- the three products become ONE launch over 3 C channels
+            return hip.conv_gemm(self.ctx.dt, x3, self.w, self.cout, self.K, F=F, Hin=H, Win=W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout, ksize=k,
+                                 stride=stride, pad_t=pad, pad_l=pad, bias=b, res0=res0, res1=res1, out=out, out_dtype=torch.float32,
+                                 out_scale=scale), Hout, Wout
         return hip.conv_gemm(self.ctx.dt, x0, self.w, self.cout, self.K, x1=x1, F=F, Hin=H, Win=W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout,
                              ksize=k, stride=stride, pad_t=pad, pad_l=pad, bias=b, rowvec=rowvec, res0=res0, res1=res1, out=out,
                              out_dtype=out_dtype, epilogue=hip.EPI_GEGLU if self.geglu else hip.EPI_NONE, out_scale=scale), Hout, Wout
@@ -132,12 +122,12 @@ class Linear:
         self.precise = precise
         if geglu:
             weight, bias_t = packing.geglu_interleave(weight, bias_t)
-        self.K = weight.shape[1]
-        self.w = ctx.dev(packing.pack_matrix(weight, ctx.h16, geglu=geglu))
         if precise:
             if geglu:
                 raise RuntimeError("precise GEGLU layers are not supported")
-            self.w_lo = ctx.dev(packing.pack_matrix((weight.float() - weight.to(ctx.h16).float()) * W_SCALE, ctx.h16))
+            weight = split3_weight(weight, ctx.h16)
+        self.K = weight.shape[1]
+        self.w = ctx.dev(packing.pack_matrix(weight, ctx.h16, geglu=geglu))
         self.b = ctx.dev(bias_t.float()) if bias_t is not None else None
 
     def __call__(self, x, res0=None, res1=None, out_dtype=torch.float32, rows_per_frame=None, out=None, split=None):
@@ -147,10 +137,7 @@ class Linear:
         if self.precise:
             if split or out_dtype != torch.float32:
                 raise RuntimeError("precise linear: fp32 row-major output only")
-            def launch(a0, a1, w, bb, r0, r1, sc, o):
-                return hip.conv_gemm(self.ctx.dt, a0, w, self.cout, self.K, F=1, Hin=M, Win=1, bias=bb, res0=r0, res1=r1, out=o,
-                                     out_dtype=torch.float32, out_scale=sc)
-            return _precise_gemm(self.ctx, launch, x, None, self.w, self.w_lo, self.b, res0, res1, 1.0, out)
+            x = hip.split3(self.ctx.dt, x)
         return hip.conv_gemm(self.ctx.dt, x, self.w, self.cout, self.K, F=1, Hin=M, Win=1, bias=self.b, res0=res0, res1=res1,
                              out_dtype=out_dtype, out=out, epilogue=hip.EPI_GEGLU if self.geglu else hip.EPI_NONE, **kw)
 

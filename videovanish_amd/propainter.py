@@ -12,14 +12,16 @@ def get_device():
 class Propainter:
     """Flow-guided propagation prior (RAFT correlation + bilinear warp)."""
 
-    def __init__(self, model_dir="ruffy369/propainter", device=None, flow_completion=False, generator=False):
+    def __init__(self, model_dir="ruffy369/propainter", device=None, flow_completion=False, generator=False, weights=None):
         # flow_completion: run the recurrent flow-completion network (flowcomplete.py) between RAFT and the propagation, as the real
         # ProPainter does.  Off by default: the network's trained weights (ruffy369/propainter, reference diffuerase.py:49) are not
         # reachable from the build image and seeded random weights would replace the measured flow inside the holes by noise.
         # generator: run the inpainting generator (inpaintgen.py) over the propagated frames -- the last stage of the real ProPainter; off by
         # default for the same reason.  With both switches on, `forward` runs the complete ProPainter pipeline: RAFT -> flow completion ->
         # image propagation -> generator.
-        self.model_dir, self.device, self.flow_completion, self.generator = model_dir, device, flow_completion, generator
+        # weights: a checkpoint.CheckpointWeights with the components "raft" (+ "fc", "gen") -- diffuerase.configure(weights=...) resolves the
+        # reference's model id to local files (modelhub.py); None = seeded random init
+        self.model_dir, self.device, self.flow_completion, self.generator, self.weights = model_dir, device, flow_completion, generator, weights
 
     def forward(self, frames, masks, ref_stride=10, neighbor_length=10, subvideo_length=50, mask_dilation=0, progress=None):
         """Same signature as the third-party call (reference diffuerase.py:52-57).  Built: RAFT flows (both directions) + flow-guided
@@ -39,4 +41,4 @@ class Propainter:
             masks = list(hip.mask_collapse_dilate(m.contiguous(), int(mask_dilation)).cpu().numpy())
         return flow_propagation_prior(frames, masks, device=self.device, progress=progress, subvideo_length=subvideo_length,
                                       flow_completion=self.flow_completion, generator=self.generator, ref_stride=ref_stride,
-                                      neighbor_length=neighbor_length)
+                                      neighbor_length=neighbor_length, weights=self.weights)

@@ -27,7 +27,7 @@ class _Mid:
 
 class VAE:
     def __init__(self, ctx, cfg, precise_decoder=False):
-        """precise_decoder: every decoder GEMM runs as three split-precision passes (nn._precise_gemm): the decoder's operand
+        """precise_decoder: every decoder GEMM runs in split precision (three products in one K-concatenated launch, nn.split3_weight): the decoder's operand
         rounding goes straight to the pixels and is the largest single term of the end-to-end error (profiles/r2_parity_*)."""
         self.ctx, self.cfg = ctx, cfg
         pd = self.precise = bool(precise_decoder)
