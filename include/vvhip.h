@@ -29,7 +29,8 @@ extern "C" {
 
 #define VV_ABI_VERSION 7
 
-enum { VV_BF16 = 0, VV_F16 = 1, VV_F32 = 2, VV_U8 = 3 };
+enum { VV_BF16 = 0, VV_F16 = 1, VV_F32 = 2, VV_U8 = 3,
+       VV_SPLIT3 = 16 /* vv_groupnorm out_dtype only: the K-concatenated split-precision operand [rows][3C] of vv_split3, in the operand dtype */ };
 enum { VV_OK = 0, VV_E_ARG = -1, VV_E_UNSUPPORTED = -2, VV_E_LAUNCH = -3 };
 enum { VV_EPI_NONE = 0, VV_EPI_GEGLU = 1 };
 enum { VV_ACT_NONE = 0, VV_ACT_SILU = 1, VV_ACT_RELU = 2, VV_ACT_LRELU = 3 /* x > 0 ? x : act_slope * x */ };
@@ -138,6 +139,24 @@ typedef struct {
     int32_t n_slabs, n_params;
 } vv_motion_params;
 int vv_motion_module_c320(const vv_motion_params* host_p, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused tail of a spatial Transformer2D block at C = 320, 8 heads, 77 text tokens (the level-0 blocks of the UNet and of BrushNet):
+ *   t = t_in + Wo1 o + bo1;  t += Wo2 CrossAttn(LN2(t), text K/V) + bo2;  t += FF(LN3(t));  out = x [+ res1] + Wout t + bout
+ * (diffusers BasicTransformerBlock after its self-attention core + Transformer2DModel.proj_out) in ONE kernel per 128 tokens:
+ * replaces 9 launches of vv_conv_gemm / vv_layernorm / vv_attention and their intermediates in HBM.  o: h16 [M][320] (the self-attention core's
+ * output), t_in: fp32 [M][320] (proj_in output = the block's residual stream), x: fp32 [M][320] (the Transformer2D input), res1: optional fp32.
+ * stream / params: packing.pack_chain_stream (462 slabs of [64][64] h16 incl. the per-head text K and V^T; 5120 floats).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* o; const float* t_in; const float* x; const float* res1;
+    void* out; int32_t out_dtype;
+    const void* stream; const float* params;
+    int64_t M;
+    int32_t C, heads, text_len;
+    int32_t n_slabs, n_params;
+} vv_chain_params;
+int vv_spatial_chain_c320(const vv_chain_params* host_p, int dtype, void* stream);
 
 /* LayerNorm over the last dim of a [M][C] fp32 matrix, eps 1e-5; out = LN(x)*gamma+beta (+ pe[(m / rows_per_frame)][c]). */
 int vv_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, const float* pe,

@@ -1,0 +1,48 @@
+"""The fused tail of a level-0 spatial transformer block (csrc/vv_chain.hip: attn1 output projection, cross-attention to the 77 text tokens,
+GEGLU feed-forward, proj_out, all residuals in one kernel at C = 320) against the fp32 oracle (oracle/model_ref.py::spatial_transformer) and
+against the layer-by-layer HIP path on the same weights."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from videovanish_amd.config import UNetConfig
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / b.abs().max()).item()
+
+
+@pytest.mark.parametrize("dname,tol", [("fp16", 3e-3), ("bf16", 2.5e-2)])
+@pytest.mark.parametrize("Fr,H,W", [(2, 8, 8), (3, 6, 7), (1, 16, 24)])          # 128 tokens (one full block), 126 (ragged), 384
+def test_fused_spatial_chain_vs_oracle_and_unfused(gpu, dname, tol, Fr, H, W):
+    from oracle import model_ref as M
+    from videovanish_amd import nn as vnn
+    cfg = UNetConfig()
+    C = 320
+    name = "unet.down_blocks.0.attentions.0"
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(Fr, C, H, W, generator=g) * 1.3 + 0.1
+    P = M.Params(0)
+    text = M.text_states(P, cfg)
+    with torch.no_grad():
+        ref = M.spatial_transformer(P, name, x, text, cfg)
+    ctx = vnn.Ctx("cuda:0", dname, 0)
+    mod = vnn.SpatialTransformer(ctx, name, C, cfg, ctx.dev(text[0], ctx.h16))
+    assert mod.fused is not None and mod.fused[0].shape == (462, 64, 64) and mod.fused[1].numel() == 5120
+    nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(Fr * H * W, C).contiguous().to(gpu)
+    back = lambda t: t.float().cpu().reshape(Fr, H, W, C).permute(0, 3, 1, 2)
+    xin = nhwc(x)
+    vnn.SpatialTransformer.FUSED = True
+    fused = back(mod(xin, Fr, H, W))
+    vnn.SpatialTransformer.FUSED = False
+    try:
+        plain = back(mod(xin, Fr, H, W))
+    finally:
+        vnn.SpatialTransformer.FUSED = True
+    e_f, e_p, e_fp = _rel(fused, ref), _rel(plain, ref), _rel(fused, plain)
+    print(f"spatial transformer [{dname}, {Fr}x{H}x{W}]: fused vs oracle {e_f:.2e}, layer-by-layer vs oracle {e_p:.2e}, fused vs layer-by-layer {e_fp:.2e}")
+    assert torch.isfinite(fused).all()
+    assert e_f <= tol and e_f <= 2.0 * e_p + 1e-4
+    out16 = mod(xin, Fr, H, W, out_dtype=ctx.h16)
+    assert out16.dtype == ctx.h16 and _rel(back(out16), fused) <= (2e-3 if dname == "fp16" else 1.6e-2)

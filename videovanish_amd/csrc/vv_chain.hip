@@ -1,0 +1,325 @@
+// Fused tail of a spatial Transformer2D block at C = 320 (the level-0 blocks of the UNet and of BrushNet: 14 per denoise step): everything after
+// the self-attention core is per TOKEN, so it runs as ONE kernel with the token's row in registers -- the design of vv_motion.hip:
+//   t   = t_in + Wo1 o + bo1                              (attn1 output projection + residual; o = the attention core's h16 output)
+//   t  += Wo2 CrossAttn(LN2(t), text K/V) + bo2           (attn2: 77 constant text keys per head; K_h and V_h^T are part of the weight stream)
+//   t  += W2 GEGLU(W1 LN3(t) + b1) + b2                   (feed-forward)
+//   out = x + [res1 +] Wout t + bout                      (proj_out + the block's residual)
+// The unfused path (nn.SpatialTransformer) runs these as 9 launches around 8 fp32 / h16 [M, 320 .. 2560] intermediates in HBM: at K = 320 every one of
+// those GEMMs is bandwidth bound (AI 53-64 FLOP/B with the fp32 trunk read and written around each layer).
+// One wave owns 32 consecutive tokens end to end (fp32 trunk in 160 registers, h16 activations in 80 as MFMA B fragments); a block = 4 waves = 128
+// tokens shares the weight stream: 462 pre-swizzled [64 x 64] h16 slabs (packing.pack_chain_stream) through the 10-slot LDS ring by LDS-DMA.
+// Fragment conventions, PERM32 and the ring protocol: vv_motion.hip.
+#include <type_traits>
+#include "vv_common.h"
+
+namespace {
+
+constexpr int CC = 320, CH = 8, CD = 40, NKEY = 77;
+constexpr int NSLOT = 10, AHEAD = 6, SLAB = 8192;
+// fp32 parameter block (floats): offsets
+constexpr int Q_BO1 = 0, Q_LN2G = 320, Q_LN2B = 640, Q_BO2 = 960, Q_LN3G = 1280, Q_LN3B = 1600, Q_B1 = 1920, Q_B2 = 4480, Q_BOUT = 4800, Q_TOTAL = 5120;
+constexpr int N_SLABS = 25 + CH * (5 + 2 + 2 + 5) + 20 * 15 + 25;      // 462
+
+__device__ __forceinline__ void glds16_asm(const void* gptr, void* lds_wave_base) {
+    typedef void __attribute__((address_space(3))) * lp_t;
+    const unsigned dst = (unsigned)(size_t)(lp_t)lds_wave_base;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gptr), "s"(dst) : "memory");
+}
+
+// two GELUs at once on packed fp32 math (exact erf GELU through Abramowitz-Stegun 7.1.26; see vv_motion.hip)
+__device__ __forceinline__ vv_f32x2 gelu2(vv_f32x2 x) {
+    const vv_f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    const vv_f32x2 z = ax * 0.70710678118654752f;
+    const vv_f32x2 d = __builtin_elementwise_fma(z, (vv_f32x2){0.3275911f, 0.3275911f}, (vv_f32x2){1.0f, 1.0f});
+    const vv_f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    vv_f32x2 q = __builtin_elementwise_fma(t, (vv_f32x2){1.061405429f, 1.061405429f}, (vv_f32x2){-1.453152027f, -1.453152027f});
+    q = __builtin_elementwise_fma(q, t, (vv_f32x2){1.421413741f, 1.421413741f});
+    q = __builtin_elementwise_fma(q, t, (vv_f32x2){-0.284496736f, -0.284496736f});
+    q = __builtin_elementwise_fma(q, t, (vv_f32x2){0.254829592f, 0.254829592f});
+    q = q * t;
+    const vv_f32x2 ez = z * z * -1.4426950408889634f;
+    const vv_f32x2 e = {__builtin_amdgcn_exp2f(ez.x), __builtin_amdgcn_exp2f(ez.y)};
+    const vv_f32x2 erfc = q * e;
+    return __builtin_elementwise_fma(ax * 0.5f, (vv_f32x2){1.0f, 1.0f} - erfc, x * 0.5f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_params p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[NSLOT * SLAB];
+    __shared__ __attribute__((aligned(16))) float prm[Q_TOTAL];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+
+    for (int i = tid * 4; i < Q_TOTAL; i += 256 * 4) *(float4*)(prm + i) = *(const float4*)(p.params + i);
+    // ---- weight stream: slab s at p.stream + s * SLAB; each wave copies 2 KB of every slab
+    const unsigned char* sbase = (const unsigned char*)p.stream + (wave * 2) * 1024 + lane * 16;
+    int issued = 0, consumed = 0;
+    auto issue = [&]() {
+        unsigned char* dst = ring + (issued % NSLOT) * SLAB + (wave * 2) * 1024;
+        const unsigned char* src = sbase + (int64_t)issued * SLAB;
+        glds16_asm(src, dst);
+        glds16_asm(src + 1024, dst + 1024);
+        ++issued;
+    };
+    auto next_slab = [&]() -> const unsigned char* {          // slabs are synchronised in PAIRS (vv_motion.hip)
+        if ((consumed & 1) == 0) {
+            if (issued < N_SLABS) { issue(); issue(); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const unsigned char* s = ring + (consumed % NSLOT) * SLAB;
+        ++consumed;
+        return s;
+    };
+
+    // ---- inputs: a = o (h16, fragments in PERM32 k order), t = t_in (fp32 trunk).  Rows past M repeat row M - 1 (never stored)
+    uint4 a[10][2];
+    f32x4 t[20][2];
+    {
+        __syncthreads();       // parameter block visible
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            int64_t row = row0 + tt * 16 + li;
+            if (row >= p.M) row = p.M - 1;
+            const unsigned short* orow = (const unsigned short*)p.o + row * CC;
+            const float* trow = p.t_in + row * CC;
+#pragma unroll
+            for (int s = 0; s < 10; ++s) {
+                const uint2 lo = *(const uint2*)(orow + 32 * s + 4 * lg), hi = *(const uint2*)(orow + 32 * s + 16 + 4 * lg);
+                a[s][tt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+#pragma unroll
+            for (int j = 0; j < 20; ++j) {
+                const float4 v = *(const float4*)(trow + 16 * j + 4 * lg);
+                t[j][tt] = f32x4{v.x, v.y, v.z, v.w};
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+        for (int i = 0; i < AHEAD; ++i) issue();
+    }
+
+    // D += W_slab * X^T for RT row tiles and KK k steps of one slab
+    auto slab_mma = [&](const unsigned char* s, auto rt_tag, auto kk_tag, f32x4* acc /* [RT][2] */, const uint4 (&x0)[2], const uint4 (&x1)[2]) {
+        constexpr int RT = decltype(rt_tag)::value, KK = decltype(kk_tag)::value;
+        const int sw = li & 7;
+        uint4 w[2][RT];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int off = ((kk * 4 + lg) ^ sw) << 4;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) w[kk][rt] = *(const uint4*)(s + (rt * 16 + li) * 128 + off);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) acc[rt * 2 + tt] = T::mfma(w[kk][rt], kk ? x1[tt] : x0[tt], acc[rt * 2 + tt]);
+        __builtin_amdgcn_sched_group_barrier(0x100, KK * RT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * KK * RT, 0);
+    };
+    using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    auto dense320 = [&](f32x4 (&acc)[20][2]) {
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb)
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt) {
+                const unsigned char* s = next_slab();
+                slab_mma(s, I4{}, I2{}, &acc[rb * 4][0], a[2 * kt], a[2 * kt + 1]);
+            }
+    };
+    auto frag = [&](const f32x4& lo, const f32x4& hi) -> uint4 {
+        return make_uint4(pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]), pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3]));
+    };
+    auto add_bias = [&](const int off) {
+#pragma unroll
+        for (int j = 0; j < 20; ++j) {
+            const float4 b = *(const float4*)(prm + off + 16 * j + 4 * lg);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) { t[j][tt][0] += b.x; t[j][tt][1] += b.y; t[j][tt][2] += b.z; t[j][tt][3] += b.w; }
+        }
+    };
+    auto layer_norm = [&](const int goff, const int boff) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 20; ++j) s += (t[j][tt][0] + t[j][tt][1]) + (t[j][tt][2] + t[j][tt][3]);
+            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+            const float mean = s * (1.0f / CC);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 20; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = t[j][tt][r] - mean; q += d * d; }
+            q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+            const float rstd = rsqrtf(q * (1.0f / CC) + 1e-5f);
+#pragma unroll
+            for (int s2 = 0; s2 < 10; ++s2) {
+                f32x4 y[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = 2 * s2 + h, c = 16 * j + 4 * lg;
+                    const float4 g = *(const float4*)(prm + goff + c), b = *(const float4*)(prm + boff + c);
+                    y[h][0] = (t[j][tt][0] - mean) * rstd * g.x + b.x; y[h][1] = (t[j][tt][1] - mean) * rstd * g.y + b.y;
+                    y[h][2] = (t[j][tt][2] - mean) * rstd * g.z + b.z; y[h][3] = (t[j][tt][3] - mean) * rstd * g.w + b.w;
+                }
+                a[s2][tt] = frag(y[0], y[1]);
+            }
+        }
+    };
+
+    // ---- attn1 output projection: t = t_in + Wo1 o + bo1
+    dense320(t);
+    add_bias(Q_BO1);
+
+    // ---- attn2: cross-attention to the 77 text keys.  Per head: q (5 slabs) | S^T = K_h q^T (2 slabs: key rows 0..63, 64..79) | softmax |
+    //      O^T = V_h^T P^T (2 slabs: keys 0..63, 64..95) | t += Wo2[:, head] O (5 slabs)
+    layer_norm(Q_LN2G, Q_LN2B);
+    const float sc = 0.15811388300841897f * 1.4426950408889634f;      // 40^-1/2 * log2(e)
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int h = 0; h < CH; ++h) {
+        f32x4 qa[3][2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) qa[i][tt] = z4;
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt) { const unsigned char* s = next_slab(); slab_mma(s, I3{}, I2{}, &qa[0][0], a[2 * kt], a[2 * kt + 1]); }
+        uint4 q0[2], q1[2];                          // [token tile]: k steps 0 (d = PERM32) and 1 (d = 32 + 4 lg + e, e < 4)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) { q0[tt] = frag(qa[0][tt], qa[1][tt]); q1[tt] = frag(qa[2][tt], z4); }
+        f32x4 sT[5][2];                              // [key tile][token tile]: lane = token li, registers = keys 16 kt + 4 lg + r
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) sT[kt][tt] = z4;
+        { const unsigned char* s = next_slab(); slab_mma(s, I4{}, I2{}, &sT[0][0], q0, q1); }
+        { const unsigned char* s = next_slab(); slab_mma(s, I1{}, I2{}, &sT[4][0], q0, q1); }
+        uint4 pf[3][2];                              // [k step of 32 keys][token tile]
+        float inv[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            if (lg == 3) { sT[4][qt][1] = -1e30f; sT[4][qt][2] = -1e30f; sT[4][qt][3] = -1e30f; }      // keys 77, 78, 79 do not exist
+            float m = sT[0][qt][0];
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, sT[kt][qt][r]);
+            m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+            const float mc = m * sc;
+            float l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(sT[kt][qt][r] * sc - mc); sT[kt][qt][r] = e; l += e; }
+            l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+            inv[qt] = 1.0f / l;
+            pf[0][qt] = frag(sT[0][qt], sT[1][qt]); pf[1][qt] = frag(sT[2][qt], sT[3][qt]); pf[2][qt] = frag(sT[4][qt], z4);
+        }
+        f32x4 oT[3][2];                              // [d tile][token tile]
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) oT[i][tt] = z4;
+        { const unsigned char* s = next_slab(); slab_mma(s, I3{}, I2{}, &oT[0][0], pf[0], pf[1]); }
+        { const unsigned char* s = next_slab(); slab_mma(s, I3{}, I1{}, &oT[0][0], pf[2], pf[2]); }
+        uint4 o0[2], o1[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) oT[i][tt] *= inv[tt];
+            o0[tt] = frag(oT[0][tt], oT[1][tt]); o1[tt] = frag(oT[2][tt], z4);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb) { const unsigned char* s = next_slab(); slab_mma(s, I4{}, I2{}, &t[rb * 4][0], o0, o1); }
+    }
+    add_bias(Q_BO2);
+
+    // ---- GEGLU feed-forward, 20 chunks of 64 hidden units: 10 slabs of W1 (value / gate rows interleaved per 16), 5 slabs of W2
+    layer_norm(Q_LN3G, Q_LN3B);
+#pragma unroll 1
+    for (int c = 0; c < 20; ++c) {
+        f32x4 g[8][2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) g[i][tt] = z4;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt) { const unsigned char* s = next_slab(); slab_mma(s, I4{}, I2{}, &g[rb * 4][0], a[2 * kt], a[2 * kt + 1]); }
+        uint4 hf0[2], hf1[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            f32x4 hv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 bv = *(const float4*)(prm + Q_B1 + c * 128 + (2 * i) * 16 + 4 * lg), bg = *(const float4*)(prm + Q_B1 + c * 128 + (2 * i + 1) * 16 + 4 * lg);
+                const vv_f32x2 g01 = gelu2((vv_f32x2){g[2 * i + 1][tt][0] + bg.x, g[2 * i + 1][tt][1] + bg.y});
+                const vv_f32x2 g23 = gelu2((vv_f32x2){g[2 * i + 1][tt][2] + bg.z, g[2 * i + 1][tt][3] + bg.w});
+                hv[i][0] = (g[2 * i][tt][0] + bv.x) * g01.x; hv[i][1] = (g[2 * i][tt][1] + bv.y) * g01.y;
+                hv[i][2] = (g[2 * i][tt][2] + bv.z) * g23.x; hv[i][3] = (g[2 * i][tt][3] + bv.w) * g23.y;
+            }
+            hf0[tt] = frag(hv[0], hv[1]); hf1[tt] = frag(hv[2], hv[3]);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb) { const unsigned char* s = next_slab(); slab_mma(s, I4{}, I2{}, &t[rb * 4][0], hf0, hf1); }
+    }
+    add_bias(Q_B2);
+
+    // ---- proj_out (+ bias + x [+ res1])
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int s2 = 0; s2 < 10; ++s2) a[s2][tt] = frag(t[2 * s2][tt], t[2 * s2 + 1][tt]);
+#pragma unroll
+    for (int j = 0; j < 20; ++j)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) t[j][tt] = z4;
+    dense320(t);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int64_t r = row0 + tt * 16 + li;
+        if (r < p.M) {
+            const int64_t row = r * CC;
+#pragma unroll
+            for (int j = 0; j < 20; ++j) {
+                const int c = 16 * j + 4 * lg;
+                const float4 b = *(const float4*)(prm + Q_BOUT + c);
+                const float4 xr = *(const float4*)(p.x + row + c);
+                float v0 = t[j][tt][0] + b.x + xr.x, v1 = t[j][tt][1] + b.y + xr.y, v2 = t[j][tt][2] + b.z + xr.z, v3 = t[j][tt][3] + b.w + xr.w;
+                if (p.res1) { const float4 r4 = *(const float4*)(p.res1 + row + c); v0 += r4.x; v1 += r4.y; v2 += r4.z; v3 += r4.w; }
+                if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + row + c) = make_float4(v0, v1, v2, v3);
+                else *(uint2*)((unsigned short*)p.out + row + c) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vv_spatial_chain_c320(const vv_chain_params* pp, int dtype, void* stream) {
+    if (!pp) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: null params");
+    const vv_chain_params& p = *pp;
+    if (!p.o || !p.t_in || !p.x || !p.out || !p.stream || !p.params) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: null pointer");
+    if (p.C != CC || p.heads != CH || p.text_len != NKEY) VV_FAIL(VV_E_UNSUPPORTED, "vv_spatial_chain_c320: built for C = 320, 8 heads, 77 text tokens (got %d, %d, %d)", p.C, p.heads, p.text_len);
+    if (p.M <= 0) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: empty input");
+    if (p.out_dtype != VV_F32 && p.out_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: out_dtype mismatch");
+    if (p.n_slabs != N_SLABS || p.n_params != Q_TOTAL) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: stream / parameter block size mismatch (%d slabs, %d floats)", p.n_slabs, p.n_params);
+    const int64_t nblk = (p.M + 127) / 128;
+    if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VV_BF16) hipLaunchKernelGGL(chain_c320_kernel<BF16>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else if (dtype == VV_F16) hipLaunchKernelGGL(chain_c320_kernel<F16>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: bad dtype");
+    VV_CHECK_LAUNCH("vv_spatial_chain_c320");
+    return VV_OK;
+}

@@ -158,6 +158,17 @@ __global__ void gn_apply_kernel(const vv_groupnorm_params p, const GNGeom g) {
         }
         const int64_t o = pix * C + chunk * 8;
         if (p.out_dtype == VV_F32) { float4* d = (float4*)((float*)p.out + o); d[0] = *(float4*)&v[0]; d[1] = *(float4*)&v[4]; }
+        else if (p.out_dtype == VV_SPLIT3) {
+            // K-concatenated split-precision operand (vv_split3): [pix][hi | (y - hi) * 2^4 | hi * 2^-10], three C-channel groups
+            float lo[8], g3[8];
+            const uint4 hi = pack8<T>(v);
+            float hf[8];
+            unpack8<T>(hi, hf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { lo[e] = (v[e] - hf[e]) * 16.0f; g3[e] = hf[e] * 0.0009765625f; }
+            unsigned short* d = (unsigned short*)p.out + pix * 3 * C + chunk * 8;
+            *(uint4*)d = hi; *(uint4*)(d + C) = pack8<T>(lo); *(uint4*)(d + 2 * C) = pack8<T>(g3);
+        }
         else *(uint4*)((unsigned short*)p.out + o) = pack8<T>(v);
     };
     int r = rbeg + r0;
@@ -244,7 +255,7 @@ extern "C" int vv_groupnorm(const vv_groupnorm_params* pp, int dtype, void* stre
     if (p.groups <= 0 || p.groups > 256 || C % p.groups) VV_FAIL(VV_E_ARG, "vv_groupnorm: groups=%d C=%d", p.groups, C);
     if (C / 8 > 1024) VV_FAIL(VV_E_UNSUPPORTED, "vv_groupnorm: C=%d too large", C);
     if (p.in_dtype != VV_F32 && p.in_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_groupnorm: in_dtype mismatch");
-    if (p.out_dtype != VV_F32 && p.out_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_groupnorm: out_dtype mismatch");
+    if (p.out_dtype != VV_F32 && p.out_dtype != dtype && p.out_dtype != VV_SPLIT3) VV_FAIL(VV_E_ARG, "vv_groupnorm: out_dtype mismatch");
     if (p.F <= 0 || p.HW <= 0) VV_FAIL(VV_E_ARG, "vv_groupnorm: empty input");
     return dtype == VV_BF16 ? gn_launch<BF16>(p, (hipStream_t)stream) : gn_launch<F16>(p, (hipStream_t)stream);
 }

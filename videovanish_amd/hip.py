@@ -9,6 +9,7 @@ import os
 import torch
 
 BF16, F16, F32, U8 = 0, 1, 2, 3
+SPLIT3 = 16      # vv_groupnorm out_dtype: the K-concatenated split-precision operand (see split3)
 EPI_NONE, EPI_GEGLU = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_LRELU = 0, 1, 2, 3
 ABI_VERSION = 7
@@ -75,6 +76,12 @@ class MotionParams(C.Structure):
                 ("n_slabs", C.c_int32), ("n_params", C.c_int32)]
 
 
+class ChainParams(C.Structure):
+    _fields_ = [("o", C.c_void_p), ("t_in", C.c_void_p), ("x", C.c_void_p), ("res1", C.c_void_p), ("out", C.c_void_p), ("out_dtype", C.c_int32),
+                ("stream", C.c_void_p), ("params", C.c_void_p), ("M", C.c_int64), ("C", C.c_int32), ("heads", C.c_int32), ("text_len", C.c_int32),
+                ("n_slabs", C.c_int32), ("n_params", C.c_int32)]
+
+
 class AttnParams(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
                 ("q_bs", C.c_int64), ("k_bs", C.c_int64), ("v_bs", C.c_int64), ("o_bs", C.c_int64),
@@ -90,7 +97,7 @@ EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name
            "vv_avgpool2_f32", "vv_corr_lookup", "vv_raft_ctx_split", "vv_raft_flow_prep", "vv_gru_rh", "vv_gru_update", "vv_add_flow",
            "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_deform_im2col", "vv_fc_input", "vv_upsample2x_bilinear", "vv_flow_combine", "vv_gather_rows", "vv_fold_patches", "vv_flow_down4", "vv_gen_compose", "vv_gen_input", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32", "vv_u8_is_zero",
            "vv_raft_prep", "vv_split_f32", "vv_pad_channels_f32", "vv_window_average",
-           "vv_groupnorm_stats", "vv_gn_affine", "vv_motion_module_c320", "vv_split3"]
+           "vv_groupnorm_stats", "vv_gn_affine", "vv_motion_module_c320", "vv_split3", "vv_spatial_chain_c320"]
 
 
 def lib():
@@ -228,11 +235,16 @@ def groupnorm(dtype, x0, gamma, beta, groups, eps, *, x1=None, F, HW, silu=False
     Ctot = C0 + C1
     nsplit = lib().vv_groupnorm_nsplit(HW, Ctot)
     ws = torch.empty(F * (nsplit + 1) * groups * 2, dtype=torch.float32, device=x0.device)
-    out = torch.empty((F * HW, Ctot), dtype=h16(dtype) if out_dtype is None else out_dtype, device=x0.device)
+    if out_dtype == "split3":          # [M, 3C] h16 = [hi | lo * 2^4 | hi * 2^-10]: feeds a split-precision GEMM directly (no fp32 round trip)
+        out = torch.empty((F * HW, 3 * Ctot), dtype=h16(dtype), device=x0.device)
+        odt = SPLIT3
+    else:
+        out = torch.empty((F * HW, Ctot), dtype=h16(dtype) if out_dtype is None else out_dtype, device=x0.device)
+        odt = dt_of(out)
     p = GroupNormParams(in0=x0.data_ptr(), in1=x1.data_ptr() if x1 is not None else 0, in_dtype=dt_of(x0), C0=C0, C1=C1, F=F, HW=HW,
                         groups=groups, pool_frames=int(pool_frames), eps=eps, gamma=gamma.data_ptr(), beta=beta.data_ptr(),
-                        silu=int(act) if act is not None else int(silu), stats_ws=ws.data_ptr(), out=out.data_ptr(), out_dtype=dt_of(out))
-    with _Prof("groupnorm", 0.0, F * HW * Ctot * (2 * x0.element_size() + out.element_size())):
+                        silu=int(act) if act is not None else int(silu), stats_ws=ws.data_ptr(), out=out.data_ptr(), out_dtype=odt)
+    with _Prof("groupnorm", 0.0, F * HW * Ctot * (2 * x0.element_size() + (6 if odt == SPLIT3 else out.element_size()))):
         _check(lib().vv_groupnorm(C.byref(p), dtype, _stream()), "vv_groupnorm")
     return out
 
@@ -496,6 +508,22 @@ def split_f32(dtype, x, lo_scale):
     lo = torch.empty(x.shape, dtype=h16(dtype), device=x.device)
     _check(lib().vv_split_f32(_p(x), C.c_int64(x.numel()), C.c_float(lo_scale), _p(hi), _p(lo), dtype, _stream()), "vv_split_f32")
     return hi, lo
+
+
+def spatial_chain_c320(dtype, o, t_in, x, stream_w, params, *, res1=None, out_dtype=torch.float32):
+    """The fused tail of a level-0 spatial transformer block (vv_chain.hip): attn1 out-proj + residual, cross-attention to the text tokens,
+    GEGLU feed-forward, proj_out + block residual in ONE kernel.  o: h16 [M,320]; t_in, x (, res1): fp32 [M,320]."""
+    _need_cuda(o, t_in, x, stream_w, params, res1)
+    M, Cc = t_in.shape
+    assert o.shape == (M, Cc) and x.shape == (M, Cc) and o.dtype == h16(dtype) and t_in.dtype == x.dtype == torch.float32
+    out = torch.empty((M, Cc), dtype=out_dtype, device=x.device)
+    cp = ChainParams(o=o.data_ptr(), t_in=t_in.data_ptr(), x=x.data_ptr(), res1=res1.data_ptr() if res1 is not None else 0, out=out.data_ptr(),
+                     out_dtype=dt_of(out), stream=stream_w.data_ptr(), params=params.data_ptr(), M=M, C=Cc, heads=8, text_len=77,
+                     n_slabs=stream_w.shape[0], n_params=params.numel())
+    flops = 2.0 * M * Cc * Cc * (1 + 1 + 1 + 12 + 1) + 4.0 * M * 77 * Cc
+    with _Prof("spatial_chain_fused[c320]", flops, M * Cc * (2 + 4 + 4 + out.element_size())):
+        _check(lib().vv_spatial_chain_c320(C.byref(cp), dtype, _stream()), "vv_spatial_chain_c320")
+    return out
 
 
 def split3(dtype, x):

@@ -80,6 +80,7 @@ class Conv:
             wpad = torch.zeros((weight.shape[0], cp) + tuple(weight.shape[2:]), dtype=torch.float32)
             wpad[:, :weight.shape[1]] = weight.float()
             wp, self.K = packing.pack_conv(split3_weight(wpad, ctx.h16), ctx.h16)
+            self.cp = cp
         else:
             wp, self.K = packing.pack_conv(weight, ctx.h16, cin_pad)
         if precise and geglu:
@@ -101,7 +102,8 @@ class Conv:
         if self.precise:
             if rowvec is not None or out_dtype != torch.float32 or x1 is not None:
                 raise RuntimeError("precise conv: one source, fp32 output, no rowvec")
-            x3 = hip.split3(self.ctx.dt, x0)                      # [M, 3 C]: hi | lo | hi' -- the three products become ONE launch over 3 C channels
+            # [M, 3 C]: hi | lo | hi' -- the three products become ONE launch over 3 C channels (a precise GroupNorm emits that form itself)
+            x3 = x0 if (x0.dtype == self.ctx.h16 and x0.shape[1] == 3 * self.cp) else hip.split3(self.ctx.dt, x0)
             return hip.conv_gemm(self.ctx.dt, x3, self.w, self.cout, self.K, F=F, Hin=H, Win=W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout, ksize=k,
                                  stride=stride, pad_t=pad, pad_l=pad, bias=b, res0=res0, res1=res1, out=out, out_dtype=torch.float32,
                                  out_scale=scale), Hout, Wout
@@ -125,6 +127,7 @@ class Linear:
         if precise:
             if geglu:
                 raise RuntimeError("precise GEGLU layers are not supported")
+            self.kin = weight.shape[1]
             weight = split3_weight(weight, ctx.h16)
         self.K = weight.shape[1]
         self.w = ctx.dev(packing.pack_matrix(weight, ctx.h16, geglu=geglu))
@@ -137,7 +140,8 @@ class Linear:
         if self.precise:
             if split or out_dtype != torch.float32:
                 raise RuntimeError("precise linear: fp32 row-major output only")
-            x = hip.split3(self.ctx.dt, x)
+            if not (x.dtype == self.ctx.h16 and x.shape[1] == 3 * self.kin):
+                x = hip.split3(self.ctx.dt, x)
         return hip.conv_gemm(self.ctx.dt, x, self.w, self.cout, self.K, F=1, Hin=M, Win=1, bias=self.b, res0=res0, res1=res1,
                              out_dtype=out_dtype, out=out, epilogue=hip.EPI_GEGLU if self.geglu else hip.EPI_NONE, **kw)
 
@@ -145,7 +149,7 @@ class Linear:
 class GroupNorm:
     def __init__(self, ctx, name, C, groups, eps, precise=False):
         self.ctx, self.groups, self.eps = ctx, groups, eps
-        self.out_dtype = torch.float32 if precise else None      # precise consumers split the fp32 result into hi + lo themselves
+        self.out_dtype = "split3" if precise else None           # precise consumers take the K-concatenated split operand [M, 3C] (hip.split3)
         g, b = ctx.src.norm(name, C)
         self.g, self.b = ctx.dev(g), ctx.dev(b)
 
@@ -222,6 +226,11 @@ class SelfAttention:
             hip.attention(dt, qkv, qkv, qkv, o, B=B, heads=self.heads, Nq=N, Nkv=N, D=D, q_bs=N * 3 * C, k_bs=N * 3 * C, v_bs=N * 3 * C,
                           o_bs=N * C, q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C, k_off=C, v_off=2 * C)
             return self.out(o, res0=res)
+        return self.out(self.core(n, B, N), res0=res)
+
+    def core(self, n, B, N):
+        """the attention core alone: fused QKV projection + softmax(QK^T)V -> h16 [B*N, C] (the output projection is the caller's)."""
+        C, dt, D = self.C, self.ctx.dt, self.C // self.heads
         # head-major QKV ([frame][q|k|v][head][token][D]): a head's K/V rows are contiguous 2*D-byte records, so the K/V tile
         # DMA of the attention kernel reads whole cache lines (the [token][3C] layout over-fetched 2.6x at D = 40)
         qkv = self.qkv(n, out_dtype=self.ctx.h16, split=(self.heads, D, N))
@@ -229,7 +238,7 @@ class SelfAttention:
         hip.attention(dt, qkv, qkv, qkv, o, B=B, heads=self.heads, Nq=N, Nkv=N, D=D, q_bs=N * 3 * C, k_bs=N * 3 * C,
                       v_bs=N * 3 * C, o_bs=N * C, q_rs=D, k_rs=D, v_rs=D, o_rs=C, k_off=N * C, v_off=2 * N * C,
                       q_hs=N * D, k_hs=N * D, v_hs=N * D, q_prescaled=self.prescale_q)
-        return self.out(o, res0=res)
+        return o
 
     def temporal(self, n, res, Fr, HW, res1=None):
         """sequence = frames; rows of the [F*HW, 3C] QKV matrix gathered with stride HW*3C inside the kernel."""
@@ -279,6 +288,11 @@ class FeedForward:
 
 
 class SpatialTransformer:
+    """Transformer2D block.  At C = 320, 8 heads and 77 text tokens (level 0: 14 blocks per denoise step) everything after the self-attention
+    core runs as ONE kernel (csrc/vv_chain.hip: output projection, cross-attention, GEGLU feed-forward, proj_out, all residuals; the token's row
+    stays in registers, weights and the per-head text K / V stream through an LDS ring); other widths run layer by layer."""
+    FUSED = True          # class-level switch (tests / A-B runs compare both paths on the same weights)
+
     def __init__(self, ctx, name, C, cfg, text_h16):
         self.ctx = ctx
         self.norm = GroupNorm(ctx, name + ".norm", C, cfg.groups, 1e-6)
@@ -289,11 +303,30 @@ class SpatialTransformer:
         self.attn2 = CrossAttention(ctx, b + ".attn2", C, cfg.heads, text_h16)
         self.ff = FeedForward(ctx, b + ".ff", C)
         self.proj_out = Conv(ctx, name + ".proj_out", C, C, k=1)
+        self.fused = None
+        if C == 320 and cfg.heads == 8 and text_h16.shape[0] == 77 and torch.device(ctx.device).type != "meta":
+            src, w = ctx.src, {}
+            w["o1.w"], w["o1.b"] = src.linear(b + ".attn1.to_out.0", C, C)
+            w["ln2.g"], w["ln2.b"] = src.norm(b + ".norm2", C)
+            w["q2.w"], _ = src.linear(b + ".attn2.to_q", C, C, 1.0, False)
+            kv = self.attn2.kv.float().cpu()                                  # [77, 2C]: the text tokens projected once at build time (h16 values)
+            w["k2"], w["v2"] = kv[:, :C].contiguous(), kv[:, C:].contiguous()
+            w["o2.w"], w["o2.b"] = src.linear(b + ".attn2.to_out.0", C, C)
+            w["ln3.g"], w["ln3.b"] = src.norm(b + ".norm3", C)
+            w["ff1.w"], w["ff1.b"] = src.linear(b + ".ff.net.0.proj", C, 8 * C)
+            w["ff2.w"], w["ff2.b"] = src.linear(b + ".ff.net.2", 4 * C, C)
+            wo, w["out.b"] = src.conv(name + ".proj_out", C, C, 1)
+            w["out.w"] = wo.reshape(C, C)
+            stream, params = packing.pack_chain_stream(w, ctx.h16, cfg.heads)
+            self.fused = (ctx.dev(stream), ctx.dev(params))
 
     def __call__(self, x, F, H, W, out_dtype=torch.float32):
         HW = H * W
         h = self.norm(x, F, HW)
         t, _, _ = self.proj_in(h, F, H, W)
+        if self.fused is not None and SpatialTransformer.FUSED and x.dtype == torch.float32:
+            o = self.attn1.core(self.n1(t), F, HW)
+            return hip.spatial_chain_c320(self.ctx.dt, o, t, x, self.fused[0], self.fused[1], out_dtype=out_dtype)
         t = self.attn1.spatial(self.n1(t), t, F, HW)
         t = self.attn2(self.n2(t), t, F, HW)
         t = self.ff(self.n3(t), t)

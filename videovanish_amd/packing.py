@@ -120,3 +120,55 @@ def pack_motion_stream(w, h16, heads=8):
                         torch.cat(b1), w["ff2.b"], w["proj_out.b"], w["pe"][:32].reshape(-1)]).float()
     assert stream.shape[0] == 670 and params.numel() == 16320
     return stream.contiguous(), params.contiguous()
+
+
+def _head_k_columns(D):
+    """column order of a per-head [rows, 64] operand whose k dimension is the head dim d (PERM32 for k step 0; k step 1: d = 32 + 4 lg + e for
+    e < 4, zero elsewhere) -- the order in which vv_motion.hip / vv_chain.hip pack three 16-row accumulator tiles of a head into two k steps.
+    Returns (dst columns, src d indices)."""
+    perm = _perm32()
+    p = torch.arange(32)
+    e, lg = p & 7, p >> 3
+    d1 = 32 + 4 * lg + e
+    ok = (e < 4) & (d1 < D)
+    return torch.cat([torch.arange(32), 32 + p[ok]]), torch.cat([perm, d1[ok]])
+
+
+def pack_chain_stream(w, h16, heads=8):
+    """w: dict of fp32 tensors of the tail of one spatial transformer block at C = 320 -- o1.w/.b (attn1.to_out.0), ln2.g/.b, q2.w (attn2.to_q),
+    k2 / v2 ([77, C]: the text tokens already projected by attn2.to_k / to_v), o2.w/.b (attn2.to_out.0), ln3.g/.b, ff1.w/.b ([8C, C]),
+    ff2.w/.b ([C, 4C]), out.w/.b (proj_out).  Returns (stream [462, 64, 64] h16, params [5120] fp32) in the consumption order of vv_chain.hip."""
+    C = w["o1.w"].shape[0]
+    D = C // heads
+    assert C == 320 and D == 40 and w["k2"].shape == (77, C) and w["v2"].shape == (77, C)
+    dst, src = _head_k_columns(D)
+    slabs = _dense_slabs(_permute_k(w["o1.w"]), h16, 64)
+    for h in range(heads):
+        wh = torch.zeros((48, C))
+        wh[:D] = w["q2.w"][h * D:(h + 1) * D]
+        slabs += _dense_slabs(_permute_k(wh), h16, 48)                     # q = Wq[head] a: 5 slabs of 48 rows
+        kh = torch.zeros((128, 64))                                        # K_h: rows = keys (77 -> 80 used), columns = d in the packed order
+        kh[:77, dst] = w["k2"][:, h * D + src]
+        slabs += [_slab(kh[0:64], h16), _slab(kh[64:80], h16)]
+        vt = torch.zeros((48, 128))                                        # V_h^T: rows = d, columns = keys (PERM32 inside every 32-key step)
+        vt[:D, :77] = w["v2"][:, h * D:(h + 1) * D].t()
+        vt = _permute_k(vt)
+        slabs += [_slab(vt[:, 0:64], h16), _slab(vt[:, 64:128], h16)]
+        wo = torch.zeros((C, 64))
+        wo[:, dst] = w["o2.w"][:, h * D + src]
+        slabs += _dense_slabs(wo, h16, 64)
+    inner = 4 * C
+    b1 = []
+    for c in range(inner // 64):
+        rows = []
+        for i in range(4):
+            rows += list(range(64 * c + 16 * i, 64 * c + 16 * i + 16)) + list(range(inner + 64 * c + 16 * i, inner + 64 * c + 16 * i + 16))
+        rows = torch.tensor(rows)
+        slabs += _dense_slabs(_permute_k(w["ff1.w"][rows]), h16, 64)
+        b1.append(w["ff1.b"][rows])
+        slabs += _dense_slabs(_permute_k(w["ff2.w"][:, 64 * c:64 * c + 64]), h16, 64)
+    slabs += _dense_slabs(_permute_k(w["out.w"]), h16, 64)
+    stream = torch.stack(slabs)
+    params = torch.cat([w["o1.b"], w["ln2.g"], w["ln2.b"], w["o2.b"], w["ln3.g"], w["ln3.b"], torch.cat(b1), w["ff2.b"], w["out.b"]]).float()
+    assert stream.shape[0] == 462 and params.numel() == 5120
+    return stream.contiguous(), params.contiguous()
