@@ -65,9 +65,14 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
         glds16_asm(src + 1024, dst + 1024);
         ++issued;
     };
-    auto next_slab = [&]() -> const unsigned char* {          // slabs are synchronised in PAIRS (vv_motion.hip)
-        if ((consumed & 1) == 0) {
-            if (issued < N_SLABS) { issue(); issue(); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+    // next slab of the stream.  Slabs are synchronised in PAIRS (vv_motion.hip): the EVEN slab of a pair issues two more slabs, waits until all but
+    // the newest AHEAD have landed (this wave's share) and joins the barrier; the odd one just advances.  The parity of every slab's stream index is
+    // a compile-time property of the call site (`even_tag`): a run-time test would cut the instruction stream into one basic block per slab
+    // and the fragment reads of slab i+1 could not be scheduled under the MFMAs of slab i.
+    // `tail_tag`: only the last group of the stream (proj_out) can run out of slabs to issue; everywhere else the issue is unconditional (no branch).
+    auto next_slab = [&](auto even_tag, auto tail_tag) -> const unsigned char* {
+        if constexpr (decltype(even_tag)::value) {
+            if (!decltype(tail_tag)::value || issued < N_SLABS) { issue(); issue(); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
@@ -103,36 +108,56 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
         for (int i = 0; i < AHEAD; ++i) issue();
     }
 
-    // D += W_slab * X^T for RT row tiles and KK k steps of one slab
-    auto slab_mma = [&](const unsigned char* s, auto rt_tag, auto kk_tag, f32x4* acc /* [RT][2] */, const uint4 (&x0)[2], const uint4 (&x1)[2]) {
+    // D += W_slab * X^T for RT row tiles and KK k steps of one slab, split into the fragment reads (LDS -> registers) and the MFMAs so that a group
+    // of slabs runs software pipelined: the reads of slab i+1 are in flight under the MFMAs of slab i.  (With ONE wave per SIMD and the four
+    // waves of a block released by the same barrier, reads that are waited for right before their MFMAs leave the matrix pipe idle for the whole
+    // LDS round trip -- 8 KB per wave, all four waves at once -- on every slab.)
+    struct WF { uint4 w[2][4]; };
+    auto slab_load = [&](const unsigned char* s, auto rt_tag, auto kk_tag, WF& f) {
         constexpr int RT = decltype(rt_tag)::value, KK = decltype(kk_tag)::value;
         const int sw = li & 7;
-        uint4 w[2][RT];
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const int off = ((kk * 4 + lg) ^ sw) << 4;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) w[kk][rt] = *(const uint4*)(s + (rt * 16 + li) * 128 + off);
+            for (int rt = 0; rt < RT; ++rt) f.w[kk][rt] = *(const uint4*)(s + (rt * 16 + li) * 128 + off);
         }
+    };
+    auto slab_fma = [&](const WF& f, auto rt_tag, auto kk_tag, f32x4* acc /* [RT][2] */, const uint4 (&x0)[2], const uint4 (&x1)[2]) {
+        constexpr int RT = decltype(rt_tag)::value, KK = decltype(kk_tag)::value;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) acc[rt * 2 + tt] = T::mfma(w[kk][rt], kk ? x1[tt] : x0[tt], acc[rt * 2 + tt]);
-        __builtin_amdgcn_sched_group_barrier(0x100, KK * RT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * KK * RT, 0);
+                for (int tt = 0; tt < 2; ++tt) acc[rt * 2 + tt] = T::mfma(f.w[kk][rt], kk ? x1[tt] : x0[tt], acc[rt * 2 + tt]);
     };
     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     using I4 = std::integral_constant<int, 4>;
-    auto dense320 = [&](f32x4 (&acc)[20][2]) {
+    using EVEN = std::true_type; using ODD = std::false_type;
+    // a group of N slabs of the same shape whose first slab has stream-index parity P0 (0 = even): acc_of(i) / x0_of(i) / x1_of(i) name the
+    // accumulator tile block and the operand k steps of slab i
+    auto slab_group = [&](auto p0_tag, auto n_tag, auto rt_tag, auto kk_tag, auto&& acc_of, auto&& x0_of, auto&& x1_of, auto tail) {
+        constexpr int P0 = decltype(p0_tag)::value, N = decltype(n_tag)::value, RT = decltype(rt_tag)::value, KK = decltype(kk_tag)::value;
+        WF f[2];
+        slab_load(next_slab(std::bool_constant<P0 == 0>{}, tail), rt_tag, kk_tag, f[0]);
 #pragma unroll
-        for (int rb = 0; rb < 5; ++rb)
-#pragma unroll
-            for (int kt = 0; kt < 5; ++kt) {
-                const unsigned char* s = next_slab();
-                slab_mma(s, I4{}, I2{}, &acc[rb * 4][0], a[2 * kt], a[2 * kt + 1]);
+        for (int i = 0; i < N; ++i) {
+            if (i + 1 < N) {
+                if (((P0 + i + 1) & 1) == 0) slab_load(next_slab(EVEN{}, tail), rt_tag, kk_tag, f[(i + 1) & 1]);
+                else slab_load(next_slab(ODD{}, tail), rt_tag, kk_tag, f[(i + 1) & 1]);
             }
+            slab_fma(f[i & 1], rt_tag, kk_tag, acc_of(i), x0_of(i), x1_of(i));
+            if (i + 1 < N) __builtin_amdgcn_sched_group_barrier(0x100, KK * RT, 0);      // next slab's reads first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * KK * RT, 0);                 // ... then this slab's MFMAs
+        }
+    };
+    using P0E = std::integral_constant<int, 0>; using P0O = std::integral_constant<int, 1>;
+    using N5 = std::integral_constant<int, 5>; using N10 = std::integral_constant<int, 10>; using N25 = std::integral_constant<int, 25>;
+    using BODY = std::false_type; using TAIL = std::true_type;
+    auto dense320 = [&](auto p0_tag, f32x4 (&acc)[20][2], auto tail) {      // 5 row blocks x 5 k tiles
+        slab_group(p0_tag, N25{}, I4{}, I2{}, [&](int i) { return &acc[(i / 5) * 4][0]; }, [&](int i) -> const uint4 (&)[2] { return a[2 * (i % 5)]; },
+                   [&](int i) -> const uint4 (&)[2] { return a[2 * (i % 5) + 1]; }, tail);
     };
     auto frag = [&](const f32x4& lo, const f32x4& hi) -> uint4 {
         return make_uint4(pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]), pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3]));
@@ -175,8 +200,8 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
         }
     };
 
-    // ---- attn1 output projection: t = t_in + Wo1 o + bo1
-    dense320(t);
+    // ---- attn1 output projection: t = t_in + Wo1 o + bo1        (stream slabs 0..24)
+    dense320(P0E{}, t, BODY{});
     add_bias(Q_BO1);
 
     // ---- attn2: cross-attention to the 77 text keys.  Per head: q (5 slabs) | S^T = K_h q^T (2 slabs: key rows 0..63, 64..79) | softmax |
@@ -191,8 +216,9 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) qa[i][tt] = z4;
-#pragma unroll
-        for (int kt = 0; kt < 5; ++kt) { const unsigned char* s = next_slab(); slab_mma(s, I3{}, I2{}, &qa[0][0], a[2 * kt], a[2 * kt + 1]); }
+        // (a head is 14 slabs and starts at an odd stream index: 25 + 14 h)
+        slab_group(P0O{}, N5{}, I3{}, I2{}, [&](int) { return &qa[0][0]; }, [&](int i) -> const uint4 (&)[2] { return a[2 * i]; },
+                   [&](int i) -> const uint4 (&)[2] { return a[2 * i + 1]; }, BODY{});
         uint4 q0[2], q1[2];                          // [token tile]: k steps 0 (d = PERM32) and 1 (d = 32 + 4 lg + e, e < 4)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) { q0[tt] = frag(qa[0][tt], qa[1][tt]); q1[tt] = frag(qa[2][tt], z4); }
@@ -201,8 +227,15 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
         for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) sT[kt][tt] = z4;
-        { const unsigned char* s = next_slab(); slab_mma(s, I4{}, I2{}, &sT[0][0], q0, q1); }
-        { const unsigned char* s = next_slab(); slab_mma(s, I1{}, I2{}, &sT[4][0], q0, q1); }
+        {      // K_h: key rows 0..63 (4 tiles), then 64..79 (1 tile)
+            WF f0, f1;
+            slab_load(next_slab(EVEN{}, BODY{}), I4{}, I2{}, f0);
+            slab_load(next_slab(ODD{}, BODY{}), I1{}, I2{}, f1);
+            slab_fma(f0, I4{}, I2{}, &sT[0][0], q0, q1);
+            slab_fma(f1, I1{}, I2{}, &sT[4][0], q0, q1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+        }
         uint4 pf[3][2];                              // [k step of 32 keys][token tile]
         float inv[2];
 #pragma unroll
@@ -229,8 +262,15 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) oT[i][tt] = z4;
-        { const unsigned char* s = next_slab(); slab_mma(s, I3{}, I2{}, &oT[0][0], pf[0], pf[1]); }
-        { const unsigned char* s = next_slab(); slab_mma(s, I3{}, I1{}, &oT[0][0], pf[2], pf[2]); }
+        {      // V_h^T: keys 0..63 (2 k steps), then 64..95 (1 k step)
+            WF f0, f1;
+            slab_load(next_slab(EVEN{}, BODY{}), I3{}, I2{}, f0);
+            slab_load(next_slab(ODD{}, BODY{}), I3{}, I1{}, f1);
+            slab_fma(f0, I3{}, I2{}, &oT[0][0], pf[0], pf[1]);
+            slab_fma(f1, I3{}, I1{}, &oT[0][0], pf[2], pf[2]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
+        }
         uint4 o0[2], o1[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -238,24 +278,22 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
             for (int i = 0; i < 3; ++i) oT[i][tt] *= inv[tt];
             o0[tt] = frag(oT[0][tt], oT[1][tt]); o1[tt] = frag(oT[2][tt], z4);
         }
-#pragma unroll
-        for (int rb = 0; rb < 5; ++rb) { const unsigned char* s = next_slab(); slab_mma(s, I4{}, I2{}, &t[rb * 4][0], o0, o1); }
+        slab_group(P0E{}, N5{}, I4{}, I2{}, [&](int i) { return &t[i * 4][0]; }, [&](int) -> const uint4 (&)[2] { return o0; },
+                   [&](int) -> const uint4 (&)[2] { return o1; }, BODY{});
     }
     add_bias(Q_BO2);
 
     // ---- GEGLU feed-forward, 20 chunks of 64 hidden units: 10 slabs of W1 (value / gate rows interleaved per 16), 5 slabs of W2
     layer_norm(Q_LN3G, Q_LN3B);
-#pragma unroll 1
-    for (int c = 0; c < 20; ++c) {
+    // (chunk c is 15 slabs and starts at stream index 137 + 15 c: odd for even c, even for odd c -> two chunks per loop iteration)
+    auto ff_chunk = [&](const int c, auto p0_tag) {
         f32x4 g[8][2];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) g[i][tt] = z4;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int kt = 0; kt < 5; ++kt) { const unsigned char* s = next_slab(); slab_mma(s, I4{}, I2{}, &g[rb * 4][0], a[2 * kt], a[2 * kt + 1]); }
+        slab_group(p0_tag, N10{}, I4{}, I2{}, [&](int i) { return &g[(i / 5) * 4][0]; }, [&](int i) -> const uint4 (&)[2] { return a[2 * (i % 5)]; },
+                   [&](int i) -> const uint4 (&)[2] { return a[2 * (i % 5) + 1]; }, BODY{});
         uint4 hf0[2], hf1[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -270,9 +308,11 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
             }
             hf0[tt] = frag(hv[0], hv[1]); hf1[tt] = frag(hv[2], hv[3]);
         }
-#pragma unroll
-        for (int rb = 0; rb < 5; ++rb) { const unsigned char* s = next_slab(); slab_mma(s, I4{}, I2{}, &t[rb * 4][0], hf0, hf1); }
-    }
+        slab_group(p0_tag, N5{}, I4{}, I2{}, [&](int i) { return &t[i * 4][0]; }, [&](int) -> const uint4 (&)[2] { return hf0; },
+                   [&](int) -> const uint4 (&)[2] { return hf1; }, BODY{});
+    };
+#pragma unroll 1
+    for (int c = 0; c < 20; c += 2) { ff_chunk(c, P0O{}); ff_chunk(c + 1, P0E{}); }
     add_bias(Q_B2);
 
     // ---- proj_out (+ bias + x [+ res1])
@@ -284,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
     for (int j = 0; j < 20; ++j)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) t[j][tt] = z4;
-    dense320(t);
+    dense320(P0O{}, t, TAIL{});          // stream slabs 437..461
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
         const int64_t r = row0 + tt * 16 + li;
