@@ -21,7 +21,7 @@ t = torch.randn(M, C, device=ctx.device)
 x = torch.randn(M, C, device=ctx.device)
 
 
-def timeit(fn, n=5, warm=2):
+def timeit(fn, n=20, warm=3):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

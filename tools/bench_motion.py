@@ -3,7 +3,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from videovanish_amd import nn as vnn
+from videovanish_amd import hip, nn as vnn
+if os.environ.get("VV_LIB_PATH"):
+    hip._LIB_PATH = os.environ["VV_LIB_PATH"]          # A/B of two builds of the library on one device
 from videovanish_amd.config import UNetConfig
 from videovanish_amd.unet import sinusoidal_pos_emb
 
@@ -15,7 +17,7 @@ mod = vnn.MotionModule(ctx, "unet.down_blocks.0.motion_modules.0", C, cfg, ctx.d
 x = torch.randn(Fr * H * W, C, device=ctx.device)
 
 
-def timeit(fn, n=5, warm=2):
+def timeit(fn, n=20, warm=3):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

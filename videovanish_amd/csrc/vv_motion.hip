@@ -92,12 +92,14 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
         glds16_asm(src + 1024, dst + 1024);
         ++issued;
     };
-    // next slab of the stream, ready to be read by every wave of the block.  Slabs are synchronised in PAIRS (N_SLABS is even): the
-    // even call issues two more slabs, waits until all but the newest AHEAD have landed (this wave's share) and joins the barrier (everybody's
-    // share has landed, everybody is done with the pair before the previous one: the ring keeps AHEAD + 4 slots); the odd call just advances.
-    auto next_slab = [&]() -> const unsigned char* {
-        if ((consumed & 1) == 0) {
-            if (issued < N_SLABS) { issue(); issue(); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }     // 2 DMA x AHEAD slabs may stay in flight
+    // next slab of the stream, ready to be read by every wave of the block.  Slabs are synchronised in PAIRS (N_SLABS is even): the EVEN slab
+    // issues two more slabs, waits until all but the newest AHEAD have landed (this wave's share) and joins the barrier (everybody's share has
+    // landed, everybody is done with the pair before the previous one: the ring keeps AHEAD + 4 slots); the odd one just advances.  The parity of a
+    // slab's stream index is a compile-time property of its call site (`even_tag`; a run-time test would cut the instruction stream into one basic
+    // block per slab); `tail_tag`: only the last group of the stream (proj_out) can run out of slabs to issue, everywhere else the issue is unconditional.
+    auto next_slab = [&](auto even_tag, auto tail_tag) -> const unsigned char* {
+        if constexpr (decltype(even_tag)::value) {
+            if (!decltype(tail_tag)::value || issued < N_SLABS) { issue(); issue(); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }     // 2 DMA x AHEAD slabs may stay in flight
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
@@ -129,56 +131,57 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
         for (int i = 0; i < AHEAD; ++i) issue();
     }
 
-    // D += W_slab * X^T for RT row tiles of one [RT*16 rows x 64 k] slab; act = the two k steps of this k tile
-    auto slab_mma = [&](const unsigned char* s, auto rt_tag, f32x4* acc /* [RT][2] */, const uint4 (&x0)[2], const uint4 (&x1)[2]) {
+    // D += W_slab * X^T for RT row tiles of one [RT*16 rows x 64 k] slab, split into the fragment reads (LDS -> registers) and the MFMAs so that
+    // a group of slabs runs software pipelined: the reads of slab i+1 are in flight under the MFMAs of slab i (with ONE wave per SIMD and the
+    // four waves of a block released by the same barrier, reads waited for right before their MFMAs leave the matrix pipe idle for the whole
+    // LDS round trip on every slab).  TR: operands exchanged, D = X * W^T (lane = output channel li, registers = tokens 4 lg + r): V^T.
+    struct WF { uint4 w[2][4]; };
+    auto slab_load = [&](const unsigned char* s, auto rt_tag, WF& f) {
         constexpr int RT = decltype(rt_tag)::value;
         const int sw = li & 7;
-        // all fragment reads of the slab first (8 LDS reads in flight), then the MFMAs: with ONE wave per SIMD a read that is waited for
-        // right before its two MFMAs exposes the whole LDS latency every 32 matrix cycles
-        uint4 w[2][RT];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int off = ((kk * 4 + lg) ^ sw) << 4;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) w[kk][rt] = *(const uint4*)(s + (rt * 16 + li) * 128 + off);
+            for (int rt = 0; rt < RT; ++rt) f.w[kk][rt] = *(const uint4*)(s + (rt * 16 + li) * 128 + off);
         }
+    };
+    auto slab_fma = [&](const WF& f, auto rt_tag, auto tr_tag, f32x4* acc /* [RT][2] */, const uint4 (&x0)[2], const uint4 (&x1)[2]) {
+        constexpr int RT = decltype(rt_tag)::value;
+        constexpr bool TR = decltype(tr_tag)::value;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) acc[rt * 2 + tt] = T::mfma(w[kk][rt], kk ? x1[tt] : x0[tt], acc[rt * 2 + tt]);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * RT, 0);      // keep the reads together, ahead of the MFMAs (hipcc otherwise
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * RT, 0);      // re-serialises read -> wait -> 2 MFMAs to save registers)
+                for (int tt = 0; tt < 2; ++tt)
+                    acc[rt * 2 + tt] = TR ? T::mfma(kk ? x1[tt] : x0[tt], f.w[kk][rt], acc[rt * 2 + tt]) : T::mfma(f.w[kk][rt], kk ? x1[tt] : x0[tt], acc[rt * 2 + tt]);
     };
-    // same with the operands exchanged: D = X * W^T (lane = output channel li, registers = tokens 4 lg + r): V^T for the attention
-    auto slab_mma_t = [&](const unsigned char* s, f32x4* acc /* [3][2] */, const uint4 (&x0)[2], const uint4 (&x1)[2]) {
-        const int sw = li & 7;
-        uint4 w[2][3];
+    using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+    using EVEN = std::true_type; using ODD = std::false_type; using BODY = std::false_type; using TAIL = std::true_type;
+    using PLAIN = std::false_type; using TRANSP = std::true_type;
+    // a group of N slabs of the same shape whose first slab has stream-index parity P0 (0 = even)
+    auto slab_group = [&](auto p0_tag, auto n_tag, auto rt_tag, auto tr_tag, auto&& acc_of, auto&& x0_of, auto&& x1_of, auto tail) {
+        constexpr int P0 = decltype(p0_tag)::value, N = decltype(n_tag)::value, RT = decltype(rt_tag)::value;
+        WF f[2];
+        slab_load(next_slab(std::bool_constant<P0 == 0>{}, tail), rt_tag, f[0]);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int off = ((kk * 4 + lg) ^ sw) << 4;
-#pragma unroll
-            for (int rt = 0; rt < 3; ++rt) w[kk][rt] = *(const uint4*)(s + (rt * 16 + li) * 128 + off);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int rt = 0; rt < 3; ++rt)
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) acc[rt * 2 + tt] = T::mfma(kk ? x1[tt] : x0[tt], w[kk][rt], acc[rt * 2 + tt]);
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-    };
-    // full-width layer: t[20][2] (+)= W [320 x 320] * a   (5 row blocks x 5 k tiles = 25 slabs)
-    auto dense320 = [&](f32x4 (&acc)[20][2]) {
-#pragma unroll
-        for (int rb = 0; rb < 5; ++rb)
-#pragma unroll
-            for (int kt = 0; kt < 5; ++kt) {
-                const unsigned char* s = next_slab();
-                slab_mma(s, std::integral_constant<int, 4>{}, &acc[rb * 4][0], a[2 * kt], a[2 * kt + 1]);
+        for (int i = 0; i < N; ++i) {
+            if (i + 1 < N) {
+                if (((P0 + i + 1) & 1) == 0) slab_load(next_slab(EVEN{}, tail), rt_tag, f[(i + 1) & 1]);
+                else slab_load(next_slab(ODD{}, tail), rt_tag, f[(i + 1) & 1]);
             }
+            slab_fma(f[i & 1], rt_tag, tr_tag, acc_of(i), x0_of(i), x1_of(i));
+            if (i + 1 < N) __builtin_amdgcn_sched_group_barrier(0x100, 2 * RT, 0);      // next slab's reads first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * RT, 0);                     // ... then this slab's MFMAs
+        }
+    };
+    using P0E = std::integral_constant<int, 0>; using P0O = std::integral_constant<int, 1>;
+    using N5 = std::integral_constant<int, 5>; using N10 = std::integral_constant<int, 10>; using N25 = std::integral_constant<int, 25>;
+    // full-width layer: t[20][2] (+)= W [320 x 320] * a   (5 row blocks x 5 k tiles = 25 slabs)
+    auto dense320 = [&](auto p0_tag, f32x4 (&acc)[20][2], auto tail) {
+        slab_group(p0_tag, N25{}, I4{}, PLAIN{}, [&](int i) { return &acc[(i / 5) * 4][0]; }, [&](int i) -> const uint4 (&)[2] { return a[2 * (i % 5)]; },
+                   [&](int i) -> const uint4 (&)[2] { return a[2 * (i % 5) + 1]; }, tail);
     };
     auto frag = [&](const f32x4& lo, const f32x4& hi) -> uint4 {
         return make_uint4(pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]), pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3]));
@@ -233,12 +236,12 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) { qa[i][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; ka[i][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; va[i][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-            for (int kt = 0; kt < 5; ++kt) { const unsigned char* s = next_slab(); slab_mma(s, std::integral_constant<int, 3>{}, &qa[0][0], a[2 * kt], a[2 * kt + 1]); }
-#pragma unroll
-            for (int kt = 0; kt < 5; ++kt) { const unsigned char* s = next_slab(); slab_mma(s, std::integral_constant<int, 3>{}, &ka[0][0], a[2 * kt], a[2 * kt + 1]); }
-#pragma unroll
-            for (int kt = 0; kt < 5; ++kt) { const unsigned char* s = next_slab(); slab_mma_t(s, &va[0][0], a[2 * kt], a[2 * kt + 1]); }
+            // (a head is 20 slabs and starts at an odd stream index: 25 + 160 A + 20 h)
+            auto ak0 = [&](int i) -> const uint4 (&)[2] { return a[2 * i]; };
+            auto ak1 = [&](int i) -> const uint4 (&)[2] { return a[2 * i + 1]; };
+            slab_group(P0O{}, N5{}, I3{}, PLAIN{}, [&](int) { return &qa[0][0]; }, ak0, ak1, BODY{});
+            slab_group(P0E{}, N5{}, I3{}, PLAIN{}, [&](int) { return &ka[0][0]; }, ak0, ak1, BODY{});
+            slab_group(P0O{}, N5{}, I3{}, TRANSP{}, [&](int) { return &va[0][0]; }, ak0, ak1, BODY{});
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
             uint4 qf[2][2], kf[2][2];                     // [token tile][k step]
 #pragma unroll
@@ -292,8 +295,8 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
             for (int tt = 0; tt < 2; ++tt) { of[tt][0] = frag(oT[0][tt], oT[1][tt]); of[tt][1] = frag(oT[2][tt], z4); }
             // t += Wo[:, head] * O   (5 row blocks, one k tile: d padded 40 -> 64)
             const uint4 o0[2] = {of[0][0], of[1][0]}, o1[2] = {of[0][1], of[1][1]};
-#pragma unroll
-            for (int rb = 0; rb < 5; ++rb) { const unsigned char* s = next_slab(); slab_mma(s, std::integral_constant<int, 4>{}, &t[rb * 4][0], o0, o1); }
+            slab_group(P0E{}, N5{}, I4{}, PLAIN{}, [&](int i) { return &t[i * 4][0]; }, [&](int) -> const uint4 (&)[2] { return o0; },
+                       [&](int) -> const uint4 (&)[2] { return o1; }, BODY{});
         }
         add_bias(bias_off);
     };
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
     for (int j = 0; j < 20; ++j)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) t[j][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dense320(t);
+    dense320(P0E{}, t, BODY{});          // stream slabs 0..24
     add_bias(P_BIN);
     // ---- two temporal self-attentions
     layer_norm(P_LN1G, P_LN1B, true);
@@ -312,17 +315,15 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
     attention(P_BO2);
     // ---- GEGLU feed-forward, 20 chunks of 64 hidden units: 10 slabs of W1 (value/gate rows interleaved per 16), 5 slabs of W2
     layer_norm(P_LN3G, P_LN3B, false);
-#pragma unroll 1
-    for (int c = 0; c < 20; ++c) {
+    // (chunk c is 15 slabs and starts at stream index 345 + 15 c: odd for even c, even for odd c -> two chunks per loop iteration)
+    auto ff_chunk = [&](const int c, auto p0_tag) {
         f32x4 g[8][2];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) g[i][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int kt = 0; kt < 5; ++kt) { const unsigned char* s = next_slab(); slab_mma(s, std::integral_constant<int, 4>{}, &g[rb * 4][0], a[2 * kt], a[2 * kt + 1]); }
+        slab_group(p0_tag, N10{}, I4{}, PLAIN{}, [&](int i) { return &g[(i / 5) * 4][0]; }, [&](int i) -> const uint4 (&)[2] { return a[2 * (i % 5)]; },
+                   [&](int i) -> const uint4 (&)[2] { return a[2 * (i % 5) + 1]; }, BODY{});
         uint4 hf0[2], hf1[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -337,9 +338,11 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
             }
             hf0[tt] = frag(hv[0], hv[1]); hf1[tt] = frag(hv[2], hv[3]);
         }
-#pragma unroll
-        for (int rb = 0; rb < 5; ++rb) { const unsigned char* s = next_slab(); slab_mma(s, std::integral_constant<int, 4>{}, &t[rb * 4][0], hf0, hf1); }
-    }
+        slab_group(p0_tag, N5{}, I4{}, PLAIN{}, [&](int i) { return &t[i * 4][0]; }, [&](int) -> const uint4 (&)[2] { return hf0; },
+                   [&](int) -> const uint4 (&)[2] { return hf1; }, BODY{});
+    };
+#pragma unroll 1
+    for (int c = 0; c < 20; c += 2) { ff_chunk(c, P0O{}); ff_chunk(c + 1, P0E{}); }
     add_bias(P_B2);
     // ---- proj_out (+ bias + x + res1)
 #pragma unroll
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
     for (int j = 0; j < 20; ++j)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) t[j][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dense320(t);
+    dense320(P0O{}, t, TAIL{});          // stream slabs 645..669
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
         const int64_t row = ((int64_t)(tt * 16 + li) * HW + pixel) * MC;
