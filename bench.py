@@ -87,9 +87,10 @@ def strong_scaling(args, model, dist, rank, world, H, W, ucfg, vcfg):
     barrier()
     dt = time.time() - t0
     per_rank = [tms[-1]]
-    backend = "none"
+    backend, ranks_seen = "none", 1
     if world > 1:
         import torch.distributed as td
+        ranks_seen = td.get_world_size()
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         dt = float(tt.item())
@@ -110,7 +111,7 @@ def strong_scaling(args, model, dist, rank, world, H, W, ucfg, vcfg):
                                f"timed host memory -> host memory (rank 0 collects every frame), {args.arch} width, random-init weights",
                    "frames": T, "chunks": len(plan), "parallelism": f"chunk-dp{world}", "ideal_speedup_from_chunk_quantisation": round(ideal, 3),
                    "precise_decoder": bool(args.precise_decoder)},
-        "job_tflops": round(fl / dt / 1e12, 1), "collective_backend": backend,
+        "job_tflops": round(fl / dt / 1e12, 1), "collective_backend": backend, "ranks_seen": ranks_seen,
         "per_rank_seconds": per_rank,
     }
 
