@@ -1400,6 +1400,7 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
                 if (var == 56) return attn40q2_launch<T, 4, 2>(p, st);                                  // 64 queries per wave, 2 waves/SIMD
                 if (var == 57) return attn40q2_launch<T, 2, 2>(p, st);                                  // ... 2-wave blocks
                 if (var == 58) return attn40q2_launch<T, 4, 1>(p, st);                                  // ... 1 wave/SIMD (512 registers)
+                if (var == 59) return attn40q2_launch<T, 8, 2>(p, st);                                  // ... 8-wave blocks: 512 queries share a K/V tile
                 if (var == 55) return attn40_launch<T, 4, 2, 6>(p, st);                                 // ... the compiler's own issue order (no sched_group_barrier pipeline)
                 if (var == 61) return attn40_launch<T, 4, 2, 1>(p, st);      // timing probes (WRONG results): no barrier
                 if (var == 62) return attn40_launch<T, 4, 2, 2>(p, st);      // ... no exp
