@@ -1,6 +1,5 @@
 // K2: GroupNorm(+SiLU) and LayerNorm(+positional embedding) for frames-major NHWC activations.  HBM-bound:
 // every element is read twice (statistics pass, apply pass) with 16/32-byte vector loads and written once as h16.
-#include <stdlib.h>
 #include "vv_common.h"
 
 namespace {
@@ -230,7 +229,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 template <typename T>
-int gn_launch_one(const vv_groupnorm_params& p, hipStream_t st, bool apply) {
+int gn_launch(const vv_groupnorm_params& p, hipStream_t st, bool apply = true) {
     const int C = p.C0 + p.C1;
     const GNGeom g = gn_geom(p.HW, C);
     const int threads = (g.threads + 63) / 64 * 64;
@@ -239,38 +238,6 @@ int gn_launch_one(const vv_groupnorm_params& p, hipStream_t st, bool apply) {
     else hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.F), dim3(256), 0, st, p, g);
     if (apply) hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
     VV_CHECK_LAUNCH("vv_groupnorm");
-    return VV_OK;
-}
-
-// Per-frame statistics are independent per frame, so a large clip is normalised a few frames at a time: the apply pass then re-reads what the
-// statistics pass of the SAME launch group has just streamed -- ~64 MB, resident in the 256 MB Infinity Cache (MI355X_MICROARCH.md: a table stays
-// resident while it plus everything loaded or stored between two uses of a line fits) -- instead of fetching the clip from HBM a second time.
-template <typename T>
-int gn_launch(const vv_groupnorm_params& p, hipStream_t st, bool apply = true) {
-    const int C = p.C0 + p.C1;
-    const int64_t in_es = p.in_dtype == VV_F32 ? 4 : 2;
-    const int64_t frame_bytes = (int64_t)p.HW * C * in_es;
-    int G = p.F;
-    int64_t target = 64ll << 20;
-#ifdef VV_AB
-    static int env_mb = -2;
-    if (env_mb == -2) { const char* e = getenv("VV_GN_GROUP_MB"); env_mb = e ? atoi(e) : -1; }
-    if (env_mb >= 0) target = (int64_t)env_mb << 20;
-#endif
-    if (apply && !p.pool_frames && target > 0 && frame_bytes * p.F > 2 * target) G = (int)(target / frame_bytes > 1 ? target / frame_bytes : 1);
-    if (G >= p.F) return gn_launch_one<T>(p, st, apply);
-    const int nsplit = gn_geom(p.HW, C).nsplit;
-    const int64_t out_es = p.out_dtype == VV_F32 ? 4 : (p.out_dtype == VV_SPLIT3 ? 6 : 2);
-    for (int f0 = 0; f0 < p.F; f0 += G) {
-        vv_groupnorm_params q = p;
-        q.F = p.F - f0 < G ? p.F - f0 : G;
-        q.in0 = (const char*)p.in0 + (int64_t)f0 * p.HW * p.C0 * in_es;
-        if (p.in1) q.in1 = (const char*)p.in1 + (int64_t)f0 * p.HW * p.C1 * in_es;
-        q.out = (char*)p.out + (int64_t)f0 * p.HW * C * out_es;
-        q.stats_ws = p.stats_ws + (int64_t)f0 * (nsplit + 1) * p.groups * 2;      // partials [F'][nsplit][groups][2] + (mean, rstd) [F'][groups][2] of this group
-        const int rc = gn_launch_one<T>(q, st, apply);
-        if (rc != VV_OK) return rc;
-    }
     return VV_OK;
 }
 
