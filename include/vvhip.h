@@ -158,6 +158,23 @@ typedef struct {
 } vv_chain_params;
 int vv_spatial_chain_c320(const vv_chain_params* host_p, int dtype, void* stream);
 
+/* Front half of the same block (everything before the self-attention core): t = Win GN(x) + bin (GroupNorm APPLY with per-frame statistics,
+ * proj_in); qkv = Wqkv LN1(t), stored head-major [frame][q|k|v][head][token][40] (what vv_attention reads with q_rs = 40, q_hs = HW * 40; the
+ * query rows of the packed weights carry scale * log2 e: q_prescaled = 1).  gn_affine: [F][2][320] per-frame scale / shift from
+ * vv_groupnorm_stats + vv_gn_affine_frames.  stream / params: packing.pack_chain_front_stream (100 slabs; 960 floats).
+ * Replaces vv_groupnorm's apply pass, two vv_conv_gemm and one vv_layernorm of nn.SpatialTransformer. */
+typedef struct {
+    const float* x; const float* gn_affine;
+    float* t_out; void* qkv;
+    const void* stream; const float* params;
+    int64_t M; int32_t HW;
+    int32_t C, heads;
+    int32_t n_slabs, n_params;
+} vv_chain_front_params;
+int vv_spatial_chain_front_c320(const vv_chain_front_params* host_p, int dtype, void* stream);
+/* (mean, rstd) [F][groups][2] of a per-frame GroupNorm -> per-channel scale / shift [F][2][C] */
+int vv_gn_affine_frames(const float* mean_rstd, const float* gamma, const float* beta, int C, int groups, int F, float* out, void* stream);
+
 /* LayerNorm over the last dim of a [M][C] fp32 matrix, eps 1e-5; out = LN(x)*gamma+beta (+ pe[(m / rows_per_frame)][c]). */
 int vv_layernorm(const float* x, int M, int C, const float* gamma, const float* beta, const float* pe,
                  int rows_per_frame, void* out, int dtype, void* stream);

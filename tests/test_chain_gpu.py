@@ -30,6 +30,7 @@ def test_fused_spatial_chain_vs_oracle_and_unfused(gpu, dname, tol, Fr, H, W):
     ctx = vnn.Ctx("cuda:0", dname, 0)
     mod = vnn.SpatialTransformer(ctx, name, C, cfg, ctx.dev(text[0], ctx.h16))
     assert mod.fused is not None and mod.fused[0].shape == (462, 64, 64) and mod.fused[1].numel() == 5120
+    assert mod.front[0].shape == (100, 64, 64) and mod.front[1].numel() == 960
     nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(Fr * H * W, C).contiguous().to(gpu)
     back = lambda t: t.float().cpu().reshape(Fr, H, W, C).permute(0, 3, 1, 2)
     xin = nhwc(x)

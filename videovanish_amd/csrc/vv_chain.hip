@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int CC = 320, CH = 8, CD = 40, NKEY = 77;
+constexpr int CC = 320, CH = 8, CD = 40, NKEY = 77;      // CD: head dim
 constexpr int NSLOT = 10, AHEAD = 6, SLAB = 8192;
 // fp32 parameter block (floats): offsets
 constexpr int Q_BO1 = 0, Q_LN2G = 320, Q_LN2B = 640, Q_BO2 = 960, Q_LN3G = 1280, Q_LN3B = 1600, Q_B1 = 1920, Q_B2 = 4480, Q_BOUT = 4800, Q_TOTAL = 5120;
@@ -344,6 +344,205 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Front half of the same block: everything BEFORE the self-attention core is per token too --
+//   t = Win GN(x) + bin        (GroupNorm apply with per-frame statistics + proj_in; t = the block's fp32 residual stream, written out for the tail)
+//   qkv = Wqkv LN1(t)          (fused q | k | v projection, stored head-major [frame][q|k|v][head][token][40] for vv_attention, q pre-scaled)
+// in one kernel per 128 tokens (100 slabs: 25 + 15 row blocks x 5), replacing vv_groupnorm's apply pass, two vv_conv_gemm and one vv_layernorm.
+constexpr int F_BIN = 0, F_LN1G = 320, F_LN1B = 640, F_TOTAL = 960;
+constexpr int NF_SLABS = 25 + 15 * 5;      // 100
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void chain_front_c320_kernel(const vv_chain_front_params p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[NSLOT * SLAB];
+    __shared__ __attribute__((aligned(16))) float prm[F_TOTAL];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+
+    for (int i = tid * 4; i < F_TOTAL; i += 256 * 4) *(float4*)(prm + i) = *(const float4*)(p.params + i);
+    const unsigned char* sbase = (const unsigned char*)p.stream + (wave * 2) * 1024 + lane * 16;
+    int issued = 0, consumed = 0;
+    auto issue = [&]() {
+        unsigned char* dst = ring + (issued % NSLOT) * SLAB + (wave * 2) * 1024;
+        const unsigned char* src = sbase + (int64_t)issued * SLAB;
+        glds16_asm(src, dst);
+        glds16_asm(src + 1024, dst + 1024);
+        ++issued;
+    };
+    auto next_slab = [&](auto even_tag, auto tail_tag) -> const unsigned char* {
+        if constexpr (decltype(even_tag)::value) {
+            if (!decltype(tail_tag)::value || issued < NF_SLABS) { issue(); issue(); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const unsigned char* s = ring + (consumed % NSLOT) * SLAB;
+        ++consumed;
+        return s;
+    };
+
+    // ---- x -> GroupNorm apply (scale / shift of the token's own frame) -> activation fragments a[ks][tt]
+    uint4 a[10][2];
+    int64_t rows[2];
+    {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            int64_t row = row0 + tt * 16 + li;
+            if (row >= p.M) row = p.M - 1;
+            rows[tt] = row;
+            const float* xrow = p.x + row * CC;
+            const float* aff = p.gn_affine + (row / p.HW) * (2 * CC);
+#pragma unroll
+            for (int s = 0; s < 10; ++s) {
+                const int c0 = 32 * s + 4 * lg, c1 = c0 + 16;
+                const float4 x0 = *(const float4*)(xrow + c0), x1 = *(const float4*)(xrow + c1);
+                const float4 a0 = *(const float4*)(aff + c0), b0 = *(const float4*)(aff + CC + c0);
+                const float4 a1 = *(const float4*)(aff + c1), b1 = *(const float4*)(aff + CC + c1);
+                a[s][tt] = make_uint4(pack2<T>(x0.x * a0.x + b0.x, x0.y * a0.y + b0.y), pack2<T>(x0.z * a0.z + b0.z, x0.w * a0.w + b0.w),
+                                      pack2<T>(x1.x * a1.x + b1.x, x1.y * a1.y + b1.y), pack2<T>(x1.z * a1.z + b1.z, x1.w * a1.w + b1.w));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();       // parameter block visible
+#pragma unroll 1
+        for (int i = 0; i < AHEAD; ++i) issue();
+    }
+
+    struct WF { uint4 w[2][4]; };
+    auto slab_load = [&](const unsigned char* s, WF& f) {
+        const int sw = li & 7;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int off = ((kk * 4 + lg) ^ sw) << 4;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) f.w[kk][rt] = *(const uint4*)(s + (rt * 16 + li) * 128 + off);
+        }
+    };
+    auto slab_fma = [&](const WF& f, f32x4* acc /* [4][2] */, const uint4 (&x0)[2], const uint4 (&x1)[2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) acc[rt * 2 + tt] = T::mfma(f.w[kk][rt], kk ? x1[tt] : x0[tt], acc[rt * 2 + tt]);
+    };
+    using EVEN = std::true_type; using ODD = std::false_type; using BODY = std::false_type; using TAIL = std::true_type;
+    // N slabs [64 rows x 64 k] (5 k tiles per 64-row block) starting at stream-index parity P0
+    auto slab_group = [&](auto p0_tag, auto n_tag, auto&& acc_of, auto tail) {
+        constexpr int P0 = decltype(p0_tag)::value, N = decltype(n_tag)::value;
+        WF f[2];
+        slab_load(next_slab(std::bool_constant<P0 == 0>{}, tail), f[0]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (i + 1 < N) {
+                if (((P0 + i + 1) & 1) == 0) slab_load(next_slab(EVEN{}, tail), f[(i + 1) & 1]);
+                else slab_load(next_slab(ODD{}, tail), f[(i + 1) & 1]);
+            }
+            slab_fma(f[i & 1], acc_of(i), a[2 * (i % 5)], a[2 * (i % 5) + 1]);
+            if (i + 1 < N) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        }
+    };
+    using P0E = std::integral_constant<int, 0>; using P0O = std::integral_constant<int, 1>;
+    using N5 = std::integral_constant<int, 5>; using N25 = std::integral_constant<int, 25>;
+    auto frag = [&](const f32x4& lo, const f32x4& hi) -> uint4 {
+        return make_uint4(pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]), pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3]));
+    };
+
+    // ---- proj_in: t = Win a + bin, stored (the tail kernel and the residual read it back)
+    f32x4 t[20][2];
+#pragma unroll
+    for (int j = 0; j < 20; ++j)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) t[j][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    slab_group(P0E{}, N25{}, [&](int i) { return &t[(i / 5) * 4][0]; }, BODY{});
+#pragma unroll
+    for (int j = 0; j < 20; ++j) {
+        const float4 b = *(const float4*)(prm + F_BIN + 16 * j + 4 * lg);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) { t[j][tt][0] += b.x; t[j][tt][1] += b.y; t[j][tt][2] += b.z; t[j][tt][3] += b.w; }
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        if (row0 + tt * 16 + li < p.M) {
+            float* trow = p.t_out + rows[tt] * CC;
+#pragma unroll
+            for (int j = 0; j < 20; ++j) *(float4*)(trow + 16 * j + 4 * lg) = make_float4(t[j][tt][0], t[j][tt][1], t[j][tt][2], t[j][tt][3]);
+        }
+    }
+    // ---- LN1 -> a
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 20; ++j) s += (t[j][tt][0] + t[j][tt][1]) + (t[j][tt][2] + t[j][tt][3]);
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        const float mean = s * (1.0f / CC);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 20; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = t[j][tt][r] - mean; q += d * d; }
+        q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+        const float rstd = rsqrtf(q * (1.0f / CC) + 1e-5f);
+#pragma unroll
+        for (int s2 = 0; s2 < 10; ++s2) {
+            f32x4 y[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = 2 * s2 + h, c = 16 * j + 4 * lg;
+                const float4 g = *(const float4*)(prm + F_LN1G + c), b = *(const float4*)(prm + F_LN1B + c);
+                y[h][0] = (t[j][tt][0] - mean) * rstd * g.x + b.x; y[h][1] = (t[j][tt][1] - mean) * rstd * g.y + b.y;
+                y[h][2] = (t[j][tt][2] - mean) * rstd * g.z + b.z; y[h][3] = (t[j][tt][3] - mean) * rstd * g.w + b.w;
+            }
+            a[s2][tt] = frag(y[0], y[1]);
+        }
+    }
+    // ---- fused q | k | v projection: 15 blocks of 64 output channels, stored head-major.  Channel c = 64 rb + 16 rt + 4 lg + r is element
+    //      (which = c / 320, head = (c % 320) / 40, d = c % 40) of the token's row; 4 consecutive channels never straddle a head (40 % 4 == 0)
+    unsigned short* qkv = (unsigned short*)p.qkv;
+    int64_t tokbase[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int64_t fr = rows[tt] / p.HW, tk = rows[tt] - fr * p.HW;
+        tokbase[tt] = fr * (3 * (int64_t)p.HW * CC) + tk * CD;          // + which * HW * 320 + head * HW * 40 + d
+    }
+    auto qkv_block = [&](const int rb, auto p0_tag, auto tail) {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) acc[rt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        slab_group(p0_tag, N5{}, [&](int) { return &acc[0][0]; }, tail);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const int c = 64 * rb + 16 * rt + 4 * lg;
+            const int which = c / CC, cc = c - which * CC, head = cc / CD, d = cc - head * CD;
+            const int64_t off = ((int64_t)which * CC + (int64_t)head * CD) * p.HW + d;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+                if (row0 + tt * 16 + li < p.M)
+                    *(uint2*)(qkv + tokbase[tt] + off) = make_uint2(pack2<T>(acc[rt][tt][0], acc[rt][tt][1]), pack2<T>(acc[rt][tt][2], acc[rt][tt][3]));
+        }
+    };
+    // (row block rb is 5 slabs and starts at stream index 25 + 5 rb: odd for even rb -> two row blocks per loop iteration)
+#pragma unroll 1
+    for (int rb = 0; rb < 12; rb += 2) { qkv_block(rb, P0O{}, BODY{}); qkv_block(rb + 1, P0E{}, BODY{}); }
+    qkv_block(12, P0O{}, TAIL{}); qkv_block(13, P0E{}, TAIL{}); qkv_block(14, P0O{}, TAIL{});
+}
+
+// per-frame GroupNorm affine: out[f][0][c] = rstd * gamma[c], out[f][1][c] = beta[c] - mean * rstd * gamma[c]
+__global__ void gn_affine_frames_kernel(const float* fin /* [F][groups][2] */, const float* gamma, const float* beta, int C, int groups, int F, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F * C) return;
+    const int f = i / C, c = i - f * C, g = c / (C / groups);
+    const float a = fin[((int64_t)f * groups + g) * 2 + 1] * gamma[c];
+    out[(int64_t)f * 2 * C + c] = a;
+    out[(int64_t)f * 2 * C + C + c] = beta[c] - fin[((int64_t)f * groups + g) * 2] * a;
+}
+
 }  // namespace
 
 extern "C" int vv_spatial_chain_c320(const vv_chain_params* pp, int dtype, void* stream) {
@@ -361,5 +560,29 @@ extern "C" int vv_spatial_chain_c320(const vv_chain_params* pp, int dtype, void*
     else if (dtype == VV_F16) hipLaunchKernelGGL(chain_c320_kernel<F16>, dim3((unsigned)nblk), dim3(256), 0, st, p);
     else VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: bad dtype");
     VV_CHECK_LAUNCH("vv_spatial_chain_c320");
+    return VV_OK;
+}
+
+extern "C" int vv_gn_affine_frames(const float* mean_rstd, const float* gamma, const float* beta, int C, int groups, int F, float* out, void* stream) {
+    if (!mean_rstd || !gamma || !beta || !out || C <= 0 || groups <= 0 || C % groups || F <= 0) VV_FAIL(VV_E_ARG, "vv_gn_affine_frames: bad args");
+    hipLaunchKernelGGL(gn_affine_frames_kernel, dim3((F * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean_rstd, gamma, beta, C, groups, F, out);
+    VV_CHECK_LAUNCH("vv_gn_affine_frames");
+    return VV_OK;
+}
+
+extern "C" int vv_spatial_chain_front_c320(const vv_chain_front_params* pp, int dtype, void* stream) {
+    if (!pp) VV_FAIL(VV_E_ARG, "vv_spatial_chain_front_c320: null params");
+    const vv_chain_front_params& p = *pp;
+    if (!p.x || !p.gn_affine || !p.t_out || !p.qkv || !p.stream || !p.params) VV_FAIL(VV_E_ARG, "vv_spatial_chain_front_c320: null pointer");
+    if (p.C != CC || p.heads != CH) VV_FAIL(VV_E_UNSUPPORTED, "vv_spatial_chain_front_c320: built for C = 320, 8 heads (got %d, %d)", p.C, p.heads);
+    if (p.M <= 0 || p.HW <= 0 || p.M % p.HW) VV_FAIL(VV_E_ARG, "vv_spatial_chain_front_c320: M must be a positive multiple of HW");
+    if (p.n_slabs != NF_SLABS || p.n_params != F_TOTAL) VV_FAIL(VV_E_ARG, "vv_spatial_chain_front_c320: stream / parameter block size mismatch (%d slabs, %d floats)", p.n_slabs, p.n_params);
+    const int64_t nblk = (p.M + 127) / 128;
+    if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_spatial_chain_front_c320: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VV_BF16) hipLaunchKernelGGL(chain_front_c320_kernel<BF16>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else if (dtype == VV_F16) hipLaunchKernelGGL(chain_front_c320_kernel<F16>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else VV_FAIL(VV_E_ARG, "vv_spatial_chain_front_c320: bad dtype");
+    VV_CHECK_LAUNCH("vv_spatial_chain_front_c320");
     return VV_OK;
 }

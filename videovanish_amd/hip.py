@@ -82,6 +82,11 @@ class ChainParams(C.Structure):
                 ("n_slabs", C.c_int32), ("n_params", C.c_int32)]
 
 
+class ChainFrontParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("gn_affine", C.c_void_p), ("t_out", C.c_void_p), ("qkv", C.c_void_p), ("stream", C.c_void_p), ("params", C.c_void_p),
+                ("M", C.c_int64), ("HW", C.c_int32), ("C", C.c_int32), ("heads", C.c_int32), ("n_slabs", C.c_int32), ("n_params", C.c_int32)]
+
+
 class AttnParams(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
                 ("q_bs", C.c_int64), ("k_bs", C.c_int64), ("v_bs", C.c_int64), ("o_bs", C.c_int64),
@@ -97,7 +102,7 @@ EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name
            "vv_avgpool2_f32", "vv_corr_lookup", "vv_raft_ctx_split", "vv_raft_flow_prep", "vv_gru_rh", "vv_gru_update", "vv_add_flow",
            "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_deform_im2col", "vv_fc_input", "vv_upsample2x_bilinear", "vv_flow_combine", "vv_gather_rows", "vv_fold_patches", "vv_flow_down4", "vv_gen_compose", "vv_gen_input", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32", "vv_u8_is_zero",
            "vv_raft_prep", "vv_split_f32", "vv_pad_channels_f32", "vv_window_average",
-           "vv_groupnorm_stats", "vv_gn_affine", "vv_motion_module_c320", "vv_split3", "vv_spatial_chain_c320"]
+           "vv_groupnorm_stats", "vv_gn_affine", "vv_motion_module_c320", "vv_split3", "vv_spatial_chain_c320", "vv_spatial_chain_front_c320", "vv_gn_affine_frames"]
 
 
 def lib():
@@ -524,6 +529,31 @@ def spatial_chain_c320(dtype, o, t_in, x, stream_w, params, *, res1=None, out_dt
     with _Prof("spatial_chain_fused[c320]", flops, M * Cc * (2 + 4 + 4 + out.element_size())):
         _check(lib().vv_spatial_chain_c320(C.byref(cp), dtype, _stream()), "vv_spatial_chain_c320")
     return out
+
+
+def spatial_chain_front_c320(dtype, x, gamma, beta, groups, eps, stream_w, params, *, F, HW):
+    """The fused front of a level-0 spatial transformer block (vv_chain.hip): per-frame GroupNorm statistics -> per-channel affine -> ONE kernel for
+    GroupNorm apply + proj_in + LayerNorm + the fused q|k|v projection.  Returns (t fp32 [M,320] = the block's residual stream, qkv h16 head-major
+    [F][3][8][HW][40])."""
+    _need_cuda(x, gamma, beta, stream_w, params)
+    M, Cc = x.shape
+    assert M == F * HW and x.dtype == torch.float32
+    nsplit = lib().vv_groupnorm_nsplit(HW, Cc)
+    ws = torch.empty(F * (nsplit + 1) * groups * 2, dtype=torch.float32, device=x.device)
+    gp = GroupNormParams(in0=x.data_ptr(), in1=0, in_dtype=dt_of(x), C0=Cc, C1=0, F=F, HW=HW, groups=groups, pool_frames=0, eps=eps,
+                         gamma=gamma.data_ptr(), beta=beta.data_ptr(), silu=0, stats_ws=ws.data_ptr(), out=0, out_dtype=F32)
+    with _Prof("groupnorm", 0.0, F * HW * Cc * x.element_size()):
+        _check(lib().vv_groupnorm_stats(C.byref(gp), dtype, _stream()), "vv_groupnorm_stats")
+    aff = torch.empty((F, 2, Cc), dtype=torch.float32, device=x.device)
+    fin = ws.data_ptr() + F * nsplit * groups * 2 * 4
+    _check(lib().vv_gn_affine_frames(C.c_void_p(fin), _p(gamma), _p(beta), Cc, groups, F, _p(aff), _stream()), "vv_gn_affine_frames")
+    t = torch.empty((M, Cc), dtype=torch.float32, device=x.device)
+    qkv = torch.empty((F, 3, 8, HW, Cc // 8), dtype=h16(dtype), device=x.device)
+    fp = ChainFrontParams(x=x.data_ptr(), gn_affine=aff.data_ptr(), t_out=t.data_ptr(), qkv=qkv.data_ptr(), stream=stream_w.data_ptr(),
+                          params=params.data_ptr(), M=M, HW=HW, C=Cc, heads=8, n_slabs=stream_w.shape[0], n_params=params.numel())
+    with _Prof("spatial_chain_front_fused[c320]", 2.0 * M * Cc * Cc * 4, M * Cc * (4 + 4 + 6)):
+        _check(lib().vv_spatial_chain_front_c320(C.byref(fp), dtype, _stream()), "vv_spatial_chain_front_c320")
+    return t, qkv
 
 
 def split3(dtype, x):

@@ -233,8 +233,12 @@ class SelfAttention:
         C, dt, D = self.C, self.ctx.dt, self.C // self.heads
         # head-major QKV ([frame][q|k|v][head][token][D]): a head's K/V rows are contiguous 2*D-byte records, so the K/V tile
         # DMA of the attention kernel reads whole cache lines (the [token][3C] layout over-fetched 2.6x at D = 40)
-        qkv = self.qkv(n, out_dtype=self.ctx.h16, split=(self.heads, D, N))
-        o = torch.empty((B * N, C), dtype=self.ctx.h16, device=n.device)
+        return self.core_qkv(self.qkv(n, out_dtype=self.ctx.h16, split=(self.heads, D, N)), B, N)
+
+    def core_qkv(self, qkv, B, N):
+        """softmax(QK^T)V on a head-major QKV buffer ([frame][q|k|v][head][token][D]) -> h16 [B*N, C]."""
+        C, dt, D = self.C, self.ctx.dt, self.C // self.heads
+        o = torch.empty((B * N, C), dtype=self.ctx.h16, device=qkv.device)
         hip.attention(dt, qkv, qkv, qkv, o, B=B, heads=self.heads, Nq=N, Nkv=N, D=D, q_bs=N * 3 * C, k_bs=N * 3 * C,
                       v_bs=N * 3 * C, o_bs=N * C, q_rs=D, k_rs=D, v_rs=D, o_rs=C, k_off=N * C, v_off=2 * N * C,
                       q_hs=N * D, k_hs=N * D, v_hs=N * D, q_prescaled=self.prescale_q)
@@ -319,14 +323,27 @@ class SpatialTransformer:
             w["out.w"] = wo.reshape(C, C)
             stream, params = packing.pack_chain_stream(w, ctx.h16, cfg.heads)
             self.fused = (ctx.dev(stream), ctx.dev(params))
+            # the front of the block (GroupNorm apply, proj_in, LN1, fused q|k|v projection) as one kernel too
+            f = {}
+            wi, f["in.b"] = src.conv(name + ".proj_in", C, C, 1)
+            f["in.w"] = wi.reshape(C, C)
+            f["ln1.g"], f["ln1.b"] = src.norm(b + ".norm1", C)
+            wq, _ = src.linear(b + ".attn1.to_q", C, C, 1.0, False)
+            wk, _ = src.linear(b + ".attn1.to_k", C, C, 1.0, False)
+            wv, _ = src.linear(b + ".attn1.to_v", C, C, 1.0, False)
+            f["qkv.w"] = torch.cat([wq * hip.attention_q_scale(C // cfg.heads), wk, wv], 0)      # as SelfAttention(prescale_q=True)
+            fs, fp = packing.pack_chain_front_stream(f, ctx.h16)
+            self.front = (ctx.dev(fs), ctx.dev(fp))
 
     def __call__(self, x, F, H, W, out_dtype=torch.float32):
         HW = H * W
+        if self.fused is not None and SpatialTransformer.FUSED and x.dtype == torch.float32:
+            t, qkv = hip.spatial_chain_front_c320(self.ctx.dt, x, self.norm.g, self.norm.b, self.norm.groups, self.norm.eps, self.front[0], self.front[1],
+                                                  F=F, HW=HW)
+            o = self.attn1.core_qkv(qkv, F, HW)
+            return hip.spatial_chain_c320(self.ctx.dt, o, t, x, self.fused[0], self.fused[1], out_dtype=out_dtype)
         h = self.norm(x, F, HW)
         t, _, _ = self.proj_in(h, F, H, W)
-        if self.fused is not None and SpatialTransformer.FUSED and x.dtype == torch.float32:
-            o = self.attn1.core(self.n1(t), F, HW)
-            return hip.spatial_chain_c320(self.ctx.dt, o, t, x, self.fused[0], self.fused[1], out_dtype=out_dtype)
         t = self.attn1.spatial(self.n1(t), t, F, HW)
         t = self.attn2(self.n2(t), t, F, HW)
         t = self.ff(self.n3(t), t)

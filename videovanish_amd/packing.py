@@ -172,3 +172,16 @@ def pack_chain_stream(w, h16, heads=8):
     params = torch.cat([w["o1.b"], w["ln2.g"], w["ln2.b"], w["o2.b"], w["ln3.g"], w["ln3.b"], torch.cat(b1), w["ff2.b"], w["out.b"]]).float()
     assert stream.shape[0] == 462 and params.numel() == 5120
     return stream.contiguous(), params.contiguous()
+
+
+def pack_chain_front_stream(w, h16):
+    """w: dict of fp32 tensors of the FRONT of one spatial transformer block at C = 320 -- in.w [C, C] / in.b (proj_in), ln1.g / ln1.b, qkv.w [3C, C]
+    (attn1 to_q | to_k | to_v stacked; the query rows already carry scale * log2 e).  Returns (stream [100, 64, 64] h16, params [960] fp32) in
+    the consumption order of vv_chain.hip::chain_front_c320_kernel: proj_in (5 x 5 slabs), then 15 row blocks x 5 k tiles of the fused projection."""
+    C = w["in.w"].shape[0]
+    assert C == 320 and w["qkv.w"].shape == (3 * C, C)
+    slabs = _dense_slabs(_permute_k(w["in.w"]), h16, 64) + _dense_slabs(_permute_k(w["qkv.w"]), h16, 64)
+    stream = torch.stack(slabs)
+    params = torch.cat([w["in.b"], w["ln1.g"], w["ln1.b"]]).float()
+    assert stream.shape[0] == 100 and params.numel() == 960
+    return stream.contiguous(), params.contiguous()
