@@ -14,13 +14,13 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("dname,tol", [("fp16", 3e-3), ("bf16", 2.5e-2)])
-@pytest.mark.parametrize("H,W,with_res1", [(6, 8, False), (5, 4, True)])
-def test_fused_motion_module_vs_oracle_and_unfused(gpu, dname, tol, H, W, with_res1):
+@pytest.mark.parametrize("H,W,with_res1,Fr", [(6, 8, False, 32), (5, 4, True, 32), (4, 4, False, 22), (3, 4, True, 17)])      # 22 = the reference's window
+def test_fused_motion_module_vs_oracle_and_unfused(gpu, dname, tol, H, W, with_res1, Fr):
     from oracle import model_ref as M
     from videovanish_amd import nn as vnn
     from videovanish_amd.unet import sinusoidal_pos_emb
     cfg = UNetConfig()
-    C, Fr = 320, 32
+    C = 320
     name = "unet.down_blocks.0.motion_modules.0"
     g = torch.Generator().manual_seed(17)
     x = torch.randn(Fr, C, H, W, generator=g) * 1.5 + 0.2

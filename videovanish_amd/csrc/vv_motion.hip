@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
         __syncthreads();       // parameter block visible
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            const float* xrow = p.x + ((int64_t)(tt * 16 + li) * HW + pixel) * MC;
+            const int fr = min(tt * 16 + li, p.F - 1);                       // clips shorter than 32 frames: the rows past F repeat the last frame (masked as keys, never stored)
+            const float* xrow = p.x + ((int64_t)fr * HW + pixel) * MC;
 #pragma unroll
             for (int s = 0; s < 10; ++s) {
                 const int c0 = 32 * s + 4 * lg, c1 = c0 + 16;
@@ -265,6 +266,11 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
             float inv[2];
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
+                // keys (frames) past the end of a short clip: selects, not a branch (a run-time branch here would cut the head into basic blocks)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sT[kt][qt][r] = (kt * 16 + 4 * lg + r >= p.F) ? -1e30f : sT[kt][qt][r];
                 float m = fmaxf(fmaxf(fmaxf(sT[0][qt][0], sT[0][qt][1]), fmaxf(sT[0][qt][2], sT[0][qt][3])),
                                 fmaxf(fmaxf(sT[1][qt][0], sT[1][qt][1]), fmaxf(sT[1][qt][2], sT[1][qt][3])));
                 m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
         const int64_t row = ((int64_t)(tt * 16 + li) * HW + pixel) * MC;
+        if (tt * 16 + li < p.F)
 #pragma unroll
         for (int j = 0; j < 20; ++j) {
             const int c = 16 * j + 4 * lg;
@@ -393,7 +400,7 @@ extern "C" int vv_motion_module_c320(const vv_motion_params* pp, int dtype, void
     if (!pp) VV_FAIL(VV_E_ARG, "vv_motion_module_c320: null params");
     const vv_motion_params& p = *pp;
     if (!p.x || !p.out || !p.stream || !p.params || !p.gn_affine) VV_FAIL(VV_E_ARG, "vv_motion_module_c320: null pointer");
-    if (p.C != MC || p.F != MF || p.heads != MH) VV_FAIL(VV_E_UNSUPPORTED, "vv_motion_module_c320: built for C = 320, F = 32, 8 heads (got %d, %d, %d)", p.C, p.F, p.heads);
+    if (p.C != MC || p.F < 1 || p.F > MF || p.heads != MH) VV_FAIL(VV_E_UNSUPPORTED, "vv_motion_module_c320: built for C = 320, F <= 32, 8 heads (got %d, %d, %d)", p.C, p.F, p.heads);
     if (p.HW <= 0 || (p.HW & 3)) VV_FAIL(VV_E_UNSUPPORTED, "vv_motion_module_c320: HW = %d must be a positive multiple of 4", p.HW);
     if (p.out_dtype != VV_F32 && p.out_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_motion_module_c320: out_dtype mismatch");
     if (p.n_slabs != N_SLABS || p.n_params != P_TOTAL - 640) VV_FAIL(VV_E_ARG, "vv_motion_module_c320: stream / parameter block size mismatch (%d slabs, %d floats)", p.n_slabs, p.n_params);

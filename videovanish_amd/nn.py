@@ -397,7 +397,8 @@ class MotionModule:
 
     def _run(self, x, F, H, W, res1, out_dtype):
         HW = H * W
-        if (self.fused is not None and MotionModule.FUSED and F == 32 and HW % 4 == 0 and x.dtype == torch.float32
+        # (clips of 16..32 frames: a wave always carries 32 token rows, the rows past F are masked -- e.g. the reference's own 22-frame windows)
+        if (self.fused is not None and MotionModule.FUSED and 16 <= F <= 32 and HW % 4 == 0 and x.dtype == torch.float32
                 and (res1 is None or res1.dtype == torch.float32)):
             return hip.motion_module_c320(self.ctx.dt, x, self.fused[0], self.fused[1], self.norm.g, self.norm.b, self.groups, self.norm.eps,
                                           F=F, HW=HW, res1=res1, out_dtype=out_dtype)
