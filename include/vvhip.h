@@ -33,7 +33,7 @@ enum { VV_BF16 = 0, VV_F16 = 1, VV_F32 = 2, VV_U8 = 3,
        VV_SPLIT3 = 16 /* vv_groupnorm out_dtype only: the K-concatenated split-precision operand [rows][3C] of vv_split3, in the operand dtype */ };
 enum { VV_OK = 0, VV_E_ARG = -1, VV_E_UNSUPPORTED = -2, VV_E_LAUNCH = -3 };
 enum { VV_EPI_NONE = 0, VV_EPI_GEGLU = 1 };
-enum { VV_ACT_NONE = 0, VV_ACT_SILU = 1, VV_ACT_RELU = 2, VV_ACT_LRELU = 3 /* x > 0 ? x : act_slope * x */ };
+enum { VV_ACT_NONE = 0, VV_ACT_SILU = 1, VV_ACT_RELU = 2, VV_ACT_LRELU = 3 /* x > 0 ? x : act_slope * x */, VV_ACT_GELU = 4 /* exact (erf) */, VV_ACT_SIGMOID = 5 };
 
 int vv_abi_version(void);
 const char* vv_last_error(void);

@@ -1,0 +1,193 @@
+"""Video predictor state machine of SAM 2.1: the API the reference's masking step drives --
+`build_sam2_video_predictor` (reference sam2_masker.py:88), `init_state(video_path=frames)` (:93), `add_new_points_or_box` (:122, :135),
+`propagate_in_video` (:147) -- restated from the published `SAM2VideoPredictor` (sam2_video_predictor.py, SAM 2.1: every object is
+tracked independently with batch size 1) [UNVERIFIED-3P].  Pure bookkeeping: every tensor operation is a call into the model object
+(videovanish_amd/sam2_model.py = the HIP kernels; tests plug the CPU oracle into the same state machine).
+
+Kept from upstream: clicks / boxes are scaled from video to model resolution, a box is two points labelled 2 / 3 in front of the clicks, a second
+prompt on a frame feeds the previous low-resolution logits (clamped to +-32) back as the mask prompt, prompted frames are conditioning
+frames whose memory is encoded in the preflight, tracking runs forward from the first conditioning frame (earlier frames are never yielded:
+the reference paints them black, sam2_masker.py:157), masks come back at video resolution as logits (> 0 = object).
+Not built (the reference never uses them): mask prompts, reverse tracking, `reset_state`, `remove_object`, CPU offloading.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+
+class Sam2VideoPredictor:
+    def __init__(self, model, fill_hole_area=None):
+        self.model = model
+        self.cfg = model.cfg
+        self.image_size = model.cfg.image_size
+        self.fill_hole_area = model.cfg.fill_hole_area if fill_hole_area is None else fill_hole_area
+
+    # ---- init_state (sam2_video_predictor.py; the numpy-frames fork takes the frame list where upstream takes a path) ------------
+    def init_state(self, video_path=None, frames=None):
+        frames = video_path if frames is None else frames
+        if not isinstance(frames, (list, tuple)) or len(frames) == 0:
+            raise RuntimeError("init_state: a non-empty list of (H, W, 3) uint8 frames is required")
+        H, W = frames[0].shape[:2]
+        for f in frames:
+            if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] != 3 or f.shape[:2] != (H, W):
+                raise RuntimeError("init_state: frames must be uint8 (H, W, 3) arrays of one size")
+        return {"images": list(frames), "num_frames": len(frames), "video_height": H, "video_width": W,
+                "point_inputs_per_obj": {}, "cached_features": {},
+                "obj_id_to_idx": OrderedDict(), "obj_idx_to_id": OrderedDict(), "obj_ids": [],
+                "output_dict_per_obj": {}, "temp_output_dict_per_obj": {}, "frames_tracked_per_obj": {}}
+
+    def _obj_id_to_idx(self, st, obj_id):
+        idx = st["obj_id_to_idx"].get(obj_id, None)
+        if idx is not None:
+            return idx
+        if any(len(d) for d in st["frames_tracked_per_obj"].values()):
+            raise RuntimeError(f"Cannot add new object id {obj_id} after tracking starts. All existing object ids: {st['obj_ids']}.")
+        idx = len(st["obj_id_to_idx"])
+        st["obj_id_to_idx"][obj_id] = idx
+        st["obj_idx_to_id"][idx] = obj_id
+        st["obj_ids"] = list(st["obj_id_to_idx"])
+        st["point_inputs_per_obj"][idx] = {}
+        st["output_dict_per_obj"][idx] = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+        st["temp_output_dict_per_obj"][idx] = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+        st["frames_tracked_per_obj"][idx] = {}
+        return idx
+
+    def _image_feature(self, st, frame_idx):
+        """one cached frame, as upstream (`cached_features` holds the most recent frame only)."""
+        hit = st["cached_features"].get(frame_idx, None)
+        if hit is None:
+            hit = self.model.encode_image(st["images"][frame_idx])
+            st["cached_features"] = {frame_idx: hit}
+        return hit
+
+    # ---- add_new_points_or_box ---------------------------------------------------------------------------------------------------
+    def add_new_points_or_box(self, inference_state, frame_idx, obj_id, points=None, labels=None, clear_old_points=True,
+                              normalize_coords=True, box=None):
+        st = inference_state
+        obj_idx = self._obj_id_to_idx(st, obj_id)
+        if (points is not None) != (labels is not None):
+            raise ValueError("points and labels must be provided together")
+        if points is None and box is None:
+            raise ValueError("at least one of points or box must be provided as input")
+        pts = torch.zeros(0, 2, dtype=torch.float32) if points is None else torch.as_tensor(np.asarray(points), dtype=torch.float32)
+        lab = torch.zeros(0, dtype=torch.int32) if labels is None else torch.as_tensor(np.asarray(labels), dtype=torch.int32)
+        if pts.dim() == 2:
+            pts = pts[None]
+        if lab.dim() == 1:
+            lab = lab[None]
+        if box is not None:
+            if not clear_old_points:
+                raise ValueError("cannot add box without clearing old points, since box prompt must be provided before any point prompt "
+                                 "(please use clear_old_points=True instead)")
+            b = torch.as_tensor(np.asarray(box), dtype=torch.float32).reshape(1, 2, 2)
+            pts = torch.cat([b, pts], dim=1)
+            lab = torch.cat([torch.tensor([[2, 3]], dtype=torch.int32), lab], dim=1)
+        if normalize_coords:
+            pts = pts / torch.tensor([st["video_width"], st["video_height"]], dtype=torch.float32)
+        pts = pts * self.image_size
+        per_frame = st["point_inputs_per_obj"][obj_idx]
+        old = None if clear_old_points else per_frame.get(frame_idx, None)
+        if old is not None:
+            pts, lab = torch.cat([old["point_coords"], pts], dim=1), torch.cat([old["point_labels"], lab], dim=1)
+        point_inputs = {"point_coords": pts, "point_labels": lab}
+        per_frame[frame_idx] = point_inputs
+        tracked = st["frames_tracked_per_obj"][obj_idx]
+        is_init_cond_frame = frame_idx not in tracked
+        reverse = False if is_init_cond_frame else tracked[frame_idx]["reverse"]
+        out_dict, temp_dict = st["output_dict_per_obj"][obj_idx], st["temp_output_dict_per_obj"][obj_idx]
+        is_cond = is_init_cond_frame                                # add_all_frames_to_correct_as_cond = False
+        key = "cond_frame_outputs" if is_cond else "non_cond_frame_outputs"
+        prev = temp_dict[key].get(frame_idx, None)
+        if prev is None:
+            prev = out_dict["cond_frame_outputs"].get(frame_idx, None)
+        if prev is None:
+            prev = out_dict["non_cond_frame_outputs"].get(frame_idx, None)
+        prev_logits = self.model.clamp_prev_logits(prev["pred_masks"]) if prev is not None and prev["pred_masks"] is not None else None
+        cur = self._run_single_frame_inference(st, out_dict, frame_idx, is_init_cond_frame, point_inputs, reverse, False, prev_logits)
+        temp_dict[key][frame_idx] = cur
+        masks = self._consolidated_video_res(st, frame_idx)
+        return frame_idx, st["obj_ids"], masks
+
+    def _consolidated_video_res(self, st, frame_idx):
+        """_consolidate_temp_output_across_obj(consolidate_at_video_res=True): every object's newest output on this frame, objects without
+        one are filled with NO_OBJ_SCORE."""
+        H, W = st["video_height"], st["video_width"]
+        per_obj = []
+        for obj_idx in range(len(st["obj_ids"])):
+            out = None
+            for d in (st["temp_output_dict_per_obj"][obj_idx], st["output_dict_per_obj"][obj_idx]):
+                for key in ("cond_frame_outputs", "non_cond_frame_outputs"):
+                    if out is None:
+                        out = d[key].get(frame_idx, None)
+            if out is None:
+                per_obj.append(np.full((1, H, W), -1024.0, dtype=np.float32))
+            else:
+                per_obj.append(self.model.to_numpy(self.model.masks_to_video_res(out["pred_masks"], H, W)).reshape(1, H, W))
+        return torch.from_numpy(np.stack(per_obj, axis=0))
+
+    def _run_single_frame_inference(self, st, output_dict, frame_idx, is_init_cond_frame, point_inputs, reverse, run_mem_encoder,
+                                    prev_sam_mask_logits=None):
+        feats = self._image_feature(st, frame_idx)
+        cur = self.model.track_step(frame_idx, is_init_cond_frame, feats, point_inputs, output_dict, st["num_frames"],
+                                    track_in_reverse=reverse, run_mem_encoder=run_mem_encoder, prev_sam_mask_logits=prev_sam_mask_logits)
+        if self.fill_hole_area > 0:
+            cur["pred_masks"] = self.model.fill_holes(cur["pred_masks"])
+        return cur
+
+    # ---- propagate_in_video ------------------------------------------------------------------------------------------------------
+    def propagate_in_video_preflight(self, st):
+        if len(st["obj_ids"]) == 0:
+            raise RuntimeError("No input points or masks are provided for any object; please add inputs first.")
+        for obj_idx, obj_id in enumerate(st["obj_ids"]):
+            out_dict, temp_dict = st["output_dict_per_obj"][obj_idx], st["temp_output_dict_per_obj"][obj_idx]
+            for key in ("non_cond_frame_outputs", "cond_frame_outputs"):
+                for frame_idx, out in temp_dict[key].items():
+                    if out["maskmem_features"] is None:
+                        feats = self._image_feature(st, frame_idx)
+                        out["maskmem_features"], out["maskmem_pos_enc"] = self.model.encode_memory_from_low_res(
+                            feats, out["pred_masks"], out["object_score_logits"], True)
+                    out_dict[key][frame_idx] = out
+                temp_dict[key].clear()
+            if len(out_dict["cond_frame_outputs"]) == 0:
+                raise RuntimeError(f"No input points or masks are provided for object id {obj_id}; please add inputs first.")
+            for frame_idx in out_dict["cond_frame_outputs"]:
+                out_dict["non_cond_frame_outputs"].pop(frame_idx, None)
+
+    def propagate_in_video(self, inference_state, start_frame_idx=None, max_frame_num_to_track=None, reverse=False):
+        st = inference_state
+        if reverse:
+            raise NotImplementedError("reverse tracking is not built (the reference never asks for it, sam2_masker.py:147)")
+        self.propagate_in_video_preflight(st)
+        n = st["num_frames"]
+        if start_frame_idx is None:
+            start_frame_idx = min(t for d in st["output_dict_per_obj"].values() for t in d["cond_frame_outputs"])
+        if max_frame_num_to_track is None:
+            max_frame_num_to_track = n
+        end = min(start_frame_idx + max_frame_num_to_track, n - 1)
+        H, W = st["video_height"], st["video_width"]
+        for frame_idx in range(start_frame_idx, end + 1):
+            per_obj = []
+            for obj_idx in range(len(st["obj_ids"])):
+                out_dict = st["output_dict_per_obj"][obj_idx]
+                if frame_idx in out_dict["cond_frame_outputs"]:
+                    cur = out_dict["cond_frame_outputs"][frame_idx]
+                else:
+                    cur = self._run_single_frame_inference(st, out_dict, frame_idx, False, None, False, True)
+                    out_dict["non_cond_frame_outputs"][frame_idx] = cur
+                st["frames_tracked_per_obj"][obj_idx][frame_idx] = {"reverse": False}
+                per_obj.append(self.model.to_numpy(self.model.masks_to_video_res(cur["pred_masks"], H, W)).reshape(1, H, W))
+            yield frame_idx, st["obj_ids"], torch.from_numpy(np.stack(per_obj, axis=0))       # [objects, 1, H, W] fp32 logits, as upstream
+
+
+def build_sam2_video_predictor(config_file=None, ckpt_path=None, device=None, model=None, dtype="fp16"):
+    """Same call as the reference makes (sam2_masker.py:88).  `config_file` is accepted for signature compatibility: the architecture is
+    the SAM 2.1 Hiera-L configuration it names.  `ckpt_path`: the published `.pt`; a missing file is an error (no silent random weights) unless
+    `model` is handed in."""
+    if model is None:
+        from .sam2_config import Sam2Config
+        from .sam2_model import HipSam2
+        from .sam2_weights import Sam2Weights
+        cfg = Sam2Config()
+        model = HipSam2(cfg, Sam2Weights.from_checkpoint(ckpt_path, cfg), device=device, dtype=dtype)
+    return Sam2VideoPredictor(model)
