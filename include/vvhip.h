@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VV_ABI_VERSION 7
+#define VV_ABI_VERSION 8
 
 enum { VV_BF16 = 0, VV_F16 = 1, VV_F32 = 2, VV_U8 = 3,
        VV_SPLIT3 = 16 /* vv_groupnorm out_dtype only: the K-concatenated split-precision operand [rows][3C] of vv_split3, in the operand dtype */ };
@@ -346,6 +346,56 @@ int vv_decode_blend(const float* dec, int ld, const float* w, int T, int64_t HW,
  * Gaussian taps (sigma 3.5, cv2.getGaussianKernel(21,0)) as fp32 in HOST memory; tmp: T*H*W floats (device). */
 int vv_blur_compose(const float* pix01, const uint8_t* orig, const uint8_t* mask2d, int T, int H, int W,
                     const float* host_taps21, float* tmp, uint8_t* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * SAM 2.1 video predictor (reference sam2_masker.py:88-150 drives the third-party `sam2` package): the kernels of that
+ * path beyond vv_conv_gemm / vv_attention / vv_gather_rows (videovanish_amd/csrc/vv_sam2.hip; host side: videovanish_amd/sam2_model.py).
+ * All activations NHWC ([rows][C]); "h16" = the dtype argument (VV_BF16 / VV_F16).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* uint8 RGB [H][W][3] -> h16: ((x / 255) - mean[c]) * istd[c] (mean3 / istd3: HOST pointers).  s2d = 1: out [H*W][cpad], channels >= 3 zero.
+ * s2d > 1 (space-to-depth): out [(H/s2d)*(W/s2d)][cpad], channel (dy*s2d + dx)*3 + c = pixel (s2d*Y + dy, s2d*X + dx): a k x k stride-s2d convolution
+ * becomes a stride-1 convolution over blocks (the patch embedding of the Hiera trunk: 7x7 stride 4 -> 2x2 over 48 channels) */
+int vv_u8_normalize(const uint8_t* src, int H, int W, const float* mean3, const float* istd3, void* out, int cpad, int s2d, int dtype, void* stream);
+/* LayerNorm over the last dim of fp32 [M][C] (any C), given eps, optional VV_ACT_* after the affine, out h16 or fp32 (LayerNorm2d of NCHW
+ * modules is this on NHWC rows) */
+int vv_layernorm_ex(const float* x, int64_t M, int C, const float* gamma, const float* beta, float eps, int act, void* out, int out_dtype,
+                    int cpad /* output row length >= C (0 = C): columns past C are written as zeros */, int dtype, void* stream);
+/* 2x2 / stride-2 max pooling of [B][H][W][C] (fp32 or h16, even H and W); in_bs: elements between input batches (0 = H*W*C) */
+int vv_maxpool2x2(const void* x, int x_dtype, int B, int H, int W, int C, int64_t in_bs, void* out, void* stream);
+/* rotary encoding in place on an h16 matrix: for rows r < rows_rope the column pairs (col0 + 2i, col0 + 2i + 1), i < D/2, are rotated by
+ * cos_sin[(r % n_table)][i] = (cos, sin)   (compute_axial_cis / apply_rotary_enc; r % n_table = rope_k_repeat) */
+int vv_rope_apply(void* x, int64_t rows_rope, int ld, int col0, int D, const float* cos_sin, int n_table, int dtype, void* stream);
+/* depthwise k x k convolution (zero padding k/2), fp32 [H][W][C], weights [C][k][k] */
+int vv_dwconv(const float* x, int H, int W, int C, const float* w, const float* bias, int k, float* out, void* stream);
+/* tail of ConvTranspose2d(kernel 2, stride 2): y [h*w][4*C] with columns (dy, dx, c) -> out [2h*2w][C] = act(y + bias (+ add)) */
+int vv_pixel_shuffle2(const float* y, const float* bias, const float* add, int h, int w, int C, int act, void* out, int out_dtype, int dtype,
+                      void* stream);
+/* bilinear resize of fp32 [Hs][Ws][C] with torch semantics (align_corners = False, no antialias) */
+int vv_resize_bilinear_f32(const float* src, int Hs, int Ws, int C, float* dst, int Hd, int Wd, void* stream);
+/* mask logits -> input of the memory encoder's mask downsampler: (binarize ? (x > 0) : sigmoid(x)) * scale + bias, h16 [n][8] (channel 0) */
+int vv_mask_mem_input(const float* logits, int64_t n, int binarize, float scale, float bias, void* out, int dtype, void* stream);
+/* in-place activation (VV_ACT_RELU / GELU / SIGMOID / SILU) on fp32 or h16 */
+int vv_act(void* x, int x_dtype, int64_t n, int act, void* stream);
+/* prompt encoder: out[p] = label < 0 ? table[0] : pe((coords[p] + 0.5) * inv_size) + table[label + 1]; pe(c) = [sin | cos](2 pi (2c - 1) @ gauss);
+ * table [5][D] = not_a_point_embed, point_embeddings 0..3 */
+int vv_prompt_points(const float* coords, const int32_t* labels, int P, float inv_size, const float* gauss, const float* table, int D, float* out,
+                     void* stream);
+/* get_1d_sine_pe: out [n][dim] = [sin(pos / t_j) | cos(pos / t_j)] */
+int vv_sine_pe_1d(const float* pos, int n, int dim, float temperature, float* out, void* stream);
+/* decoder output selection: sel[0] = mask index (multimask: argmax of iou[1..]; else mask 0 if its stability score >= thresh, else that argmax),
+ * sel[1] = (obj_logit > 0), sel[2] = output-token index for the object pointer */
+int vv_sam_select(const float* masks, int HW, int nm, const float* iou, const float* obj_logit, int multimask, float delta, float thresh,
+                  int32_t* sel, void* stream);
+/* out [HW] = sel[1] ? masks[sel[0]] : no_obj_score */
+int vv_sam_pick(const float* masks, int HW, const int32_t* sel, float no_obj_score, float* out, void* stream);
+/* out = flag[0] ? a : b ;  x[m][c] += vec[c] unless score[0] > 0 (no_obj_embed_spatial of the memory encoder) ;  out = clamp(x, lo, hi) */
+int vv_select_f32(const float* a, const float* b, const int32_t* flag, int64_t n, float* out, void* stream);
+int vv_add_rowvec_unless(float* x, const float* vec, const float* score, int64_t M, int C, void* stream);
+int vv_clamp_f32(const float* x, int64_t n, float lo, float hi, float* out, void* stream);
+/* masks [nm][HW] = hyper [nm][C] @ up [HW][C]^T (fp32; the mask decoder's hypernetwork product), nm <= 8 */
+int vv_hyper_masks(const float* hyper, const float* up, int HW, int C, int nm, float* masks, void* stream);
+/* fill_holes_in_mask_scores: 8-connected components of (mask <= 0) with area <= max_area are set to 0.1; ws: 3*H*W int32 */
+int vv_fill_holes(float* mask, int H, int W, int max_area, int32_t* ws, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,190 @@
+"""SAM 2 masking step, CPU side: the drop-in `sam2_masker` against fixtures captured from the REAL reference module
+(tests/golden/make_sam2_masker_fixtures.py ran /root/reference/sam2_masker.py under stub `cv2` / `sam2` modules), the architecture manifest
+against the published parameter count, the predictor state machine on the fp32 oracle, and the host-side helpers."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sam2_masker
+from videovanish_amd.sam2_config import SMALL_SAM2, TINY_SAM2, Sam2Config, hiera_blocks, select_memories
+from videovanish_amd.sam2_predictor import Sam2VideoPredictor
+from videovanish_amd.sam2_weights import Sam2Weights, manifest, parameter_count
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class _RecordingPredictor:
+    """what the fixture generator's stub predictor does: records the calls, yields seeded random logits from the first prompted frame to T-2."""
+
+    def __init__(self, T, H, W):
+        self.calls, self.T, self.H, self.W = [], T, H, W
+
+    def init_state(self, video_path=None):
+        self.calls.append({"op": "init_state", "n_frames": len(video_path), "shape": list(video_path[0].shape)})
+        self.first, self.objs = None, []
+        return {}
+
+    def add_new_points_or_box(self, inference_state, frame_idx, obj_id, points=None, labels=None, box=None):
+        c = {"op": "add", "frame_idx": int(frame_idx), "obj_id": int(obj_id), "frame_type": type(frame_idx).__name__}
+        if points is not None:
+            c.update(points=np.asarray(points).tolist(), points_dtype=str(np.asarray(points).dtype), labels=np.asarray(labels).tolist(),
+                     labels_dtype=str(np.asarray(labels).dtype))
+        if box is not None:
+            c.update(box=np.asarray(box).tolist(), box_dtype=str(np.asarray(box).dtype))
+        self.calls.append(c)
+        if obj_id not in self.objs:
+            self.objs.append(obj_id)
+        self.first = frame_idx if self.first is None else min(self.first, frame_idx)
+
+    def propagate_in_video(self, inference_state):
+        self.calls.append({"op": "propagate"})
+        g = torch.Generator().manual_seed(123)
+        for t in range(self.first, self.T - 1):
+            yield t, list(self.objs), torch.randn(len(self.objs), 1, self.H, self.W, generator=g) - 0.4
+
+
+def test_drop_in_against_the_reference_fixtures(monkeypatch):
+    """same annotations -> the same predictor calls (coordinates, dtypes, order), the same prog sequence, the same painted frames as the
+    reference module produced (reference sam2_masker.py:93-175)."""
+    fx = json.load(open(os.path.join(GOLD, "sam2_masker_calls.json")))
+    want = np.load(os.path.join(GOLD, "sam2_masker_frames.npz"))["out"]
+    H0, W0, T = fx["H0"], fx["W0"], fx["T"]
+    frames = [np.random.default_rng(5).integers(0, 256, (H0, W0, 3), dtype=np.uint8) for _ in range(T)]
+    p = _RecordingPredictor(T, H0, W0)
+    asked = []
+    monkeypatch.setattr(sam2_masker, "color_for_obj", lambda i: (asked.append(i), tuple(fx["stub_colours"][str(i)]))[1])
+    prog = []
+    try:
+        sam2_masker.configure(p)
+        got = sam2_masker.run_sam2_on_frames(frames, fx["annotations"], prog=lambda a, b: prog.append([a, b]))
+    finally:
+        sam2_masker.configure(None)
+    assert p.calls == fx["calls"]
+    assert prog == fx["prog"]
+    assert np.array_equal(np.stack(got), want)
+    assert not want[0].any() and not want[-1].any() and want[1].any()        # frames the predictor never yields stay black
+    assert [sam2_masker.SAM2_MODEL_CFG, sam2_masker.SAM2_CHECKPOINT] == fx["build"][:2]
+    # the hue the reference asks cv2 for: (obj * 37) % 180 at s = 200, v = 255 (reference :31-35)
+    assert fx["hsv_requests"][:3] == [[37, 200, 255, 54], [74, 200, 255, 54], [111, 200, 255, 54]]
+
+
+def test_color_for_obj_is_opencv_hsv_to_bgr():
+    """OpenCV's 8-bit HSV -> BGR at s = 200, v = 255: V on the dominant channel, V (1 - S) = 55 on the weakest, a linear ramp between."""
+    assert sam2_masker.color_for_obj(0) == (55, 55, 255)                      # h = 0: red
+    c = {i: sam2_masker.color_for_obj(i) for i in range(1, 30)}
+    for i, (b, g, r) in c.items():
+        assert max(b, g, r) == 255 and min(b, g, r) == 55
+        h = (i * 37) % 180
+        sector, f = divmod(h / 30.0, 1.0)
+        mid = sorted((b, g, r))[1]
+        ramp = 255 * (1 - (200 / 255) * (f if int(sector) % 2 else 1 - f))
+        assert abs(mid - ramp) <= 0.51
+    assert c[1] == (55, 255, 208) and c[5] == (55, 88, 255)                   # h = 37 (yellow-green), h = 5 (red-orange): hand-checked values
+    assert len(set(c.values())) == len(c)
+
+
+def test_manifest_is_the_published_architecture():
+    man = manifest()
+    assert parameter_count(man) == 224_446_898                                # "224.4 M" (SAM 2.1 Hiera-L, published)
+    assert parameter_count({k: v for k, v in man.items() if k.startswith("image_encoder.trunk.")}) == 212_149_296
+    blocks, ends = hiera_blocks(Sam2Config())
+    assert ends == [1, 7, 43, 47] and len(blocks) == 48
+    assert [i for i, b in enumerate(blocks) if b["q_stride"]] == [2, 8, 44]
+    assert [i for i, b in enumerate(blocks) if b["window"] == 0] == [23, 33, 43]
+    assert [(b["dim_out"], b["heads"]) for b in (blocks[0], blocks[2], blocks[8], blocks[44])] == [(144, 2), (288, 4), (576, 8), (1152, 16)]
+    assert [blocks[i]["window"] for i in (0, 2, 3, 8, 9, 44, 45)] == [8, 8, 4, 4, 16, 16, 8]      # the window size lags the stage change by one block
+    # names a real checkpoint is matched against, spot checks
+    for name, shape in (("image_encoder.trunk.pos_embed", (1, 144, 7, 7)), ("image_encoder.trunk.blocks.2.proj.weight", (288, 144)),
+                        ("image_encoder.neck.convs.0.conv.weight", (256, 1152, 1, 1)), ("memory_attention.layers.3.cross_attn_image.k_proj.weight", (256, 64)),
+                        ("memory_encoder.mask_downsampler.encoder.9.weight", (256, 64, 3, 3)), ("memory_encoder.fuser.layers.1.dwconv.weight", (256, 1, 7, 7)),
+                        ("sam_mask_decoder.output_upscaling.0.weight", (256, 64, 2, 2)), ("sam_mask_decoder.transformer.layers.1.cross_attn_token_to_image.q_proj.weight", (128, 256)),
+                        ("maskmem_tpos_enc", (7, 1, 1, 64)), ("obj_ptr_tpos_proj.weight", (64, 256)), ("sam_prompt_encoder.pe_layer.positional_encoding_gaussian_matrix", (2, 128))):
+        assert tuple(man[name][0]) == shape, name
+
+
+def test_checkpoint_validation_names_every_mismatch(tmp_path):
+    w = Sam2Weights(TINY_SAM2, 3)
+    sd = {n: w.get(n) for n in w.man}
+    path = str(tmp_path / "tiny.pt")
+    torch.save({"model": sd}, path)
+    loaded = Sam2Weights.from_checkpoint(path, TINY_SAM2)
+    assert all(torch.equal(loaded.get(n), sd[n]) for n in list(sd)[:40])
+    del sd["no_obj_ptr"]
+    sd["obj_ptr_tpos_proj.weight"] = torch.zeros(3, 3)
+    torch.save({"model": sd}, path)
+    with pytest.raises(ValueError) as e:
+        Sam2Weights.from_checkpoint(path, TINY_SAM2)
+    assert "'no_obj_ptr' missing" in str(e.value) and "'obj_ptr_tpos_proj.weight' has shape (3, 3)" in str(e.value)
+    with pytest.raises(FileNotFoundError):
+        Sam2Weights.from_checkpoint(str(tmp_path / "absent.pt"))
+    with pytest.raises(ValueError, match="does not fit the architecture"):
+        Sam2Weights.from_checkpoint(path, SMALL_SAM2)
+
+
+def test_memory_selection_follows_the_published_rule():
+    cfg = Sam2Config()
+    out = lambda t: {"t": t}
+    od = {"cond_frame_outputs": {2: out(2), 40: out(40)}, "non_cond_frame_outputs": {t: out(t) for t in range(3, 30)}}
+    mems, ptrs, max_ptrs = select_memories(cfg, 30, od, 100)
+    # both conditioning frames at t_pos 0, then the six frames before frame 30, oldest first (t_pos 1 = 6 frames back)
+    assert [(tp, o["t"]) for tp, o in mems] == [(0, 2), (0, 40), (1, 24), (2, 25), (3, 26), (4, 27), (5, 28), (6, 29)]
+    # pointers: conditioning frames in the PAST only (frame 40 is in the future), then the 15 previous frames
+    assert max_ptrs == 16 and [(d, o["t"]) for d, o in ptrs] == [(28, 2)] + [(d, 30 - d) for d in range(1, 16)]
+    mems, ptrs, max_ptrs = select_memories(cfg, 3, {"cond_frame_outputs": {2: out(2)}, "non_cond_frame_outputs": {}}, 5)
+    assert [(tp, o["t"]) for tp, o in mems] == [(0, 2)] and [(d, o["t"]) for d, o in ptrs] == [(1, 2)] and max_ptrs == 5
+
+
+def test_predictor_state_machine_on_the_oracle():
+    from oracle.sam2_ref import OracleSam2
+    model = OracleSam2(TINY_SAM2, seed=1)
+    p = Sam2VideoPredictor(model)
+    rng = np.random.default_rng(0)
+    frames = [rng.integers(0, 256, (64, 96, 3), dtype=np.uint8) for _ in range(5)]
+    st = p.init_state(video_path=frames)
+    with pytest.raises(RuntimeError, match="No input points or masks are provided for any object"):
+        next(p.propagate_in_video(st))
+    with pytest.raises(ValueError, match="at least one of points or box"):
+        p.add_new_points_or_box(st, 0, 1)
+    st = p.init_state(video_path=frames)                                      # (the refused call had already registered object 1, as upstream does)
+    t, ids, m = p.add_new_points_or_box(st, 2, 7, points=np.array([[48.0, 32.0]], dtype=np.float32), labels=np.array([1], dtype=np.int32))
+    assert (t, ids) == (2, [7]) and tuple(m.shape) == (1, 1, 64, 96) and m.dtype == torch.float32
+    # clicks are scaled from video to model resolution: (48, 32) of 96 x 64 -> the centre of the 128 x 128 model image
+    assert torch.equal(st["point_inputs_per_obj"][0][2]["point_coords"], torch.tensor([[[64.0, 64.0]]]))
+    # a box replaces the clicks of that object on that frame and arrives as two points labelled 2, 3; the previous logits are fed back
+    t, ids, m2 = p.add_new_points_or_box(st, 2, 7, box=np.array([24.0, 16.0, 72.0, 48.0], dtype=np.float32))
+    assert st["point_inputs_per_obj"][0][2]["point_labels"].tolist() == [[2, 3]]
+    assert not torch.equal(m, m2)
+    p.add_new_points_or_box(st, 2, 9, points=np.array([[10.0, 10.0]], dtype=np.float32), labels=np.array([1], dtype=np.int32))
+    seen = list(p.propagate_in_video(st))
+    assert [s[0] for s in seen] == [2, 3, 4] and all(s[1] == [7, 9] and tuple(s[2].shape) == (2, 1, 64, 96) for s in seen)
+    assert torch.equal(seen[0][2][0], m2[0])                                  # the conditioning frame is reported as prompted, not re-inferred
+    od = st["output_dict_per_obj"][0]
+    assert sorted(od["cond_frame_outputs"]) == [2] and sorted(od["non_cond_frame_outputs"]) == [3, 4]
+    assert od["cond_frame_outputs"][2]["maskmem_features"] is not None        # encoded in the preflight
+    with pytest.raises(RuntimeError, match="Cannot add new object id"):
+        p.add_new_points_or_box(st, 3, 11, points=np.array([[1.0, 1.0]], dtype=np.float32), labels=np.array([1], dtype=np.int32))
+    # deterministic: a second predictor on the same inputs gives identical logits
+    p2 = Sam2VideoPredictor(OracleSam2(TINY_SAM2, seed=1))
+    st2 = p2.init_state(video_path=frames)
+    p2.add_new_points_or_box(st2, 2, 7, points=np.array([[48.0, 32.0]], dtype=np.float32), labels=np.array([1], dtype=np.int32))
+    p2.add_new_points_or_box(st2, 2, 7, box=np.array([24.0, 16.0, 72.0, 48.0], dtype=np.float32))
+    p2.add_new_points_or_box(st2, 2, 9, points=np.array([[10.0, 10.0]], dtype=np.float32), labels=np.array([1], dtype=np.int32))
+    assert all(torch.equal(a[2], b[2]) for a, b in zip(seen, p2.propagate_in_video(st2)))
+
+
+def test_oracle_hole_filling_and_product_imports():
+    from oracle.sam2_ref import OracleSam2
+    m = OracleSam2(TINY_SAM2, seed=0)
+    lo = 4 * TINY_SAM2.feat_size
+    x = torch.ones(1, 1, lo, lo)
+    x[0, 0, 3, 3] = -1.0
+    x[0, 0, 10, 10:19] = -1.0                                                 # area 9 > 8: kept
+    y = m.fill_holes(x)
+    assert float(y[0, 0, 3, 3]) == pytest.approx(0.1) and float(y[0, 0, 10, 12]) == -1.0
+    # the product modules never import the oracle
+    for f in ("sam2_masker.py", "videovanish_amd/sam2_model.py", "videovanish_amd/sam2_predictor.py", "videovanish_amd/sam2_weights.py", "videovanish_amd/sam2_config.py"):
+        src = open(os.path.join(os.path.dirname(GOLD), "..", f)).read()
+        assert "import oracle" not in src and "from oracle" not in src

@@ -1,0 +1,263 @@
+"""SAM 2.1 video predictor on the HIP kernels against the fp32 CPU oracle (oracle/sam2_ref.py), through the C ABI.
+
+Kernel-level: every new entry point of vv_sam2.hip against a torch / scipy restatement of the same op.  Model-level: image encoder, prompted
+frame, memory encoder, memory-conditioned tracking and the drop-in `sam2_masker.run_sam2_on_frames` on two structurally complete small
+configurations (TINY: head dims 32 / 64; SMALL: trunk head dim 72 -> padded 80, memory attention head dim 256), same seeded weights and inputs.
+Tolerances: fp16 MFMA operands against fp32 -> relative max-abs error of feature maps / logits; masks compared as the fraction of pixels whose
+sign differs (pixels with |logit| below the error bar may flip)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+@pytest.fixture(scope="module")
+def hipmod():
+    from videovanish_amd import hip
+    hip.lib()
+    return hip
+
+
+# ---- kernels ------------------------------------------------------------------------------------------------------------------------
+def test_layernorm_ex_and_act(hipmod):
+    hip = hipmod
+    g = torch.Generator().manual_seed(0)
+    for M, C, eps, act, cpad in ((37, 144, 1e-6, hip.ACT_NONE, None), (1000, 4, 1e-6, hip.ACT_GELU, 8), (9, 256, 1e-5, hip.ACT_NONE, None),
+                                 (513, 1152, 1e-6, hip.ACT_NONE, None)):
+        x = torch.randn(M, C, generator=g) * 3 + 1
+        ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        ref = F.layer_norm(x, (C,), ga, be, eps)
+        if act == hip.ACT_GELU:
+            ref = F.gelu(ref)
+        out32 = hip.layernorm_ex(hip.F16, x.to(_dev()), ga.to(_dev()), be.to(_dev()), eps, act=act, out_dtype=torch.float32, cpad=cpad)
+        out16 = hip.layernorm_ex(hip.F16, x.to(_dev()), ga.to(_dev()), be.to(_dev()), eps, act=act, cpad=cpad)
+        assert out32.shape == (M, cpad or C) and out16.dtype == torch.float16
+        assert _rel(out32[:, :C], ref) < 2e-5 and _rel(out16[:, :C], ref) < 1.5e-3
+        if cpad:
+            assert float(out32[:, C:].abs().max()) == 0.0 and float(out16[:, C:].float().abs().max()) == 0.0
+    x = torch.randn(1000, generator=g).to(_dev())
+    for act, fn in ((hip.ACT_GELU, F.gelu), (hip.ACT_RELU, F.relu), (hip.ACT_SIGMOID, torch.sigmoid)):
+        assert _rel(hip.act_inplace(x.clone(), act), fn(x.cpu())) < 1e-5
+        assert _rel(hip.act_inplace(x.half(), act), fn(x.half().float().cpu())) < 1.5e-3
+
+
+def test_maxpool_and_pixel_shuffle_and_resize(hipmod):
+    hip = hipmod
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 8, 12, 20, generator=g)                                              # [B, H, W, C]
+    ref = F.max_pool2d(x.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).reshape(-1, 20)
+    assert torch.equal(hip.maxpool2x2(x.reshape(-1, 20).to(_dev()), 3, 8, 12).cpu(), ref)
+    xh = x.half()
+    assert torch.equal(hip.maxpool2x2(xh.reshape(-1, 20).to(_dev()), 3, 8, 12).cpu(), ref.half())
+    # strided batches: image b starts in_bs elements after image b-1 (the q block of a head-major QKV buffer)
+    buf = torch.randn(3, 3, 8 * 12 * 20, generator=g)
+    ref = F.max_pool2d(buf[:, 0].reshape(3, 8, 12, 20).permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).reshape(-1, 20)
+    assert torch.equal(hip.maxpool2x2(buf.reshape(-1, 20).to(_dev()), 3, 8, 12, Cc=20, in_bs=3 * 8 * 12 * 20).cpu(), ref)
+    # ConvTranspose2d(k 2, s 2) = GEMM + pixel shuffle
+    cin, cout, h, w = 16, 8, 5, 7
+    xi, wt, b = torch.randn(1, cin, h, w, generator=g), torch.randn(cin, cout, 2, 2, generator=g), torch.randn(cout, generator=g)
+    add = torch.randn(1, cout, 2 * h, 2 * w, generator=g)
+    ref = F.gelu(F.conv_transpose2d(xi, wt, b, stride=2) + add).permute(0, 2, 3, 1).reshape(-1, cout)
+    y = xi.permute(0, 2, 3, 1).reshape(-1, cin) @ wt.permute(2, 3, 1, 0).reshape(-1, cin).T
+    out = hip.pixel_shuffle2(hip.F16, y.contiguous().to(_dev()), b.to(_dev()), h, w, add=add.permute(0, 2, 3, 1).reshape(-1, cout).contiguous().to(_dev()),
+                             act=hip.ACT_GELU)
+    assert _rel(out, ref) < 1e-5
+    # bilinear resize, torch semantics, up and down, multi-channel
+    for (Hs, Ws, Hd, Wd, C) in ((16, 16, 64, 64, 1), (32, 24, 45, 80, 3), (64, 64, 24, 40, 1)):
+        s = torch.randn(1, C, Hs, Ws, generator=g)
+        ref = F.interpolate(s, size=(Hd, Wd), mode="bilinear", align_corners=False).permute(0, 2, 3, 1).reshape(-1, C)
+        out = hip.resize_bilinear_f32(s.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(_dev()), Hs, Ws, Hd, Wd)
+        assert _rel(out, ref) < 1e-5
+
+
+def test_rope_dwconv_positional_kernels(hipmod):
+    hip = hipmod
+    from oracle import sam2_ref
+    g = torch.Generator().manual_seed(2)
+    fs, D = 4, 64
+    cis = sam2_ref.axial_cis(D, fs, fs)
+    cs = torch.stack([cis.real, cis.imag], dim=-1).float().contiguous().to(_dev())
+    x = torch.randn(1, 1, 2 * fs * fs + 4, D, generator=g).half().float()
+    nk = 2 * fs * fs
+    ref = torch.cat([sam2_ref.apply_rope(x[:, :, :nk], cis, repeat=True), x[:, :, nk:]], dim=2)[0, 0]
+    xd = x[0, 0].half().contiguous().to(_dev())
+    hip.rope_apply(hip.F16, xd, nk, cs, D)
+    assert _rel(xd, ref) < 1.5e-3 and torch.equal(xd[nk:].cpu(), x[0, 0, nk:].half())
+    # depthwise 7x7
+    C, H, W = 24, 9, 11
+    xi, wt, b = torch.randn(1, C, H, W, generator=g), torch.randn(C, 1, 7, 7, generator=g), torch.randn(C, generator=g)
+    ref = F.conv2d(xi, wt, b, padding=3, groups=C).permute(0, 2, 3, 1).reshape(-1, C)
+    out = hip.dwconv(xi.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(_dev()), H, W, wt.reshape(C, 7, 7).contiguous().to(_dev()), b.to(_dev()))
+    assert _rel(out, ref) < 1e-5
+    # 1-D sine encoding, prompt point encoding
+    pos = torch.tensor([0.0, 1.0 / 15, -3.0 / 15, 7.0 / 15])
+    assert _rel(hip.sine_pe_1d(pos.to(_dev()), 64), sam2_ref.sine_pe_1d(pos, 64)) < 1e-5
+    gauss, table = torch.randn(2, 32, generator=g), torch.randn(5, 64, generator=g)
+    coords = torch.tensor([[10.0, 20.0], [100.5, 3.25], [0.0, 0.0], [64.0, 127.0]])
+    labels = torch.tensor([1, 0, -1, 3], dtype=torch.int32)
+    c = (2 * ((coords + 0.5) / 128.0) - 1) @ gauss * (2 * np.pi)
+    ref = torch.cat([torch.sin(c), torch.cos(c)], dim=-1)
+    ref[labels == -1] = 0.0
+    ref = ref + table[(labels + 1).long()]
+    out = hip.prompt_points(coords.to(_dev()), labels.to(_dev()), 1.0 / 128.0, gauss.to(_dev()), table.to(_dev()))
+    assert _rel(out, ref) < 2e-5
+
+
+def test_mask_selection_and_hole_filling(hipmod):
+    hip = hipmod
+    from scipy import ndimage
+    g = torch.Generator().manual_seed(3)
+    hyper, up = torch.randn(4, 32, generator=g), torch.randn(400, 32, generator=g)
+    masks = hip.hyper_masks(hyper.to(_dev()), up.to(_dev()))
+    assert _rel(masks, hyper @ up.T) < 1e-5
+    m = (hyper @ up.T).contiguous()
+    for multimask, iou, obj in ((True, [0.9, 0.2, 0.7, 0.4], 1.0), (False, [0.9, 0.2, 0.7, 0.4], 1.0), (False, [0.1, 0.3, 0.3, 0.2], -2.0)):
+        sel = hip.sam_select(m.to(_dev()), torch.tensor(iou).to(_dev()), torch.tensor([obj]).to(_dev()), multimask, 0.05, 0.98).cpu()
+        best = 1 + int(np.argmax(iou[1:]))
+        ai, au = float((m[0] > 0.05).sum()), float((m[0] > -0.05).sum())
+        stable = (ai / au if au > 0 else 1.0) >= 0.98
+        assert int(sel[0]) == (best if multimask else (0 if stable else best)) and int(sel[1]) == int(obj > 0) and int(sel[2]) == (best if multimask else 0)
+        low = hip.sam_pick(m.to(_dev()), sel.to(_dev()), -1024.0).cpu()
+        assert torch.equal(low, m[int(sel[0])] if obj > 0 else torch.full_like(low, -1024.0))
+    # stable single mask: a mask far from the +-delta band
+    big = torch.cat([torch.full((1, 400), 5.0), m[1:]], dim=0)
+    sel = hip.sam_select(big.to(_dev()), torch.tensor([0.1, 0.2, 0.7, 0.4]).to(_dev()), torch.tensor([1.0]).to(_dev()), False, 0.05, 0.98).cpu()
+    assert int(sel[0]) == 0
+    # hole filling: random blobs + hand-placed holes of area 1..10, 8-connectivity, including a diagonal chain and a hole on the border
+    H = W = 64
+    base = (torch.rand(H, W, generator=g) > 0.35).float() * 2 - 1                                   # noisy: many tiny components
+    base[20:44, 20:44] = 1.0
+    base[22, 22] = -1.0                                                                              # area 1
+    for j in range(4):
+        base[25 + j, 25 + j] = -1.0                                                                  # diagonal chain, area 4 (8-connected)
+    base[32, 22:27] = -1.0
+    base[33:36, 26] = -1.0                                                                           # L shape, area 8: filled
+    base[38, 22:31] = -1.0                                                                           # area 9: kept
+    base[0, 0:3], base[1, 0:4], base[0, 3] = -1.0, 1.0, 1.0                                           # area 3 on the border
+    ref = base.clone()
+    lab, n = ndimage.label((base <= 0).numpy(), structure=np.ones((3, 3), dtype=bool))
+    areas = np.bincount(lab.ravel())
+    ref[torch.from_numpy((lab > 0) & (areas[lab] <= 8))] = 0.1
+    out = hip.fill_holes(base.reshape(-1).clone().to(_dev()), H, W, 8).cpu().reshape(H, W)
+    assert torch.equal(out, ref)
+    assert int((ref == 0.1).sum()) > 10 and int((ref <= 0).sum()) > 10                              # both outcomes occur
+    assert _rel(hip.clamp_f32(torch.tensor([-40.0, 3.0, 50.0]).to(_dev()), -32.0, 32.0), torch.tensor([-32.0, 3.0, 32.0])) == 0.0
+
+
+# ---- model --------------------------------------------------------------------------------------------------------------------------
+def _models(cfg, seed=5):
+    from oracle.sam2_ref import OracleSam2
+    from videovanish_amd.sam2_model import HipSam2
+    from videovanish_amd.sam2_weights import Sam2Weights
+    w = Sam2Weights(cfg, seed)
+    return OracleSam2(cfg, w), HipSam2(cfg, w, device="cuda:0", dtype="fp16")
+
+
+def _frames(n, H, W, seed=0):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (H + 8 * n, W + 8 * n, 3), dtype=np.uint8)
+    ys, xs = np.mgrid[0:H + 8 * n, 0:W + 8 * n]
+    base = (base // 4 + (96 + 64 * np.sin(ys / 9.0)[..., None] + 64 * np.cos(xs / 7.0)[..., None])).clip(0, 255).astype(np.uint8)   # structure + noise
+    return [np.ascontiguousarray(base[3 * t:3 * t + H, 5 * t:5 * t + W]) for t in range(n)]                                         # a drifting crop
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_image_encoder_and_prompted_frame(name):
+    from videovanish_amd.sam2_config import SMALL_SAM2, TINY_SAM2
+    cfg = {"tiny": TINY_SAM2, "small": SMALL_SAM2}[name]
+    ora, hipm = _models(cfg)
+    S, fs, D = cfg.image_size, cfg.feat_size, cfg.d_model
+    frame = _frames(1, S, S + 16)[0]                                                        # not square: exercises the bit-exact uint8 resize
+    fo, fh = ora.encode_image(frame), hipm.encode_image(frame)
+    nhwc = lambda t: t[0].permute(1, 2, 0).reshape(-1, t.shape[1])
+    e_top, e_s1, e_s0 = _rel(fh["top"], nhwc(fo["fpn"][2])), _rel(fh["s1"], nhwc(fo["fpn"][1])), _rel(fh["s0"], nhwc(fo["fpn"][0]))
+    print(f"sam2_image_encoder[{name}]: rel max-abs top {e_top:.2e} s1 {e_s1:.2e} s0 {e_s0:.2e}")
+    assert max(e_top, e_s1, e_s0) < 6e-3
+    # a prompted (initial conditioning) frame: clicks -> multimask path, a box -> single-mask path with the stability test
+    for pts, labs in (([[0.4 * S, 0.5 * S]], [1]), ([[0.2 * S, 0.2 * S], [0.7 * S, 0.8 * S]], [2, 3]), ([[0.5 * S, 0.5 * S], [0.1 * S, 0.9 * S]], [1, 0])):
+        pi = {"point_coords": torch.tensor([pts], dtype=torch.float32), "point_labels": torch.tensor([labs], dtype=torch.int32)}
+        o = ora.track_step(0, True, fo, pi, {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}, 1, run_mem_encoder=True)
+        h = hipm.track_step(0, True, fh, pi, {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}, 1, run_mem_encoder=True)
+        lo = 4 * fs
+        mo, mh = o["pred_masks"].reshape(-1), h["pred_masks"].cpu().reshape(-1)
+        e_m, e_p = _rel(mh, mo), _rel(h["obj_ptr"], o["obj_ptr"])
+        flips = float(((mo > 0) != (mh > 0)).float().mean())
+        e_mem = _rel(h["maskmem_features"], nhwc(o["maskmem_features"]))
+        print(f"sam2_prompted_frame[{name},{len(labs)} pts]: logits rel {e_m:.2e} sign flips {flips:.2e} obj_ptr rel {e_p:.2e} memory rel {e_mem:.2e} "
+              f"object score {float(o['object_score_logits']):.3f} / {float(h['object_score_logits'].cpu()):.3f}")
+        assert e_m < 1.5e-2 and flips < 5e-3 and e_p < 1.5e-2 and e_mem < 1.5e-2
+        assert abs(float(o["object_score_logits"]) - float(h["object_score_logits"].cpu())) < 2e-2 * max(1.0, abs(float(o["object_score_logits"])))
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_tracking_through_the_predictor(name):
+    """clicks on two objects + a box on a third, a correction click on a later frame, 7 frames: the same state machine drives the oracle and the
+    HIP model; per-frame logits at video resolution are compared."""
+    from videovanish_amd.sam2_config import SMALL_SAM2, TINY_SAM2
+    from videovanish_amd.sam2_predictor import Sam2VideoPredictor
+    cfg = {"tiny": TINY_SAM2, "small": SMALL_SAM2}[name]
+    ora, hipm = _models(cfg, seed=7)
+    H, W = (96, 160) if name == "tiny" else (144, 256)
+    frames = _frames(7 if name == "tiny" else 4, H, W, seed=1)
+    outs = []
+    for model in (ora, hipm):
+        p = Sam2VideoPredictor(model)
+        st = p.init_state(video_path=frames)
+        p.add_new_points_or_box(st, 1, 1, points=np.array([[0.5 * W, 0.5 * H], [0.1 * W, 0.2 * H]], dtype=np.float32), labels=np.array([1, 0], dtype=np.int32))
+        p.add_new_points_or_box(st, 1, 2, points=np.array([[0.25 * W, 0.3 * H]], dtype=np.float32), labels=np.array([1], dtype=np.int32))
+        p.add_new_points_or_box(st, 1, 3, box=np.array([0.2 * W, 0.2 * H, 0.7 * W, 0.7 * H], dtype=np.float32))
+        _, ids, m = p.add_new_points_or_box(st, 1, 2, points=np.array([[0.3 * W, 0.35 * H]], dtype=np.float32), labels=np.array([1], dtype=np.int32))   # re-prompt: previous logits fed back
+        assert ids == [1, 2, 3] and tuple(m.shape) == (3, 1, H, W)
+        p.add_new_points_or_box(st, 3, 1, points=np.array([[0.6 * W, 0.6 * H]], dtype=np.float32), labels=np.array([1], dtype=np.int32))                # a second conditioning frame
+        outs.append({t: (ids, logits) for t, ids, logits in p.propagate_in_video(st)})
+    o, h = outs
+    assert sorted(o) == sorted(h) == list(range(1, len(frames)))                                    # frame 0 precedes the first prompt: never yielded
+    worst, flips = 0.0, 0.0
+    for t in o:
+        assert o[t][0] == h[t][0] == [1, 2, 3]
+        lo, lh = o[t][1], h[t][1]
+        real = lo.abs() < 1000                                                                      # NO_OBJ_SCORE planes compare exactly below
+        worst = max(worst, float(((lo - lh).abs() * real).max() / lo[real].abs().max()))
+        flips = max(flips, float(((lo > 0) != (lh > 0)).float().mean()))
+    print(f"sam2_tracking[{name}]: {len(o)} frames x 3 objects, logits rel max-abs {worst:.2e}, worst per-frame sign-flip fraction {flips:.2e}")
+    assert worst < 4e-2 and flips < 1e-2
+
+
+def test_drop_in_masker_on_the_hip_path():
+    import sam2_masker
+    from oracle.sam2_ref import OracleSam2
+    from videovanish_amd.sam2_config import TINY_SAM2
+    from videovanish_amd.sam2_predictor import Sam2VideoPredictor
+    from videovanish_amd.sam2_weights import Sam2Weights
+    H, W = 96, 160
+    frames = _frames(5, H, W, seed=2)
+    ann = {"keyframes": [{"frame_idx": 1, "pos_clicks": [{"x": 0.5, "y": 0.5, "obj": 1}, {"x": 40, "y": 30, "obj": 2}],
+                          "neg_clicks": [{"x": 0.1, "y": 0.2, "obj": 1}], "rects": [{"x": 0.2, "y": 0.2, "w": 0.5, "h": 0.5, "obj": 3}]}]}
+    try:
+        sam2_masker.configure(cfg=TINY_SAM2, seed=11, dtype="fp16", device="cuda:0")
+        seen = []
+        got = sam2_masker.run_sam2_on_frames(frames, ann, prog=lambda p, s: seen.append((p, s)))
+        assert [p for p, _ in seen] == [1, 25, 45, 80] and all(isinstance(s, str) and s for _, s in seen)
+        sam2_masker.configure(Sam2VideoPredictor(OracleSam2(TINY_SAM2, Sam2Weights(TINY_SAM2, 11))))
+        want = sam2_masker.run_sam2_on_frames(frames, ann)
+    finally:
+        sam2_masker.configure(None)
+    assert len(got) == len(want) == 5 and got[0].shape == (H, W, 3) and got[0].dtype == np.uint8
+    assert not got[0].any() and not want[0].any()                                                   # before the first prompt: black
+    differ = max(float((g != w).any(axis=2).mean()) for g, w in zip(got, want))
+    painted = min(float(w.any(axis=2).mean()) for w in want[1:])
+    print(f"sam2_drop_in[tiny]: worst fraction of differing pixels {differ:.2e}, least painted fraction {painted:.2f}")
+    assert differ < 1e-2 and painted > 0.02
+    colours = {tuple(c) for w in got[1:] for c in np.unique(w.reshape(-1, 3), axis=0)}
+    assert colours <= {(0, 0, 0)} | {sam2_masker.color_for_obj(i) for i in (1, 2, 3)}

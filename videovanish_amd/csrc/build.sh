@@ -14,7 +14,7 @@ compile() {   # compile <src> <obj> [extra flags]
 }
 # VV_AB=1 ./build.sh builds the lab variant: environment-selected A/B kernels + the opt-in vv_conv3 kernel
 AB=""
-SRCS="vv_api vv_gemm vv_gemm256 vv_motion vv_chain vv_norm vv_elem vv_image vv_flow vv_deform"
+SRCS="vv_api vv_gemm vv_gemm256 vv_motion vv_chain vv_norm vv_elem vv_image vv_flow vv_deform vv_sam2"
 if [ -n "$VV_AB" ]; then AB="-DVV_AB"; SRCS="$SRCS vv_conv3"; else rm -f build/vv_conv3.o; fi
 if [ "$(cat build/.ab 2>/dev/null)" != "$AB" ]; then rm -f build/*.o; echo "$AB" > build/.ab; fi
 for f in $SRCS; do

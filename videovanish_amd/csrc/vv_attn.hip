@@ -1430,9 +1430,10 @@ int attn_by_d(const vv_attn_params& p, hipStream_t st) {
 #else                      // large head dims need the AGPR half of the register file for O^T
         case 128: return attn_dispatch<T, 128>(p, st);
         case 160: return attn_dispatch<T, 160>(p, st);
+        case 256: return attn_dispatch<T, 256>(p, st);
         case 512: return attn_dispatch<T, 512>(p, st);
 #endif
-        default: VV_FAIL(VV_E_UNSUPPORTED, "vv_attention: head dim %d not built (32,40,64,80,128,160,512)", p.D);
+        default: VV_FAIL(VV_E_UNSUPPORTED, "vv_attention: head dim %d not built (32,40,64,80,128,160,256,512)", p.D);
     }
 }
 

@@ -11,8 +11,8 @@ import torch
 BF16, F16, F32, U8 = 0, 1, 2, 3
 SPLIT3 = 16      # vv_groupnorm out_dtype: the K-concatenated split-precision operand (see split3)
 EPI_NONE, EPI_GEGLU = 0, 1
-ACT_NONE, ACT_SILU, ACT_RELU, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 7
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
+ABI_VERSION = 8
 _DT = {"bf16": BF16, "fp16": F16}
 _TORCH_H16 = {BF16: torch.bfloat16, F16: torch.float16}
 
@@ -102,7 +102,11 @@ EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name
            "vv_avgpool2_f32", "vv_corr_lookup", "vv_raft_ctx_split", "vv_raft_flow_prep", "vv_gru_rh", "vv_gru_update", "vv_add_flow",
            "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_deform_im2col", "vv_fc_input", "vv_upsample2x_bilinear", "vv_flow_combine", "vv_gather_rows", "vv_fold_patches", "vv_flow_down4", "vv_gen_compose", "vv_gen_input", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32", "vv_u8_is_zero",
            "vv_raft_prep", "vv_split_f32", "vv_pad_channels_f32", "vv_window_average",
-           "vv_groupnorm_stats", "vv_gn_affine", "vv_motion_module_c320", "vv_split3", "vv_spatial_chain_c320", "vv_spatial_chain_front_c320", "vv_gn_affine_frames"]
+           "vv_groupnorm_stats", "vv_gn_affine", "vv_motion_module_c320", "vv_split3", "vv_spatial_chain_c320", "vv_spatial_chain_front_c320", "vv_gn_affine_frames",
+           # SAM 2 (row n4)
+           "vv_u8_normalize", "vv_layernorm_ex", "vv_maxpool2x2", "vv_rope_apply", "vv_dwconv", "vv_pixel_shuffle2", "vv_resize_bilinear_f32",
+           "vv_mask_mem_input", "vv_act", "vv_prompt_points", "vv_sine_pe_1d", "vv_sam_select", "vv_sam_pick", "vv_select_f32",
+           "vv_add_rowvec_unless", "vv_clamp_f32", "vv_fill_holes", "vv_hyper_masks"]
 
 
 def lib():
@@ -291,14 +295,14 @@ def attention_q_scale(D):
 
 
 def attention(dtype, q, k, v, out, *, B, heads, Nq, Nkv, D, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, q_off=0, k_off=0, v_off=0,
-              q_hs=0, k_hs=0, v_hs=0, q_prescaled=False):
+              q_hs=0, k_hs=0, v_hs=0, q_prescaled=False, scale=None):
     """q/k/v/out: h16 tensors (any shape); element offsets *_off select a column block inside a fused QKV buffer.
     q_prescaled: q already carries D**-0.5 * log2(e) (attention_q_scale(D) folded into the query projection)."""
     _need_cuda(q, k, v, out)
     es = 2
     p = AttnParams(q=q.data_ptr() + q_off * es, k=k.data_ptr() + k_off * es, v=v.data_ptr() + v_off * es, o=out.data_ptr(),
                    q_bs=q_bs, k_bs=k_bs, v_bs=v_bs, o_bs=o_bs, q_rs=q_rs, k_rs=k_rs, v_rs=v_rs, o_rs=o_rs, B=B, heads=heads, Nq=Nq,
-                   Nkv=Nkv, D=D, scale=float(D) ** -0.5, q_hs=q_hs, k_hs=k_hs, v_hs=v_hs, q_prescaled=1 if q_prescaled else 0)
+                   Nkv=Nkv, D=D, scale=float(D) ** -0.5 if scale is None else float(scale), q_hs=q_hs, k_hs=k_hs, v_hs=v_hs, q_prescaled=1 if q_prescaled else 0)
     kind = "temporal" if (Nq <= 32 and Nkv <= 32) else ("cross" if Nkv < 128 and Nq != Nkv else "spatial")
     if os.environ.get("VV_PROFILE_SHAPES"):
         kind = f"B{B},N{Nq}|" + kind
@@ -695,4 +699,155 @@ def raft_prep(dtype, img):
     _need_cuda(img)
     out = torch.empty(img.shape[:-1] + (8,), dtype=h16(dtype), device=img.device)
     _check(lib().vv_raft_prep(_p(img), C.c_int64(img.numel() // 3), _p(out), dtype, _stream()), "vv_raft_prep")
+    return out
+
+
+# ---- SAM 2 (include/vvhip.h "SAM 2" section) ---------------------------------------------------------------------
+def _f(x):
+    return C.c_float(float(x))
+
+
+def u8_normalize(dtype, img_u8, mean, std, cpad=8, s2d=1):
+    """uint8 [H, W, 3] -> h16 [(H/s2d)*(W/s2d), cpad] = ((x / 255) - mean) / std; s2d > 1: space-to-depth blocks, channel (dy*s2d + dx)*3 + c."""
+    _need_cuda(img_u8)
+    H, W = img_u8.shape[:2]
+    out = torch.empty(((H // s2d) * (W // s2d), cpad), dtype=h16(dtype), device=img_u8.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[1.0 / float(v) for v in std])
+    _check(lib().vv_u8_normalize(_p(img_u8), H, W, m, s, _p(out), cpad, s2d, dtype, _stream()), "vv_u8_normalize")
+    return out
+
+
+def layernorm_ex(dtype, x, gamma, beta, eps, act=ACT_NONE, out_dtype=None, cpad=None):
+    """LayerNorm over the last dim of fp32 [M, C] (any C) + optional activation; out_dtype None = h16, torch.float32 = fp32;
+    cpad: output row length (zero padded channels, for a following conv whose input channels are padded)."""
+    _need_cuda(x, gamma, beta)
+    M, Cc = x.shape
+    cp = Cc if cpad is None else cpad
+    out = torch.empty((M, cp), dtype=h16(dtype) if out_dtype is None else out_dtype, device=x.device)
+    _check(lib().vv_layernorm_ex(_p(x), C.c_int64(M), Cc, _p(gamma), _p(beta), _f(eps), act, _p(out), dt_of(out), cp, dtype, _stream()), "vv_layernorm_ex")
+    return out
+
+
+def maxpool2x2(x, B, H, W, Cc=None, in_bs=0, x_off=0):
+    """B images [H, W, C] (fp32 or h16; image b starts x_off + b * in_bs elements into x, in_bs = 0: contiguous) -> [B*(H/2)*(W/2), C]."""
+    _need_cuda(x)
+    Cc = x.shape[-1] if Cc is None else Cc
+    out = torch.empty((B * (H // 2) * (W // 2), Cc), dtype=x.dtype, device=x.device)
+    _check(lib().vv_maxpool2x2(C.c_void_p(x.data_ptr() + x_off * x.element_size()), dt_of(x), B, H, W, Cc, C.c_int64(in_bs), _p(out), _stream()),
+           "vv_maxpool2x2")
+    return out
+
+
+def rope_apply(dtype, x, rows_rope, cos_sin, D, col0=0, ld=None):
+    """in place: rows < rows_rope of the h16 matrix x, columns col0 .. col0 + D, rotated pairwise by cos_sin [n, D/2, 2] (row r uses r % n)."""
+    _need_cuda(x, cos_sin)
+    _check(lib().vv_rope_apply(_p(x), C.c_int64(rows_rope), x.shape[-1] if ld is None else ld, col0, D, _p(cos_sin), cos_sin.shape[0], dtype,
+                               _stream()), "vv_rope_apply")
+    return x
+
+
+def dwconv(x, H, W, w, bias):
+    _need_cuda(x, w, bias)
+    out = torch.empty_like(x)
+    _check(lib().vv_dwconv(_p(x), H, W, x.shape[-1], _p(w), _p(bias), w.shape[-1], _p(out), _stream()), "vv_dwconv")
+    return out
+
+
+def pixel_shuffle2(dtype, y, bias, h, w, add=None, act=ACT_NONE, out_dtype=torch.float32):
+    _need_cuda(y, bias, add)
+    Cc = y.shape[-1] // 4
+    out = torch.empty((4 * h * w, Cc), dtype=out_dtype, device=y.device)
+    _check(lib().vv_pixel_shuffle2(_p(y), _p(bias), _p(add), h, w, Cc, act, _p(out), dt_of(out), dtype, _stream()), "vv_pixel_shuffle2")
+    return out
+
+
+def resize_bilinear_f32(src, Hs, Ws, Hd, Wd):
+    """fp32 [Hs*Ws, C] -> [Hd*Wd, C], F.interpolate(mode="bilinear", align_corners=False)."""
+    _need_cuda(src)
+    Cc = src.shape[-1]
+    out = torch.empty((Hd * Wd, Cc), dtype=torch.float32, device=src.device)
+    _check(lib().vv_resize_bilinear_f32(_p(src), Hs, Ws, Cc, _p(out), Hd, Wd, _stream()), "vv_resize_bilinear_f32")
+    return out
+
+
+def mask_mem_input(dtype, logits, binarize, scale, bias):
+    _need_cuda(logits)
+    n = logits.numel()
+    out = torch.empty((n, 8), dtype=h16(dtype), device=logits.device)
+    _check(lib().vv_mask_mem_input(_p(logits), C.c_int64(n), int(bool(binarize)), _f(scale), _f(bias), _p(out), dtype, _stream()), "vv_mask_mem_input")
+    return out
+
+
+def act_inplace(x, act):
+    _need_cuda(x)
+    _check(lib().vv_act(_p(x), dt_of(x), C.c_int64(x.numel()), act, _stream()), "vv_act")
+    return x
+
+
+def prompt_points(coords, labels, inv_size, gauss, table):
+    _need_cuda(coords, labels, gauss, table)
+    P, D = labels.numel(), table.shape[-1]
+    out = torch.empty((P, D), dtype=torch.float32, device=coords.device)
+    _check(lib().vv_prompt_points(_p(coords), _p(labels), P, _f(inv_size), _p(gauss), _p(table), D, _p(out), _stream()), "vv_prompt_points")
+    return out
+
+
+def sine_pe_1d(pos, dim, temperature=10000.0):
+    _need_cuda(pos)
+    out = torch.empty((pos.numel(), dim), dtype=torch.float32, device=pos.device)
+    _check(lib().vv_sine_pe_1d(_p(pos), pos.numel(), dim, _f(temperature), _p(out), _stream()), "vv_sine_pe_1d")
+    return out
+
+
+def sam_select(masks, iou, obj_logit, multimask, delta, thresh):
+    _need_cuda(masks, iou, obj_logit)
+    sel = torch.empty(4, dtype=torch.int32, device=masks.device)
+    _check(lib().vv_sam_select(_p(masks), masks.shape[-1], masks.shape[0], _p(iou), _p(obj_logit), int(bool(multimask)), _f(delta), _f(thresh), _p(sel),
+                               _stream()), "vv_sam_select")
+    return sel
+
+
+def sam_pick(masks, sel, no_obj_score):
+    _need_cuda(masks, sel)
+    out = torch.empty(masks.shape[-1], dtype=torch.float32, device=masks.device)
+    _check(lib().vv_sam_pick(_p(masks), masks.shape[-1], _p(sel), _f(no_obj_score), _p(out), _stream()), "vv_sam_pick")
+    return out
+
+
+def select_f32(a, b, flag):
+    _need_cuda(a, b, flag)
+    out = torch.empty_like(a)
+    _check(lib().vv_select_f32(_p(a), _p(b), _p(flag), C.c_int64(a.numel()), _p(out), _stream()), "vv_select_f32")
+    return out
+
+
+def add_rowvec_unless(x, vec, score):
+    """x[m] += vec unless score[0] > 0 (score: fp32 on the device)."""
+    _need_cuda(x, vec, score)
+    _check(lib().vv_add_rowvec_unless(_p(x), _p(vec), _p(score), C.c_int64(x.shape[0]), x.shape[1], _stream()), "vv_add_rowvec_unless")
+    return x
+
+
+def clamp_f32(x, lo, hi):
+    _need_cuda(x)
+    out = torch.empty_like(x)
+    _check(lib().vv_clamp_f32(_p(x), C.c_int64(x.numel()), _f(lo), _f(hi), _p(out), _stream()), "vv_clamp_f32")
+    return out
+
+
+def fill_holes(mask, H, W, max_area):
+    """in place on fp32 [H*W]."""
+    _need_cuda(mask)
+    ws = torch.empty(3 * H * W, dtype=torch.int32, device=mask.device)
+    _check(lib().vv_fill_holes(_p(mask), H, W, max_area, _p(ws), _stream()), "vv_fill_holes")
+    return mask
+
+
+def hyper_masks(hyper, up):
+    """masks [nm, HW] = hyper [nm, C] @ up [HW, C]^T, fp32."""
+    _need_cuda(hyper, up)
+    nm, Cc = hyper.shape
+    out = torch.empty((nm, up.shape[0]), dtype=torch.float32, device=up.device)
+    _check(lib().vv_hyper_masks(_p(hyper), _p(up), up.shape[0], Cc, nm, _p(out), _stream()), "vv_hyper_masks")
     return out
