@@ -58,7 +58,7 @@ typedef struct {
     int32_t Hin, Win;     /* stored spatial size of the sources */
     int32_t Hv, Wv;       /* virtual size after nearest resize (== Hin,Win when no resize) */
     int32_t Hout, Wout;   /* output spatial size; M = F*Hout*Wout */
-    int32_t ksize;        /* kernel height: 1, 3, 5 or 7 */
+    int32_t ksize;        /* kernel height: 1, 2, 3, 5 or 7 (2: explicit pad_t / pad_l, e.g. stride 2 without padding) */
     int32_t stride;       /* 1 or 2 */
     int32_t pad_t, pad_l; /* top/left zero padding (bottom/right implied by bounds) */
     const void* weight;   /* h16 [Npad][Kpad], Kpad % 64 == 0, rows >= N are zero, Npad % tileN == 0 */

@@ -329,12 +329,14 @@ class OracleSam2:
         masks = (hyper @ up.view(b, c, h * w)).view(b, -1, h, w)
         iou = self.mlp(iou_token_out, Q + "iou_prediction_head", 3, sigmoid=True)
         obj = self.mlp(hs[:, 0, :], Q + "pred_obj_score_head", 3)
+        self.last_decoder = {"masks": masks.clone(), "iou": iou.clone()}          # for tests: every candidate the selection below chooses from
         if multimask_output:
             masks, iou, tok = masks[:, 1:], iou[:, 1:], mask_tokens_out[:, 1:]
         else:                                                   # dynamic_multimask_via_stability
             flat = masks[:, 0:1].flatten(-2)
             d = self.cfg.stability_delta
             ai, au = (flat > d).sum(-1).float(), (flat > -d).sum(-1).float()
+            self.last_decoder["stability"] = float(torch.where(au > 0, ai / au, torch.ones_like(au)))
             stable = torch.where(au > 0, ai / au, torch.ones_like(au)) >= self.cfg.stability_thresh
             best = torch.argmax(iou[:, 1:], dim=-1)
             bm, bi = masks[:, 1:][torch.arange(b), best].unsqueeze(1), iou[:, 1:][torch.arange(b), best].unsqueeze(1)

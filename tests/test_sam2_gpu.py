@@ -81,6 +81,46 @@ def test_maxpool_and_pixel_shuffle_and_resize(hipmod):
         assert _rel(out, ref) < 1e-5
 
 
+def test_conv_gemm_2x2_kernels(hipmod):
+    """vv_conv_gemm with 2x2 taps (allowed since ABI 8): stride 2 / no padding (the prompt encoder's mask downscaling) and stride 1 with one row /
+    column of padding on the top / left only (the space-to-depth form of the 7x7 stride-4 patch embedding)."""
+    hip = hipmod
+    from videovanish_amd import packing
+    g = torch.Generator().manual_seed(4)
+    cin, cout, H, W = 16, 24, 10, 14
+    x = torch.randn(1, cin, H, W, generator=g).half().float()
+    w = (torch.randn(cout, cin, 2, 2, generator=g) / 8).half().float()
+    b = torch.randn(cout, generator=g)
+    wp, K = packing.pack_conv(w, torch.float16)
+    xd = x.permute(0, 2, 3, 1).reshape(-1, cin).half().contiguous().to(_dev())
+    out = hip.conv_gemm(hip.F16, xd, wp.to(_dev()), cout, K, F=1, Hin=H, Win=W, Hout=H // 2, Wout=W // 2, ksize=2, stride=2, pad_t=0, pad_l=0, bias=b.to(_dev()),
+                        out_dtype=torch.float32)
+    ref = F.conv2d(x, w, b, stride=2).permute(0, 2, 3, 1).reshape(-1, cout)
+    assert _rel(out, ref) < 1e-5
+    out = hip.conv_gemm(hip.F16, xd, wp.to(_dev()), cout, K, F=1, Hin=H, Win=W, Hout=H, Wout=W, ksize=2, stride=1, pad_t=1, pad_l=1, bias=b.to(_dev()),
+                        out_dtype=torch.float32)
+    ref = F.conv2d(F.pad(x, (1, 0, 1, 0)), w, b).permute(0, 2, 3, 1).reshape(-1, cout)
+    assert _rel(out, ref) < 1e-5
+    # the 7x7 / stride-4 patch embedding as space-to-depth + 2x2 (sam2_model.HipSam2.__init__)
+    S, E = 32, 16
+    img = torch.randint(0, 256, (S, S, 3), generator=g, dtype=torch.uint8)
+    w7, b7 = torch.randn(E, 3, 7, 7, generator=g) / 12, torch.randn(E, generator=g)
+    w2 = torch.zeros(E, 4, 4, 3, 2, 2)
+    for ky in range(7):
+        by, dy = (0, ky + 1) if ky < 3 else (1, ky - 3)
+        for kx in range(7):
+            bx, dx = (0, kx + 1) if kx < 3 else (1, kx - 3)
+            w2[:, dy, dx, :, by, bx] = w7[:, :, ky, kx]
+    wp, K = packing.pack_conv(w2.reshape(E, 48, 2, 2), torch.float16)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    x48 = hip.u8_normalize(hip.F16, img.to(_dev()), mean, std, 48, s2d=4)
+    out = hip.conv_gemm(hip.F16, x48, wp.to(_dev()), E, K, F=1, Hin=S // 4, Win=S // 4, Hout=S // 4, Wout=S // 4, ksize=2, stride=1, pad_t=1, pad_l=1,
+                        bias=b7.to(_dev()), out_dtype=torch.float32)
+    xn = ((img.float() / 255 - torch.tensor(mean)) / torch.tensor(std)).permute(2, 0, 1)[None]
+    ref = F.conv2d(xn, w7, b7, stride=4, padding=3).permute(0, 2, 3, 1).reshape(-1, E)
+    assert _rel(out, ref) < 2e-3                                                          # h16 rounding of the image and the weights
+
+
 def test_rope_dwconv_positional_kernels(hipmod):
     hip = hipmod
     from oracle import sam2_ref
@@ -185,19 +225,63 @@ def test_image_encoder_and_prompted_frame(name):
     print(f"sam2_image_encoder[{name}]: rel max-abs top {e_top:.2e} s1 {e_s1:.2e} s0 {e_s0:.2e}")
     assert max(e_top, e_s1, e_s0) < 6e-3
     # a prompted (initial conditioning) frame: clicks -> multimask path, a box -> single-mask path with the stability test
+    empty = lambda: {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+    lo = 4 * fs
     for pts, labs in (([[0.4 * S, 0.5 * S]], [1]), ([[0.2 * S, 0.2 * S], [0.7 * S, 0.8 * S]], [2, 3]), ([[0.5 * S, 0.5 * S], [0.1 * S, 0.9 * S]], [1, 0])):
         pi = {"point_coords": torch.tensor([pts], dtype=torch.float32), "point_labels": torch.tensor([labs], dtype=torch.int32)}
-        o = ora.track_step(0, True, fo, pi, {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}, 1, run_mem_encoder=True)
-        h = hipm.track_step(0, True, fh, pi, {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}, 1, run_mem_encoder=True)
-        lo = 4 * fs
+        o = ora.track_step(0, True, fo, pi, empty(), 1, run_mem_encoder=False)
+        h = hipm.track_step(0, True, fh, pi, empty(), 1, run_mem_encoder=False)
         mo, mh = o["pred_masks"].reshape(-1), h["pred_masks"].cpu().reshape(-1)
+        assert float(o["object_score_logits"]) > 0 and float(mo.max()) > 0 > float(mo.min()) > -1000          # a real mask, not the NO_OBJ plane
         e_m, e_p = _rel(mh, mo), _rel(h["obj_ptr"], o["obj_ptr"])
+        note = ""
+        if e_m > 1.5e-2:
+            # the selection among the decoder's candidates is a discontinuous decision (stability score against 0.98, argmax of the IoU scores):
+            # when the oracle sits on the edge the other candidate is an equally valid answer -- it must then BE that candidate
+            cand = ora.last_decoder["masks"][0].reshape(ora.last_decoder["masks"].shape[1], -1)
+            errs = [_rel(mh, c) for c in cand]
+            iou = ora.last_decoder["iou"][0]
+            edge = abs(ora.last_decoder.get("stability", 0.0) - cfg.stability_thresh) < 5e-3 or float(iou[1:].topk(2).values.diff().abs()) < 5e-3
+            note = f" [oracle on a decision edge: stability {ora.last_decoder.get('stability', float('nan')):.4f}, iou {[round(float(v), 4) for v in iou]}; HIP chose candidate {int(np.argmin(errs))}]"
+            assert edge and min(errs) < 1.5e-2, (errs, ora.last_decoder.get("stability"), iou)
+            mo = cand[int(np.argmin(errs))]
+            e_m = min(errs)
         flips = float(((mo > 0) != (mh > 0)).float().mean())
-        e_mem = _rel(h["maskmem_features"], nhwc(o["maskmem_features"]))
-        print(f"sam2_prompted_frame[{name},{len(labs)} pts]: logits rel {e_m:.2e} sign flips {flips:.2e} obj_ptr rel {e_p:.2e} memory rel {e_mem:.2e} "
-              f"object score {float(o['object_score_logits']):.3f} / {float(h['object_score_logits'].cpu()):.3f}")
-        assert e_m < 1.5e-2 and flips < 5e-3 and e_p < 1.5e-2 and e_mem < 1.5e-2
+        print(f"sam2_prompted_frame[{name},{len(labs)} pts]: logits rel {e_m:.2e} sign flips {flips:.2e} obj_ptr rel {e_p:.2e} "
+              f"object score {float(o['object_score_logits']):.3f} / {float(h['object_score_logits'].cpu()):.3f}{note}")
+        assert e_m < 1.5e-2 and flips < 5e-3 and e_p < 1.5e-2
         assert abs(float(o["object_score_logits"]) - float(h["object_score_logits"].cpu())) < 2e-2 * max(1.0, abs(float(o["object_score_logits"])))
+        # re-prompt with the previous logits as the mask prompt (the prompt encoder's mask downscaling path)
+        o2 = ora.track_step(0, True, fo, pi, empty(), 1, run_mem_encoder=False, prev_sam_mask_logits=ora.clamp_prev_logits(o["pred_masks"]))
+        h2 = hipm.track_step(0, True, fh, pi, empty(), 1, run_mem_encoder=False,
+                             prev_sam_mask_logits=hipm.clamp_prev_logits(o["pred_masks"].reshape(-1).contiguous().to(_dev())))
+        e2 = _rel(h2["pred_masks"].cpu().reshape(-1), o2["pred_masks"].reshape(-1))
+        print(f"sam2_mask_prompt[{name}]: logits rel {e2:.2e}")
+        assert e2 < 1.5e-2 and not torch.equal(o2["pred_masks"], o["pred_masks"])
+    # memory encoder on IDENTICAL inputs (the oracle's logits): binarised (from clicks) and sigmoid (tracked frame) forms; an absent object
+    for from_pts, score in ((True, 1.0), (False, 1.0), (False, -1.0)):
+        fm_o, _ = ora.encode_memory_from_low_res(fo, o["pred_masks"], torch.tensor([[score]]), from_pts)
+        fm_h, _ = hipm.encode_memory_from_low_res(fh, o["pred_masks"].reshape(-1).contiguous().to(_dev()), torch.tensor([score]).to(_dev()), from_pts)
+        e = _rel(fm_h, nhwc(fm_o))
+        print(f"sam2_memory_encoder[{name},binarised={from_pts},score={score}]: rel {e:.2e}")
+        assert e < 6e-3
+    # one tracked frame on IDENTICAL memories (the oracle's, re-laid-out for the HIP model): memory attention + RoPE + object pointers
+    f1 = _frames(2, S, S + 16)[1]
+    fo1, fh1 = ora.encode_image(f1), hipm.encode_image(f1)
+    od_o, od_h = empty(), empty()
+    for t in range(3):
+        pi = {"point_coords": torch.tensor([[[0.3 * S + 9 * t, 0.5 * S]]], dtype=torch.float32), "point_labels": torch.tensor([[1]], dtype=torch.int32)}
+        c = ora.track_step(t, True, fo, pi, empty(), 8, run_mem_encoder=True)
+        key = "cond_frame_outputs" if t == 0 else "non_cond_frame_outputs"
+        od_o[key][t] = c
+        od_h[key][t] = {"maskmem_features": nhwc(c["maskmem_features"]).contiguous().to(_dev()), "maskmem_pos_enc": None,
+                        "obj_ptr": c["obj_ptr"].contiguous().to(_dev()), "pred_masks": None, "object_score_logits": None}
+    o = ora.track_step(3, False, fo1, None, od_o, 8, run_mem_encoder=False)
+    h = hipm.track_step(3, False, fh1, None, od_h, 8, run_mem_encoder=False)
+    mo, mh = o["pred_masks"].reshape(-1), h["pred_masks"].cpu().reshape(-1)
+    e_m, flips = _rel(mh, mo), float(((mo > 0) != (mh > 0)).float().mean())
+    print(f"sam2_tracked_frame[{name}]: logits rel {e_m:.2e} sign flips {flips:.2e} obj_ptr rel {_rel(h['obj_ptr'], o['obj_ptr']):.2e}")
+    assert float(mo.min()) > -1000 and e_m < 1.5e-2 and flips < 5e-3
 
 
 @pytest.mark.parametrize("name", ["tiny", "small"])
@@ -223,15 +307,19 @@ def test_tracking_through_the_predictor(name):
         outs.append({t: (ids, logits) for t, ids, logits in p.propagate_in_video(st)})
     o, h = outs
     assert sorted(o) == sorted(h) == list(range(1, len(frames)))                                    # frame 0 precedes the first prompt: never yielded
-    worst, flips = 0.0, 0.0
+    worst, flips, painted = 0.0, 0.0, 1.0
     for t in o:
         assert o[t][0] == h[t][0] == [1, 2, 3]
         lo, lh = o[t][1], h[t][1]
-        real = lo.abs() < 1000                                                                      # NO_OBJ_SCORE planes compare exactly below
-        worst = max(worst, float(((lo - lh).abs() * real).max() / lo[real].abs().max()))
+        assert float(lo.min()) > -1000                                                              # every object is tracked (no NO_OBJ planes)
+        worst = max(worst, float((lo - lh).pow(2).mean().sqrt() / lo.pow(2).mean().sqrt()))
         flips = max(flips, float(((lo > 0) != (lh > 0)).float().mean()))
-    print(f"sam2_tracking[{name}]: {len(o)} frames x 3 objects, logits rel max-abs {worst:.2e}, worst per-frame sign-flip fraction {flips:.2e}")
-    assert worst < 4e-2 and flips < 1e-2
+        painted = min(painted, float((lo > 0).float().mean()))
+    print(f"sam2_tracking[{name}]: {len(o)} frames x 3 objects, logits rel RMS {worst:.2e}, worst per-frame sign-flip fraction {flips:.2e}, "
+          f"least foreground fraction {painted:.2f}")
+    # a flipped pixel of a binarised click mask changes that frame's memory for good: the recurrence is compared statistically, the arithmetic of
+    # every stage is pinned on identical inputs in test_image_encoder_and_prompted_frame
+    assert worst < 5e-2 and flips < 2e-2
 
 
 def test_drop_in_masker_on_the_hip_path():

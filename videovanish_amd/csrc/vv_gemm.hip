@@ -474,7 +474,8 @@ extern "C" int vv_conv_gemm(const vv_conv_params* pp, int dtype, void* stream) {
     if (!p.in0 || !p.weight || !p.out) VV_FAIL(VV_E_ARG, "vv_conv_gemm: null tensor pointer");
     if (p.C0 <= 0 || p.C0 % 8 || p.C1 < 0 || p.C1 % 8 || (p.C1 > 0 && !p.in1)) VV_FAIL(VV_E_ARG, "vv_conv_gemm: C0=%d C1=%d must be multiples of 8", p.C0, p.C1);
     const int kw_ = p.ksize_w > 0 ? p.ksize_w : p.ksize;
-    if ((p.ksize != 1 && p.ksize != 3 && p.ksize != 5 && p.ksize != 7) || (kw_ != 1 && kw_ != 3 && kw_ != 5 && kw_ != 7)) VV_FAIL(VV_E_ARG, "vv_conv_gemm: kernel %dx%d", p.ksize, kw_);
+    if (p.ksize < 1 || p.ksize > 7 || p.ksize == 4 || p.ksize == 6 || kw_ < 1 || kw_ > 7 || kw_ == 4 || kw_ == 6) VV_FAIL      // 2x2: ConvTranspose-style / space-to-depth layers of SAM 2
+       (VV_E_ARG, "vv_conv_gemm: kernel %dx%d", p.ksize, kw_);
     if (p.act != VV_ACT_NONE && p.act != VV_ACT_RELU && p.act != VV_ACT_LRELU) VV_FAIL(VV_E_ARG, "vv_conv_gemm: act %d", p.act);
     if (p.stride != 1 && p.stride != 2) VV_FAIL(VV_E_ARG, "vv_conv_gemm: stride %d", p.stride);
     if (p.K != p.ksize * kw_ * (p.C0 + p.C1)) VV_FAIL(VV_E_ARG, "vv_conv_gemm: K=%d != kh*kw*Cin", p.K);

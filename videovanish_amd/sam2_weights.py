@@ -182,6 +182,8 @@ class Sam2Weights:
         if kind == "wt":                                  # ConvTranspose2d [cin, cout, k, k]: every output pixel sees cin inputs
             return self.src.normal(name, shape, std=float(shape[0]) ** -0.5)
         if kind == "b":
+            if name == "sam_mask_decoder.pred_obj_score_head.layers.2.bias":
+                return self.src.normal(name, shape, std=0.02, mean=3.0)     # synthetic models "see" their object (score > 0), so masks / memories are exercised
             return self.src.normal(name, shape, std=0.02)
         if kind == "g":
             return self.src.normal(name, shape, std=0.1, mean=1.0)
