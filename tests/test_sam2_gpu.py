@@ -349,3 +349,52 @@ def test_drop_in_masker_on_the_hip_path():
     assert differ < 1e-2 and painted > 0.02
     colours = {tuple(c) for w in got[1:] for c in np.unique(w.reshape(-1, 3), axis=0)}
     assert colours <= {(0, 0, 0)} | {sam2_masker.color_for_obj(i) for i in (1, 2, 3)}
+
+
+def test_full_size_hiera_l():
+    """the published configuration (1024 x 1024, Hiera-L, 224.4 M parameters, seeded synthetic weights): image encoder, a prompted frame, the
+    memory encoder and one memory-conditioned frame against the fp32 oracle (about a minute of CPU work)."""
+    import time
+    from videovanish_amd.sam2_config import Sam2Config
+    cfg = Sam2Config()
+    t0 = time.time()
+    ora, hipm = _models(cfg, seed=3)
+    S, fs = cfg.image_size, cfg.feat_size
+    frames = _frames(2, 720, 1280, seed=4)
+    fo, fh = ora.encode_image(frames[0]), hipm.encode_image(frames[0])
+    nhwc = lambda t: t[0].permute(1, 2, 0).reshape(-1, t.shape[1])
+    e_top, e_s1, e_s0 = _rel(fh["top"], nhwc(fo["fpn"][2])), _rel(fh["s1"], nhwc(fo["fpn"][1])), _rel(fh["s0"], nhwc(fo["fpn"][0]))
+    print(f"sam2_image_encoder[hiera_l,1024]: rel max-abs top {e_top:.2e} s1 {e_s1:.2e} s0 {e_s0:.2e} ({time.time() - t0:.0f} s)")
+    assert max(e_top, e_s1, e_s0) < 1e-2
+    empty = lambda: {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+    pi = {"point_coords": torch.tensor([[[0.4 * S, 0.5 * S]]], dtype=torch.float32), "point_labels": torch.tensor([[1]], dtype=torch.int32)}
+    o = ora.track_step(0, True, fo, pi, empty(), 4, run_mem_encoder=True)
+    h = hipm.track_step(0, True, fh, pi, empty(), 4, run_mem_encoder=False)
+    mo, mh = o["pred_masks"].reshape(-1), h["pred_masks"].cpu().reshape(-1)
+    assert float(o["object_score_logits"]) > 0
+    e_m, flips = _rel(mh, mo), float(((mo > 0) != (mh > 0)).float().mean())
+    fm_h, _ = hipm.encode_memory_from_low_res(fh, o["pred_masks"].reshape(-1).contiguous().to(_dev()), o["object_score_logits"].reshape(-1).to(_dev()), True)
+    e_mem = _rel(fm_h, nhwc(o["maskmem_features"]))
+    print(f"sam2_prompted_frame[hiera_l]: logits rel {e_m:.2e} sign flips {flips:.2e} obj_ptr rel {_rel(h['obj_ptr'], o['obj_ptr']):.2e}; memory encoder rel {e_mem:.2e}")
+    assert e_m < 2e-2 and flips < 5e-3 and e_mem < 1e-2
+    od_o, od_h = empty(), empty()
+    od_o["cond_frame_outputs"][0] = o
+    od_h["cond_frame_outputs"][0] = {"maskmem_features": nhwc(o["maskmem_features"]).contiguous().to(_dev()), "maskmem_pos_enc": None,
+                                     "obj_ptr": o["obj_ptr"].contiguous().to(_dev()), "pred_masks": None, "object_score_logits": None}
+    fo1, fh1 = ora.encode_image(frames[1]), hipm.encode_image(frames[1])
+    o1 = ora.track_step(1, False, fo1, None, od_o, 4, run_mem_encoder=False)
+    h1 = hipm.track_step(1, False, fh1, None, od_h, 4, run_mem_encoder=False)
+    mo, mh = o1["pred_masks"].reshape(-1), h1["pred_masks"].cpu().reshape(-1)
+    e_m, flips = _rel(mh, mo), float(((mo > 0) != (mh > 0)).float().mean())
+    print(f"sam2_tracked_frame[hiera_l]: logits rel {e_m:.2e} sign flips {flips:.2e} ({time.time() - t0:.0f} s)")
+    assert e_m < 2e-2 and flips < 5e-3
+
+
+def test_batched_image_encoding_equals_frame_by_frame():
+    from videovanish_amd.sam2_config import SMALL_SAM2
+    _, hipm = _models(SMALL_SAM2, seed=9)
+    frames = _frames(3, 144, 256, seed=6)
+    batch = hipm.encode_images(frames)
+    for f, b in zip(frames, batch):
+        one = hipm.encode_image(f)
+        assert all(torch.equal(one[k], b[k]) for k in ("s0", "s1", "top"))

@@ -262,35 +262,42 @@ class HipSam2:
             self._idx[key] = torch.from_numpy(builder().astype(np.int32)).to(self.device)
         return self._idx[key]
 
-    def _part_idx(self, H, W, ws):
-        """row of window-ordered token (window, wy, wx) in the [H*W] map."""
+    def _index_free(self, key, builder):
+        if key not in self._idx:
+            self._idx[key] = builder()
+        return self._idx[key]
+
+    def _part_idx(self, Bf, H, W, ws):
+        """row of window-ordered token (frame, window, wy, wx) in the [Bf*H*W] map."""
         def b():
             y, x = np.arange(H).reshape(H // ws, ws), np.arange(W).reshape(W // ws, ws)
-            return (y[:, None, :, None] * W + x[None, :, None, :]).reshape(-1)
-        return self._index(("part", H, W, ws), b)
+            one = (y[:, None, :, None] * W + x[None, :, None, :]).reshape(-1)
+            return (np.arange(Bf)[:, None] * (H * W) + one[None, :]).reshape(-1)
+        return self._index(("part", Bf, H, W, ws), b)
 
-    def _unpart_idx(self, H, W, ws):
-        """row of map token (y, x) in the window-ordered matrix."""
+    def _unpart_idx(self, Bf, H, W, ws):
+        """row of map token (frame, y, x) in the window-ordered matrix."""
         def b():
             y, x = np.arange(H)[:, None], np.arange(W)[None, :]
-            return (((y // ws) * (W // ws) + x // ws) * ws * ws + (y % ws) * ws + x % ws).reshape(-1)
-        return self._index(("unpart", H, W, ws), b)
+            one = (((y // ws) * (W // ws) + x // ws) * ws * ws + (y % ws) * ws + x % ws).reshape(-1)
+            return (np.arange(Bf)[:, None] * (H * W) + one[None, :]).reshape(-1)
+        return self._index(("unpart", Bf, H, W, ws), b)
 
     # ---- image encoder -------------------------------------------------------------------------------------------------------------
-    def _block(self, x, H, W, L):
+    def _block(self, x, Bf, H, W, L):
         ctx, dt = self.ctx, self.ctx.dt
         heads, dp, ws = L["heads"], L["dp"], L["window"]
         xn = self._ln(x, L["n1"], 1e-6)
         sc = x
         if "sc" in L:
-            sc = hip.maxpool2x2(L["sc"](xn), 1, H, W)
+            sc = hip.maxpool2x2(L["sc"](xn), Bf, H, W)
         if ws > 0:
             if H % ws or W % ws:
                 raise RuntimeError(f"Hiera window {ws} does not divide the {H}x{W} map (padded windows are not built)")
-            xn = hip.gather_rows(xn, self._part_idx(H, W, ws))
-            B, N, wh = (H // ws) * (W // ws), ws * ws, ws
+            xn = hip.gather_rows(xn, self._part_idx(Bf, H, W, ws))
+            B, N, wh = Bf * (H // ws) * (W // ws), ws * ws, ws
         else:
-            B, N, wh = 1, H * W, H
+            B, N, wh = Bf, H * W, H
         ww = N // wh
         qkv = L["qkv"](xn, out_dtype=ctx.h16, split=(heads, dp, N))                      # [B][q|k|v][head][token][dp]
         blk = heads * N * dp
@@ -307,7 +314,7 @@ class HipSam2:
                       q_rs=dp, k_rs=dp, v_rs=dp, o_rs=heads * dp, k_off=blk, v_off=2 * blk, q_hs=Nq * dp, k_hs=N * dp, v_hs=N * dp,
                       scale=float(L["d"]) ** -0.5)
         if ws > 0:
-            y = hip.gather_rows(L["proj"](o), self._unpart_idx(Ho, Wo, ws // 2 if L["q_stride"] else ws))
+            y = hip.gather_rows(L["proj"](o), self._unpart_idx(Bf, Ho, Wo, ws // 2 if L["q_stride"] else ws))
             x = hip.axpby(sc, y, 1.0, 1.0)
         else:
             x = L["proj"](o, res0=sc)
@@ -315,19 +322,22 @@ class HipSam2:
         hip.act_inplace(h, hip.ACT_GELU)
         return L["mlp1"](h, res0=x), Ho, Wo
 
-    def encode_image(self, frame_u8):
+    def encode_images(self, frames_u8):
+        """a batch of frames through the image encoder in one pass (every GEMM sees Bf x the rows: the stage-3 blocks of a single 1024^2 frame are
+        only 4096 tokens); results are per frame and do not depend on the batch they were computed in."""
         cfg, ctx = self.cfg, self.ctx
-        S = cfg.image_size
-        img = torch.from_numpy(np.ascontiguousarray(frame_u8)).to(self.device)
-        if tuple(img.shape[:2]) != (S, S):
-            img = hip.resize_u8(img[None].contiguous(), S, S, mode="bilinear")[0]          # cv2.INTER_LINEAR semantics (bit exact, vv_image.hip)
-        x48 = hip.u8_normalize(ctx.dt, img.contiguous(), IMG_MEAN, IMG_STD, 48, s2d=4)
+        S, Bf = cfg.image_size, len(frames_u8)
+        img = torch.from_numpy(np.ascontiguousarray(np.stack(frames_u8))).to(self.device)
+        if tuple(img.shape[1:3]) != (S, S):
+            img = hip.resize_u8(img.contiguous(), S, S, mode="bilinear")                    # cv2.INTER_LINEAR semantics (bit exact, vv_image.hip)
+        x48 = hip.u8_normalize(ctx.dt, img.reshape(Bf * S, S, 3).contiguous(), IMG_MEAN, IMG_STD, 48, s2d=4)     # frames stacked vertically (S % 4 == 0)
         H = W = S // 4
-        x = hip.conv_gemm(ctx.dt, x48, self.patch.w, self.patch.N, self.patch.K, F=1, Hin=H, Win=W, Hout=H, Wout=W, ksize=2, stride=1, pad_t=1, pad_l=1,
-                          bias=self.patch.b, res0=self.pos_embed, out_dtype=torch.float32)
+        pos = self._index_free(("pos", Bf), lambda: self.pos_embed.repeat(Bf, 1))
+        x = hip.conv_gemm(ctx.dt, x48, self.patch.w, self.patch.N, self.patch.K, F=Bf, Hin=H, Win=W, Hout=H, Wout=W, ksize=2, stride=1, pad_t=1, pad_l=1,
+                          bias=self.patch.b, res0=pos, out_dtype=torch.float32)
         outs = []
         for i, L in enumerate(self.hb):
-            x, H, W = self._block(x, H, W, L)
+            x, H, W = self._block(x, Bf, H, W, L)
             if i in self.stage_ends:
                 outs.append((x, H, W))
         n = len(outs) - 1
@@ -336,7 +346,8 @@ class HipSam2:
             xi, Hi, Wi = outs[i]
             lat = self.neck[n - i](xi)
             if i in cfg.fpn_top_down_levels and prev is not None:
-                up = hip.gather_rows(prev, self._index(("up2", Hi, Wi), lambda: ((np.arange(Hi)[:, None] // 2) * (Wi // 2) + np.arange(Wi)[None, :] // 2).reshape(-1)))
+                one = lambda: ((np.arange(Hi)[:, None] // 2) * (Wi // 2) + np.arange(Wi)[None, :] // 2).reshape(-1)
+                up = hip.gather_rows(prev, self._index(("up2", Bf, Hi, Wi), lambda: (np.arange(Bf)[:, None] * ((Hi // 2) * (Wi // 2)) + one()[None, :]).reshape(-1)))
                 prev = hip.axpby(lat, up, 1.0, 1.0)
             else:
                 prev = lat
@@ -344,7 +355,12 @@ class HipSam2:
         if cfg.scalp > 0:
             feats = feats[:-cfg.scalp]
         f0, f1, top = feats[-3:]
-        return {"s0": self.conv_s0(f0), "s1": self.conv_s1(f1), "top": top}
+        s0, s1 = self.conv_s0(f0), self.conv_s1(f1)
+        n0, n1, nt = s0.shape[0] // Bf, s1.shape[0] // Bf, top.shape[0] // Bf
+        return [{"s0": s0[f * n0:(f + 1) * n0], "s1": s1[f * n1:(f + 1) * n1], "top": top[f * nt:(f + 1) * nt]} for f in range(Bf)]
+
+    def encode_image(self, frame_u8):
+        return self.encode_images([frame_u8])[0]
 
     # ---- memory attention ----------------------------------------------------------------------------------------------------------
     def _memory_attention(self, cur, memory, memory_pos, n_ptr_tokens):
