@@ -1415,6 +1415,26 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
             if (D <= 64) return cross ? attn_launch<T, D, 2, 64, 4, false, 3, true, 1>(p, st) : attn_launch<T, D, 2, 64, 4, false, 3, true, 0>(p, st);
             return cross ? attn_launch<T, D, 2, 64, 4, true, 1, false, 1>(p, st) : attn_launch<T, D, 2, 64, 4, true, 1, false, 0>(p, st);
         }
+#ifdef VV_AB      // lab build: block shapes for the long single-head case (SAM 2 memory attention, d = 256: profiles/r3_sam2_attn256_ab.txt)
+        if constexpr (D == 256) {
+            static int var = -1;
+            if (var < 0) { const char* e = getenv("VV_ATTN_VARIANT"); var = e ? atoi(e) : 0; }
+            if (var == 71) return attn_launch<T, D, 1, 64, 4, true>(p, st);       // 16 queries per wave: 64 per block
+            if (var == 72) return attn_launch<T, D, 2, 64, 2, true>(p, st);       // 2-wave blocks: 64 per block
+            if (var == 73) return attn_launch<T, D, 1, 64, 2, true>(p, st);       // 32 per block
+            if (var == 74) return attn_launch<T, D, 2, 32, 4, true>(p, st);       // 32-key tiles
+            if (var == 75) return attn_launch<T, D, 1, 32, 4, false>(p, st);      // the d = 512 form
+            if (var == 76) return attn_launch<T, D, 2, 64, 4, false>(p, st);      // no register prefetch
+            if (var == 77) return attn_launch<T, D, 1, 64, 8, true>(p, st);       // 8 waves x 16 queries
+            if (var == 78) return attn_launch<T, D, 2, 32, 1, true>(p, st);       // one wave per block
+        }
+#endif
+        // one long head (SAM 2 memory attention: d = 256, 4096 queries x up to 28736 keys) is 32 blocks whatever the block shape below 8 waves:
+        // eight waves of 16 queries keep the block's K/V tile loads covered (1.80 -> 1.05 ms; blocks of fewer than four waves are 7x slower:
+        // the register-staged loader wants 256 threads), profiles/r3_sam2_attn256_ab.txt
+        if constexpr (D == 256) {
+            if ((int64_t)p.B * p.heads * ((p.Nq + 127) / 128) <= 128) return attn_launch<T, D, 1, 64, 8, true>(p, st);
+        }
         return attn_launch<T, D, 2, 64, 4, true>(p, st);
     }
 }
