@@ -398,3 +398,36 @@ def test_batched_image_encoding_equals_frame_by_frame():
     for f, b in zip(frames, batch):
         one = hipm.encode_image(f)
         assert all(torch.equal(one[k], b[k]) for k in ("s0", "s1", "top"))
+
+
+def test_cli_main_on_the_hip_path(tmp_path, monkeypatch):
+    """reference sam2_masker.py:183-205 end to end on the GPU: FFV1 / Matroska in + a JSON annotation file -> main() -> SAM 2 on the HIP kernels
+    (tiny configuration, seeded weights) -> FFV1 / Matroska out; the decoded mask video equals a direct run_sam2_on_frames call."""
+    import json
+    import sys
+    import sam2_masker
+    from videovanish_amd import frameio as FIO
+    from videovanish_amd.sam2_config import TINY_SAM2
+    H, W = 96, 160
+    frames = _frames(5, H, W, seed=8)
+    color, ann_path = str(tmp_path / "color.mkv"), str(tmp_path / "ann.json")
+    FIO.write_video_frames_to_path(color, frames, 25.0, H, W)
+    ann = {"keyframes": [{"frame_idx": 0, "pos_clicks": [{"x": 0.5, "y": 0.5, "obj": 1}], "rects": [{"x": 0.1, "y": 0.1, "w": 0.4, "h": 0.5, "obj": 4}]}]}
+    json.dump(ann, open(ann_path, "w"))
+    monkeypatch.delitem(sys.modules, "tools", raising=False)
+    try:
+        sam2_masker.configure(cfg=TINY_SAM2, seed=13, dtype="fp16", device="cuda:0")
+        monkeypatch.setattr(sys, "argv", ["sam2_masker.py", "--color_video", color, "--annotations", ann_path])
+        sam2_masker.main()
+        out, fps = FIO.load_video_frames_from_path(color + "_sam2_mask.mkv")          # default output name, reference :193
+        assert abs(fps - 25.0) < 1e-3 and len(out) == 5 and all(o.shape == (H, W, 3) and o.dtype == np.uint8 for o in out)
+        ref = sam2_masker.run_sam2_on_frames(frames, ann)
+        assert all(np.array_equal(o, r) for o, r in zip(out, ref))
+        assert all(o.any() for o in out)                                              # prompted on frame 0: every frame carries a mask
+        monkeypatch.setattr(sys, "argv", ["sam2_masker.py", "--color_video", color, "--annotations", ann_path, "--start_frame", "1", "--max_frames", "3",
+                                          "--out", str(tmp_path / "part.mkv")])
+        sam2_masker.main()
+        part, _ = FIO.load_video_frames_from_path(str(tmp_path / "part.mkv"))
+        assert len(part) == 3
+    finally:
+        sam2_masker.configure(None)
