@@ -202,8 +202,15 @@ typedef struct {
                                          caller, so the single h16 rounding of q covers it); the kernel then skips its own scaling.
                                          The d = 40 spatial kernel subtracts the softmax reference maximum on the matrix pipe and
                                          needs Q in that form: with q_prescaled = 0 it rescales (and re-rounds) Q itself */
+    float* lse;                       /* optional (ABI 8) [B][heads][Nq] fp32: log2 of sum_k 2^(scale log2e q.k) over THIS call's keys.  With it a
+                                         long key sequence is split over the batch index (q_bs = 0, k_bs = v_bs = chunk * row stride) and the
+                                         partial outputs are merged by vv_attention_merge: more blocks for one long head (SAM 2 memory attention:
+                                         4096 queries x 28736 keys, one head of 256).  Generic kernel only (not the d = 40 spatial form). */
 } vv_attn_params;
 int vv_attention(const vv_attn_params* host_p, int dtype, void* stream);
+/* out[q][h*D + c] = sum_s w_s o_parts[s][q][h*D + c] / sum_s w_s, w_s = 2^(lse[s][h][q] - max_s lse): merges S partial attention results
+ * (o_parts: h16 [S][Nq][ld], lse: [S][heads][Nq]) into out (h16 [Nq][ld]) */
+int vv_attention_merge(const void* o_parts, const float* lse, int S, int heads, int Nq, int D, int ld, void* out, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K12  scheduler / latent elementwise (fp32).  Replaces scheduler.add_noise / scheduler.step.

@@ -121,6 +121,25 @@ def test_conv_gemm_2x2_kernels(hipmod):
     assert _rel(out, ref) < 2e-3                                                          # h16 rounding of the image and the weights
 
 
+@pytest.mark.parametrize("D,Nq,Nk", [(256, 1024, 4 * 1040), (64, 200, 4 * 77), (80, 333, 4 * 500)])
+def test_attention_split_kv(hipmod, D, Nq, Nk):
+    """vv_attention's log-sum-exp output + vv_attention_merge: the keys of one long sequence split 4 ways over the batch index give the unsplit
+    result (against fp32 torch and against the unsplit kernel)."""
+    hip = hipmod
+    g = torch.Generator().manual_seed(5)
+    heads = 2 if D < 256 else 1
+    I = heads * D
+    q, k, v = (torch.randn(n, I, generator=g).half().to(_dev()) for n in (Nq, Nk, Nk))
+    k = k * 1.5
+    o_split, o_one = torch.empty(Nq, I, dtype=torch.float16, device=_dev()), torch.empty(Nq, I, dtype=torch.float16, device=_dev())
+    kw = dict(heads=heads, Nq=Nq, Nkv=Nk, D=D, q_rs=I, k_rs=I, v_rs=I, o_rs=I, q_hs=D, k_hs=D, v_hs=D)
+    hip.attention_split_kv(hip.F16, q, k, v, o_split, S=4, **kw)
+    hip.attention(hip.F16, q, k, v, o_one, B=1, q_bs=0, k_bs=0, v_bs=0, o_bs=0, **kw)
+    sep = lambda t: t.float().cpu().reshape(t.shape[0], heads, D).transpose(0, 1)[None]
+    ref = F.scaled_dot_product_attention(sep(q), sep(k), sep(v))[0].transpose(0, 1).reshape(Nq, I)
+    assert _rel(o_one, ref) < 2e-3 and _rel(o_split, ref) < 2e-3 and _rel(o_split, o_one.float()) < 1.5e-3
+
+
 def test_rope_dwconv_positional_kernels(hipmod):
     hip = hipmod
     from oracle import sam2_ref

@@ -414,6 +414,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
         const float inv = 1.0f / l;
         const int q = q0 + j * 16 + li;
         if (q < p.Nq) {
+            if constexpr (!LAZY) {      // log-sum-exp of this call's keys (log2 domain) for vv_attention_merge
+                if (p.lse && lg == 0) p.lse[((int64_t)b * p.heads + h) * p.Nq + q] = mrun[j] * c + __log2f(l);
+            }
 #pragma unroll
             for (int d = 0; d < NDT; ++d) {
                 const int dd = d * 16 + lg * 4;
@@ -1460,6 +1463,41 @@ int attn_by_d(const vv_attn_params& p, hipStream_t st) {
 }  // namespace
 
 #if VV_ATTN_PART == 0
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void attn_merge_kernel(const unsigned short* __restrict__ parts, const float* __restrict__ lse, int S, int heads, int Nq, int D,
+                                                         int ld, unsigned short* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;        // one thread per (query, head, pair of channels)
+    const int half = D >> 1;
+    if (i >= (int64_t)Nq * heads * half) return;
+    const int c2 = (int)(i % half);
+    const int h = (int)((i / half) % heads);
+    const int q = (int)(i / ((int64_t)half * heads));
+    float mx = -3.0e38f;
+    for (int s = 0; s < S; ++s) mx = fmaxf(mx, lse[((int64_t)s * heads + h) * Nq + q]);
+    float a0 = 0.f, a1 = 0.f, den = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float w = __builtin_amdgcn_exp2f(lse[((int64_t)s * heads + h) * Nq + q] - mx);
+        const unsigned u = *(const unsigned*)(parts + ((int64_t)s * Nq + q) * ld + h * D + 2 * c2);
+        a0 = fmaf(w, T::to_f32(u & 0xffff), a0); a1 = fmaf(w, T::to_f32(u >> 16), a1); den += w;
+    }
+    const float inv = 1.0f / den;
+    *(unsigned*)(out + (int64_t)q * ld + h * D + 2 * c2) = pack2<T>(a0 * inv, a1 * inv);
+}
+}  // namespace
+
+extern "C" int vv_attention_merge(const void* o_parts, const float* lse, int S, int heads, int Nq, int D, int ld, void* out, int dtype, void* stream) {
+    if (!o_parts || !lse || !out || S <= 0 || heads <= 0 || Nq <= 0 || D <= 0 || (D & 1) || (ld & 1) || ld < heads * D) VV_FAIL(VV_E_ARG, "vv_attention_merge: bad arguments");
+    const int64_t n = (int64_t)Nq * heads * (D / 2);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VV_BF16) hipLaunchKernelGGL(attn_merge_kernel<BF16>, grid, dim3(256), 0, st, (const unsigned short*)o_parts, lse, S, heads, Nq, D, ld, (unsigned short*)out);
+    else if (dtype == VV_F16) hipLaunchKernelGGL(attn_merge_kernel<F16>, grid, dim3(256), 0, st, (const unsigned short*)o_parts, lse, S, heads, Nq, D, ld, (unsigned short*)out);
+    else VV_FAIL(VV_E_ARG, "vv_attention_merge: bad dtype");
+    VV_CHECK_LAUNCH("vv_attention_merge");
+    return VV_OK;
+}
+
 extern "C" int vv_attention_large_d(const vv_attn_params* pp, int dtype, void* stream);
 
 extern "C" int vv_attention(const vv_attn_params* pp, int dtype, void* stream) {
@@ -1470,6 +1508,7 @@ extern "C" int vv_attention(const vv_attn_params* pp, int dtype, void* stream) {
     if ((p.q_rs | p.k_rs | p.v_rs | p.o_rs | p.q_bs | p.k_bs | p.v_bs | p.o_bs) & 3) VV_FAIL(VV_E_ARG, "vv_attention: strides must be multiples of 4 elements (q/k/v: 8)");
     if ((p.q_rs | p.k_rs | p.v_rs | p.q_bs | p.k_bs | p.v_bs | p.q_hs | p.k_hs | p.v_hs) & 7) VV_FAIL(VV_E_ARG, "vv_attention: q/k/v strides must be multiples of 8 elements");
     if (dtype != VV_BF16 && dtype != VV_F16) VV_FAIL(VV_E_ARG, "vv_attention: bad dtype");
+    if (p.lse && p.D == 40) VV_FAIL(VV_E_UNSUPPORTED, "vv_attention: lse output is not available at D = 40");
     if (p.D > 80) return vv_attention_large_d(pp, dtype, stream);
     return dtype == VV_BF16 ? attn_by_d<BF16>(p, (hipStream_t)stream) : attn_by_d<F16>(p, (hipStream_t)stream);
 }

@@ -92,7 +92,7 @@ class AttnParams(C.Structure):
                 ("q_bs", C.c_int64), ("k_bs", C.c_int64), ("v_bs", C.c_int64), ("o_bs", C.c_int64),
                 ("q_rs", C.c_int64), ("k_rs", C.c_int64), ("v_rs", C.c_int64), ("o_rs", C.c_int64),
                 ("B", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nkv", C.c_int32), ("D", C.c_int32),
-                ("scale", C.c_float), ("q_hs", C.c_int64), ("k_hs", C.c_int64), ("v_hs", C.c_int64), ("q_prescaled", C.c_int32)]
+                ("scale", C.c_float), ("q_hs", C.c_int64), ("k_hs", C.c_int64), ("v_hs", C.c_int64), ("q_prescaled", C.c_int32), ("lse", C.c_void_p)]
 
 
 EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name", "vv_conv_gemm", "vv_groupnorm_nsplit",
@@ -106,7 +106,7 @@ EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name
            # SAM 2 (row n4)
            "vv_u8_normalize", "vv_layernorm_ex", "vv_maxpool2x2", "vv_rope_apply", "vv_dwconv", "vv_pixel_shuffle2", "vv_resize_bilinear_f32",
            "vv_mask_mem_input", "vv_act", "vv_prompt_points", "vv_sine_pe_1d", "vv_sam_select", "vv_sam_pick", "vv_select_f32",
-           "vv_add_rowvec_unless", "vv_clamp_f32", "vv_fill_holes", "vv_hyper_masks"]
+           "vv_add_rowvec_unless", "vv_clamp_f32", "vv_fill_holes", "vv_hyper_masks", "vv_attention_merge"]
 
 
 def lib():
@@ -295,14 +295,14 @@ def attention_q_scale(D):
 
 
 def attention(dtype, q, k, v, out, *, B, heads, Nq, Nkv, D, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, q_off=0, k_off=0, v_off=0,
-              q_hs=0, k_hs=0, v_hs=0, q_prescaled=False, scale=None):
+              q_hs=0, k_hs=0, v_hs=0, q_prescaled=False, scale=None, lse=None):
     """q/k/v/out: h16 tensors (any shape); element offsets *_off select a column block inside a fused QKV buffer.
     q_prescaled: q already carries D**-0.5 * log2(e) (attention_q_scale(D) folded into the query projection)."""
     _need_cuda(q, k, v, out)
     es = 2
     p = AttnParams(q=q.data_ptr() + q_off * es, k=k.data_ptr() + k_off * es, v=v.data_ptr() + v_off * es, o=out.data_ptr(),
                    q_bs=q_bs, k_bs=k_bs, v_bs=v_bs, o_bs=o_bs, q_rs=q_rs, k_rs=k_rs, v_rs=v_rs, o_rs=o_rs, B=B, heads=heads, Nq=Nq,
-                   Nkv=Nkv, D=D, scale=float(D) ** -0.5 if scale is None else float(scale), q_hs=q_hs, k_hs=k_hs, v_hs=v_hs, q_prescaled=1 if q_prescaled else 0)
+                   Nkv=Nkv, D=D, scale=float(D) ** -0.5 if scale is None else float(scale), q_hs=q_hs, k_hs=k_hs, v_hs=v_hs, q_prescaled=1 if q_prescaled else 0, lse=lse.data_ptr() if lse is not None else 0)
     kind = "temporal" if (Nq <= 32 and Nkv <= 32) else ("cross" if Nkv < 128 and Nq != Nkv else "spatial")
     if os.environ.get("VV_PROFILE_SHAPES"):
         kind = f"B{B},N{Nq}|" + kind
@@ -850,4 +850,18 @@ def hyper_masks(hyper, up):
     nm, Cc = hyper.shape
     out = torch.empty((nm, up.shape[0]), dtype=torch.float32, device=up.device)
     _check(lib().vv_hyper_masks(_p(hyper), _p(up), up.shape[0], Cc, nm, _p(out), _stream()), "vv_hyper_masks")
+    return out
+
+
+def attention_split_kv(dtype, q, k, v, out, *, heads, Nq, Nkv, D, S, q_rs, k_rs, v_rs, o_rs, q_hs=0, k_hs=0, v_hs=0, scale=None):
+    """one batch of `heads` heads over a LONG key sequence, the keys split into S equal chunks that run as S batches of vv_attention (S x the blocks)
+    and are merged through their log-sum-exps (vv_attention_merge).  Nkv % S == 0.  q / k / v / out: row-major [N, heads * D]-style matrices."""
+    if Nkv % S:
+        raise RuntimeError(f"attention_split_kv: Nkv={Nkv} is not a multiple of S={S}")
+    chunk = Nkv // S
+    parts = torch.empty((S, Nq, o_rs), dtype=h16(dtype), device=q.device)
+    lse = torch.empty((S, heads, Nq), dtype=torch.float32, device=q.device)
+    attention(dtype, q, k, v, parts, B=S, heads=heads, Nq=Nq, Nkv=chunk, D=D, q_bs=0, k_bs=chunk * k_rs, v_bs=chunk * v_rs, o_bs=Nq * o_rs,
+              q_rs=q_rs, k_rs=k_rs, v_rs=v_rs, o_rs=o_rs, q_hs=q_hs, k_hs=k_hs, v_hs=v_hs, scale=scale, lse=lse)
+    _check(lib().vv_attention_merge(_p(parts), _p(lse), S, heads, Nq, D, o_rs, _p(out), dtype, _stream()), "vv_attention_merge")
     return out

@@ -113,8 +113,13 @@ class _Attention:
             hip.rope_apply(m.ctx.dt, k, k.shape[0] if rows_rope_k is None else rows_rope_k, m.rope_cs, self.dp)
         Nq, Nk, I = q.shape[0], k.shape[0], self.heads * self.dp
         o = torch.empty((Nq, I), dtype=h16, device=q.device)
-        hip.attention(m.ctx.dt, q, k, v, o, B=1, heads=self.heads, Nq=Nq, Nkv=Nk, D=self.dp, q_bs=0, k_bs=0, v_bs=0, o_bs=0, q_rs=I, k_rs=I, v_rs=I,
-                      o_rs=I, q_hs=self.dp, k_hs=self.dp, v_hs=self.dp, scale=float(self.d) ** -0.5)
+        if self.heads == 1 and Nq >= 1024 and Nk >= 2048 and Nk % 4 == 0:
+            # one long head is only Nq / 128 blocks: split the keys 4 ways over the batch index and merge by log-sum-exp (4 x the blocks)
+            hip.attention_split_kv(m.ctx.dt, q, k, v, o, heads=1, Nq=Nq, Nkv=Nk, D=self.dp, S=4, q_rs=I, k_rs=I, v_rs=I, o_rs=I, q_hs=self.dp,
+                                   k_hs=self.dp, v_hs=self.dp, scale=float(self.d) ** -0.5)
+        else:
+            hip.attention(m.ctx.dt, q, k, v, o, B=1, heads=self.heads, Nq=Nq, Nkv=Nk, D=self.dp, q_bs=0, k_bs=0, v_bs=0, o_bs=0, q_rs=I, k_rs=I,
+                          v_rs=I, o_rs=I, q_hs=self.dp, k_hs=self.dp, v_hs=self.dp, scale=float(self.d) ** -0.5)
         return self.o(o, res0=res0)
 
 
