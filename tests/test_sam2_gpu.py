@@ -450,3 +450,27 @@ def test_cli_main_on_the_hip_path(tmp_path, monkeypatch):
         assert len(part) == 3
     finally:
         sam2_masker.configure(None)
+
+
+def test_bf16_operands():
+    """the other MFMA operand type (8 significant bits): image encoder and a prompted frame of the tiny configuration at the bf16 tolerance."""
+    from oracle.sam2_ref import OracleSam2
+    from videovanish_amd.sam2_config import TINY_SAM2 as cfg
+    from videovanish_amd.sam2_model import HipSam2
+    from videovanish_amd.sam2_weights import Sam2Weights
+    w = Sam2Weights(cfg, 5)
+    ora, hipm = OracleSam2(cfg, w), HipSam2(cfg, w, device="cuda:0", dtype="bf16")
+    S = cfg.image_size
+    frame = _frames(1, S, S)[0]
+    fo, fh = ora.encode_image(frame), hipm.encode_image(frame)
+    nhwc = lambda t: t[0].permute(1, 2, 0).reshape(-1, t.shape[1])
+    e = max(_rel(fh["top"], nhwc(fo["fpn"][2])), _rel(fh["s1"], nhwc(fo["fpn"][1])), _rel(fh["s0"], nhwc(fo["fpn"][0])))
+    pi = {"point_coords": torch.tensor([[[0.4 * S, 0.5 * S]]], dtype=torch.float32), "point_labels": torch.tensor([[1]], dtype=torch.int32)}
+    empty = lambda: {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+    o = ora.track_step(0, True, fo, pi, empty(), 1, run_mem_encoder=True)
+    h = hipm.track_step(0, True, fh, pi, empty(), 1, run_mem_encoder=True)
+    e_m = _rel(h["pred_masks"].cpu().reshape(-1), o["pred_masks"].reshape(-1))
+    e_mem = _rel(hipm.encode_memory_from_low_res(fh, o["pred_masks"].reshape(-1).contiguous().to(_dev()), torch.tensor([1.0]).to(_dev()), True)[0],
+                 nhwc(ora.encode_memory_from_low_res(fo, o["pred_masks"], torch.tensor([[1.0]]), True)[0]))
+    print(f"sam2_bf16[tiny]: image encoder rel {e:.2e}, prompted logits rel {e_m:.2e}, memory encoder rel {e_mem:.2e}")
+    assert e < 1.6e-2 and e_m < 5e-2 and e_mem < 1.6e-2
