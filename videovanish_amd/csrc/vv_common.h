@@ -52,7 +52,20 @@ template <typename T> __device__ __forceinline__ void unpack8(uint4 u, float* v)
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact (erf) GELU, matching torch.nn.functional.gelu default
+#ifndef VV_GELU_AS
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+#else
+// lab build (-DVV_GELU_AS): erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, one v_rcp + one v_exp + 6 FMAs instead of ocml's two-branch erff);
+// measured in profiles/r3_gelu_as_ab.txt, NOT the product default (every numerics change is re-validated against the 1e-3 parity asserts first)
+__device__ __forceinline__ float gelu_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f); p = fmaf(p, t, -0.284496736f); p = fmaf(p, t, 0.254829592f);
+    const float erfz = 1.0f - p * t * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(erfz, x));
+}
+#endif
 
 // host-side error plumbing -------------------------------------------------------------------------------------
 void vv_set_error(const char* fmt, ...);

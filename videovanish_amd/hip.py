@@ -40,7 +40,8 @@ class _Prof:
         return False
 
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libvvhip.so")
+# $VV_LIB_PATH: another build of the library (A/B of two builds on one device: tools/, lab builds); default = the in-tree product build
+_LIB_PATH = os.environ.get("VV_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libvvhip.so")
 _lib = None
 
 
