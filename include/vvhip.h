@@ -235,6 +235,11 @@ int vv_mask_collapse_dilate(const uint8_t* masks, int T, int H, int W, int ch, i
 /* cv2.resize INTER_LINEAR / INTER_NEAREST on uint8 (reference diffuerase.py:73,86), T images [Hs][Ws][ch]. */
 int vv_resize_bilinear_u8(const uint8_t* src, int T, int Hs, int Ws, int ch, uint8_t* dst, int Hd, int Wd, void* stream);
 int vv_resize_nearest_u8(const uint8_t* src, int T, int Hs, int Ws, int ch, uint8_t* dst, int Hd, int Wd, void* stream);
+/* planar 8-bit YCbCr -> RGB24 on the GPU (row n3: colour conversion of decoded frames; replaces the libswscale conversion behind cv2.VideoCapture,
+ * reference tools.py:17-21): y [T][H][W], cb / cr [T][ceil(H >> vshift)][ceil(W >> hshift)] -> rgb [T][H][W][3].  BT.601 matrix, limited (16..235) or
+ * full range, MPEG-2 4:2:0 chroma siting with bilinear chroma interpolation, integer arithmetic identical to vvio_ycbcr_to_rgb (include/vvio.h). */
+int vv_ycbcr_to_rgb(const uint8_t* y, const uint8_t* cb, const uint8_t* cr, int T, int H, int W, int hshift, int vshift, int full_range, uint8_t* rgb,
+                    void* stream);
 /* reference diffuerase.py:77-112: alpha from the 5x5-chamfer distance transforms of mask / inverse mask (16.16 fixed
  * point, evaluated in a (2R+1)^2 window, R = ceil(feather_px): alpha saturates beyond), then
  * out = clip(rint(alpha*inp + (1-alpha)*orig)).  feather_px <= 0: hard composite. */

@@ -11,7 +11,7 @@
 extern "C" {
 #endif
 
-#define VVIO_ABI_VERSION 1
+#define VVIO_ABI_VERSION 2
 int vvio_abi_version(void);
 
 /* FFV1 configuration record (the Matroska CodecPrivate payload after the BITMAPINFOHEADER; RFC 9043 section 4.2) for RGB24 frames cut
@@ -30,6 +30,16 @@ int vvio_ffv1_encode_frame(const uint8_t* rgb, int W, int H, int num_v_slices, u
  * sample, coded initial states, inter (non-key) frames, and any header field outside its range (the stream is untrusted input).
  * 0 = ok, negative = error code.  Replaces VideoCapture.read (reference tools.py:17-21). */
 int vvio_ffv1_decode_frame(const uint8_t* cfg, int cfglen, const uint8_t* data, int len, int W, int H, uint8_t* rgb);
+
+/* ---- ABI 2: planar YCbCr streams (colorspace_type 0: what ffmpeg writes for yuv420p / yuv422p / yuv444p / gray FFV1) ----
+ * vvio_ffv1_stream_info: info[6] = colorspace_type (0 YCbCr, 1 RGB), chroma_planes, log2_h_chroma_subsample, log2_v_chroma_subsample, extra_plane,
+ * bits_per_raw_sample.  vvio_ffv1_decode_frame_yuv: Y [H][W], Cb / Cr [ceil(H >> vshift)][ceil(W >> hshift)] (gray: 128); Golomb-Rice or range-coded
+ * samples, any slice grid, optional alpha plane (dropped).  vvio_ffv1_decode_frame refuses YCbCr streams with -9 and vice versa. */
+int vvio_ffv1_stream_info(const uint8_t* cfg, int cfglen, int* info);
+int vvio_ffv1_decode_frame_yuv(const uint8_t* cfg, int cfglen, const uint8_t* data, int len, int W, int H, uint8_t* y, uint8_t* cb, uint8_t* cr);
+/* YCbCr -> RGB24 on the host, the same integer arithmetic as the GPU kernel vv_ycbcr_to_rgb (include/vvhip.h): BT.601, limited or full range,
+ * MPEG-2 4:2:0 chroma siting, bilinear chroma.  Used when no GPU is visible (frame I/O is host work; the hot path has no CPU fallback). */
+int vvio_ycbcr_to_rgb(const uint8_t* y, const uint8_t* cb, const uint8_t* cr, int W, int H, int hshift, int vshift, int full_range, uint8_t* rgb);
 
 #ifdef __cplusplus
 }

@@ -158,7 +158,7 @@ def _put_quant_table(rc, tab):
     rc.put_symbol(st, i - last - 1, False)
 
 
-def config_record(coder, nh, nv, alpha=False, ec=1, sets=None):
+def config_record(coder, nh, nv, alpha=False, ec=1, sets=None, colorspace=1, chroma_planes=True, hshift=0, vshift=0):
     rc = RangeEncoder()
     st = [128] * 32
     rc.put_symbol(st, 3, False)            # version
@@ -168,11 +168,11 @@ def config_record(coder, nh, nv, alpha=False, ec=1, sets=None):
         d = default_state_transition()
         for i in range(1, 256):
             rc.put_symbol(st, ALT_STATE[i] - d[i], True)
-    rc.put_symbol(st, 1, False)            # colorspace_type RGB
+    rc.put_symbol(st, colorspace, False)   # colorspace_type: 1 RGB (JPEG 2000 RCT), 0 YCbCr
     rc.put_symbol(st, 8, False)            # bits_per_raw_sample
-    rc.put(st, 0, 1)                       # chroma_planes
-    rc.put_symbol(st, 0, False)
-    rc.put_symbol(st, 0, False)
+    rc.put(st, 0, 1 if chroma_planes else 0)
+    rc.put_symbol(st, hshift, False)       # log2_h_chroma_subsample
+    rc.put_symbol(st, vshift, False)       # log2_v_chroma_subsample
     rc.put(st, 0, 1 if alpha else 0)       # extra_plane
     rc.put_symbol(st, nh - 1, False)
     rc.put_symbol(st, nv - 1, False)
@@ -196,8 +196,158 @@ def _median(a, b, c):
     return sorted((a, b, c))[1]
 
 
+# ---- Golomb-Rice sample coding (RFC 9043 3.8.2), written from the RFC: run mode + adaptive Rice parameter per context -------------------------
+LOG2_RUN = [0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24]
+
+
+class BitWriter:
+    def __init__(self):
+        self.bits = []
+
+    def put(self, n, v):
+        for i in range(n - 1, -1, -1):
+            self.bits.append((v >> i) & 1)
+
+    def tobytes(self):
+        b = self.bits + [0] * (-len(self.bits) % 8)
+        return bytes(int("".join(map(str, b[i:i + 8])), 2) for i in range(0, len(b), 8))
+
+
+class VlcState:
+    def __init__(self):
+        self.drift, self.error_sum, self.bias, self.count = 0, 4, 0, 1
+
+
+def _fold(v, bits):
+    v &= (1 << bits) - 1
+    return v - (1 << bits) if v >> (bits - 1) else v
+
+
+def _put_vlc(bw, st, v, bits):
+    v = _fold(v - st.bias, bits)
+    k, i = 0, st.count
+    while i < st.error_sum:
+        k, i = k + 1, i + i
+    code = v ^ (-1 if 2 * st.drift + st.count < 0 else 0)
+    u = 2 * code if code >= 0 else -2 * code - 1            # signed -> unsigned: 0, -1, 1, -2, ... -> 0, 1, 2, 3, ...
+    e = u >> k
+    if e < 12:
+        bw.put(e, 0)
+        bw.put(1, 1)
+        bw.put(k, u & ((1 << k) - 1))
+    else:
+        bw.put(12, 0)
+        bw.put(bits, u - 11)
+    # state update (RFC 9043 3.8.2.4)
+    st.error_sum += abs(v)
+    st.drift += v
+    if st.count == 128:
+        st.count >>= 1
+        st.drift >>= 1
+        st.error_sum >>= 1
+    st.count += 1
+    if st.drift <= -st.count:
+        st.bias = max(st.bias - 1, -128)
+        st.drift = max(st.drift + st.count, -st.count + 1)
+    elif st.drift > 0:
+        st.bias = min(st.bias + 1, 127)
+        st.drift = min(st.drift - st.count, 0)
+
+
+class GolombLineCoder:
+    """codes the (context, difference) pairs of successive lines; the run index persists across the lines (and planes) it is used for."""
+
+    def __init__(self, bw, bits):
+        self.bw, self.bits, self.run_index = bw, bits, 0
+
+    def _flush(self, run_count, final):
+        while run_count >= 1 << LOG2_RUN[self.run_index]:
+            run_count -= 1 << LOG2_RUN[self.run_index]
+            self.run_index += 1
+            self.bw.put(1, 1)
+        return run_count
+
+    def line(self, symbols, states):
+        run_mode, run_count = False, 0
+        for ctx, diff in symbols:
+            if ctx == 0:
+                run_mode = True
+            if run_mode:
+                if diff != 0:
+                    run_count = self._flush(run_count, False)
+                    self.bw.put(1 + LOG2_RUN[self.run_index], run_count)
+                    if self.run_index:
+                        self.run_index -= 1
+                    run_count, run_mode = 0, False
+                    if diff > 0:
+                        diff -= 1
+                else:
+                    run_count += 1
+            if not run_mode:
+                _put_vlc(self.bw, states[ctx], diff, self.bits)
+        if run_mode:
+            run_count = self._flush(run_count, True)
+            if run_count:
+                self.bw.put(1, 1)
+
+
+def _line_symbols(P, qs, y, w, bits):
+    """(context, difference) of every sample of line y of plane P (int array [h, w]) under the border rules of RFC 9043 3.2."""
+    five = any(qs[3]) or any(qs[4])
+    half = 1 << (bits - 1)
+
+    def S(yy, xx):
+        if yy < 0 or xx < -1:
+            return 0                                   # rows above the slice and the additional column to the left are 0
+        if xx < 0:
+            return S(yy - 1, 0) if yy > 0 else 0       # left border = the first column shifted down by one row, 0 on top
+        if xx >= w:
+            return int(P[yy, w - 1])
+        return int(P[yy, xx])
+    out = []
+    for x in range(w):
+        L, T, LT, RT = S(y, x - 1), S(y - 1, x), S(y - 1, x - 1), S(y - 1, x + 1)
+        ctx = qs[0][(L - LT) & 0xFF] + qs[1][(LT - T) & 0xFF] + qs[2][(T - RT) & 0xFF]
+        if five:
+            ctx += qs[3][(S(y, x - 2) - L) & 0xFF] + qs[4][(S(y - 2, x) - T) & 0xFF]
+        diff = int(P[y, x]) - _median(L, L + T - LT, T)
+        if ctx < 0:
+            ctx, diff = -ctx, -diff
+        out.append((ctx, ((diff + half) & (2 * half - 1)) - half))       # folded to `bits` bits
+    return out
+
+
+def _slice_header(rc, first, coder, sx, sy, qidx):
+    if first:
+        rc.put([128], 0, 1)        # keyframe
+    if coder == 2:
+        rc.set_table(ALT_STATE)
+    st = [128] * 32
+    for v in (sx, sy, 0, 0):
+        rc.put_symbol(st, v, False)
+    for v in qidx:
+        rc.put_symbol(st, v, False)
+    rc.put_symbol(st, 3, False)    # picture_structure
+    rc.put_symbol(st, 0, False)
+    rc.put_symbol(st, 0, False)
+
+
+def _finish_slice(rc, bw, ec):
+    if bw is not None:                                   # Golomb-Rice: the range coder only carried the header
+        rc.put([129], 0, 0)
+        body = rc.terminate() + bw.tobytes()
+    else:
+        body = rc.terminate()
+    sl = bytearray(body) + len(body).to_bytes(3, "big")
+    if ec:
+        sl += b"\x00"
+        sl += crc32_mpeg(bytes(sl)).to_bytes(4, "big")
+    return sl
+
+
 def encode_frame(rgb, coder, nh, nv, alpha=None, ec=1, set_luma=0, set_chroma=1, set_alpha=0):
-    """rgb: (H, W, 3) uint8; alpha: optional (H, W) uint8.  Returns the FFV1 packet (all slices, range-coded samples)."""
+    """rgb: (H, W, 3) uint8; alpha: optional (H, W) uint8.  coder 1 / 2: range-coded samples (default / custom state table); coder 0:
+    Golomb-Rice.  Returns the FFV1 packet (all slices).  RGB mode codes the planes G, B-G, R-G (9 bits) line by line, interleaved."""
     sets, counts = quant_tables()
     H, W = rgb.shape[:2]
     pkt = bytearray()
@@ -208,30 +358,10 @@ def encode_frame(rgb, coder, nh, nv, alpha=None, ec=1, set_luma=0, set_chroma=1,
             x0, x1 = sx * W // nh, (sx + 1) * W // nh
             w, h = x1 - x0, y1 - y0
             rc = RangeEncoder()
-            if first:
-                rc.put([128], 0, 1)        # keyframe
-                first = False
-            if coder == 2:
-                rc.set_table(ALT_STATE)
-            st = [128] * 32
-            for v in (sx, sy, 0, 0):
-                rc.put_symbol(st, v, False)
             qidx = [set_luma, set_chroma] + ([set_alpha] if alpha is not None else [])
-            for v in qidx:
-                rc.put_symbol(st, v, False)
-            rc.put_symbol(st, 3, False)    # picture_structure
-            rc.put_symbol(st, 0, False)
-            rc.put_symbol(st, 0, False)
-            nplanes = 4 if alpha is not None else 3
+            _slice_header(rc, first, coder, sx, sy, qidx)
+            first = False
             plane_set = [qidx[0], qidx[1], qidx[1]] + ([qidx[2]] if alpha is not None else [])
-            states = {}
-            for s in set(plane_set):
-                pass
-            # one state array per CONTEXT SET index (planes 1 and 2 share theirs; luma / alpha sets are separate arrays even when they
-            # name the same table set)
-            sarr = [[128] * (32 * counts[plane_set[0]]), [128] * (32 * counts[plane_set[1]])]
-            if alpha is not None:
-                sarr.append([128] * (32 * counts[plane_set[3]]))
             px = rgb[y0:y1, x0:x1].astype(np.int32)
             g, b, r = px[..., 1].copy(), px[..., 2].copy(), px[..., 0].copy()
             b -= g
@@ -240,41 +370,65 @@ def encode_frame(rgb, coder, nh, nv, alpha=None, ec=1, set_luma=0, set_chroma=1,
             b += 256
             r += 256
             planes = [g, b, r] + ([alpha[y0:y1, x0:x1].astype(np.int32)] if alpha is not None else [])
+            # one state array per plane INDEX (0 luma, 1 both chroma planes, 2 alpha), even when two indices name the same table set
+            nidx = 3 if alpha is not None else 2
+            if coder == 0:
+                bw = BitWriter()
+                gl = GolombLineCoder(bw, 9)
+                vst = [[VlcState() for _ in range(counts[plane_set[[0, 1, 3][i]]])] for i in range(nidx)]
+            else:
+                bw = None
+                sarr = [[128] * (32 * counts[plane_set[[0, 1, 3][i]]]) for i in range(nidx)]
             for y in range(h):
-                for p in range(nplanes):
-                    P = planes[p]
-                    qs = sets[plane_set[p]]
-                    five = any(qs[3]) or any(qs[4])
-                    arr = sarr[(p + 1) // 2]
+                for p, P in enumerate(planes):
+                    syms = _line_symbols(P, sets[plane_set[p]], y, w, 9)
+                    if coder == 0:
+                        gl.line(syms, vst[(p + 1) // 2])
+                    else:
+                        arr = sarr[(p + 1) // 2]
+                        for ctx, diff in syms:
+                            rc.put_symbol(arr, diff, True, base=32 * ctx)
+            pkt += _finish_slice(rc, bw, ec)
+    return bytes(pkt)
 
-                    def S(yy, xx):          # RFC 9043 3.1-3.2: samples outside the slice
-                        if yy < 0:
-                            return 0
-                        if xx < 0:
-                            return S(yy - 1, 0) if yy > 0 else 0       # left border = top sample of the first column ... of the row above
-                        if xx >= w:
-                            return int(P[yy, w - 1])
-                        return int(P[yy, xx])
-                    for x in range(w):
-                        L, T, LT, RT = S(y, x - 1), S(y - 1, x), S(y - 1, x - 1), S(y - 1, x + 1)
-                        if y == 0:
-                            T = LT = RT = 0
-                        ctx = qs[0][(L - LT) & 0xFF] + qs[1][(LT - T) & 0xFF] + qs[2][(T - RT) & 0xFF]
-                        if five:
-                            LL = S(y, x - 2) if x >= 1 else L          # cur[-2] = cur[-1] at the left border
-                            TT = S(y - 2, x) if y >= 2 else 0
-                            ctx += qs[3][(LL - L) & 0xFF] + qs[4][(TT - T) & 0xFF]
-                        pred = _median(L, L + T - LT, T)
-                        diff = int(P[y, x]) - pred
-                        if ctx < 0:
-                            ctx, diff = -ctx, -diff
-                        diff = ((diff + 256) & 0x1FF) - 256               # fold to 9 bits
-                        rc.put_symbol(arr, diff, True, base=32 * ctx)
-            body = rc.terminate()
-            n = len(body)
-            sl = bytearray(body) + n.to_bytes(3, "big")
-            if ec:
-                sl += b"\x00"
-                sl += crc32_mpeg(bytes(sl)).to_bytes(4, "big")
-            pkt += sl
+
+def encode_frame_ycbcr(y, cb, cr, coder, nh, nv, hshift, vshift, alpha=None, ec=1, set_luma=0, set_chroma=1, set_alpha=0):
+    """planar 8-bit YCbCr (colorspace_type 0): y (H, W), cb / cr (ceil(H >> vshift), ceil(W >> hshift)) or None for a gray stream.  Per slice
+    the planes are coded one after the other (Y, Cb, Cr [, alpha]); Cb and Cr share the context states of plane index 1; the run index of the
+    Golomb-Rice coder restarts with every plane (RFC 9043 4.7 / 3.8.2.2)."""
+    sets, counts = quant_tables()
+    H, W = y.shape
+    chroma = cb is not None
+    pkt = bytearray()
+    first = True
+    for sy in range(nv):
+        for sx in range(nh):
+            y0, y1 = sy * H // nv, (sy + 1) * H // nv
+            x0, x1 = sx * W // nh, (sx + 1) * W // nh
+            w, h = x1 - x0, y1 - y0
+            rc = RangeEncoder()
+            qidx = [set_luma] + ([set_chroma] if chroma else []) + ([set_alpha] if alpha is not None else [])
+            _slice_header(rc, first, coder, sx, sy, qidx)
+            first = False
+            cw, ch = (w + (1 << hshift) - 1) >> hshift, (h + (1 << vshift) - 1) >> vshift
+            cx, cy = x0 >> hshift, y0 >> vshift
+            jobs = [(y[y0:y1, x0:x1].astype(np.int32), 0, set_luma)]
+            if chroma:
+                jobs += [(cb[cy:cy + ch, cx:cx + cw].astype(np.int32), 1, set_chroma), (cr[cy:cy + ch, cx:cx + cw].astype(np.int32), 1, set_chroma)]
+            if alpha is not None:
+                jobs.append((alpha[y0:y1, x0:x1].astype(np.int32), 2, set_alpha))
+            bw = BitWriter() if coder == 0 else None
+            states = {}
+            for P, idx, si in jobs:
+                if idx not in states:
+                    states[idx] = [VlcState() for _ in range(counts[si])] if coder == 0 else [128] * (32 * counts[si])
+                gl = GolombLineCoder(bw, 8) if coder == 0 else None
+                for yy in range(P.shape[0]):
+                    syms = _line_symbols(P, sets[si], yy, P.shape[1], 8)
+                    if coder == 0:
+                        gl.line(syms, states[idx])
+                    else:
+                        for ctx, diff in syms:
+                            rc.put_symbol(states[idx], diff, True, base=32 * ctx)
+            pkt += _finish_slice(rc, bw, ec)
     return bytes(pkt)

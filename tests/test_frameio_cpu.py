@@ -202,3 +202,133 @@ def test_ffv1_decoder_rejects_crafted_headers():
     assert np.array_equal(FIO.ffv1_decode(cfg, good, W, H), f)
     with pytest.raises(RuntimeError):                             # a slice grid of 2^20 x 1 in the configuration record
         FIO.ffv1_decode(PY.config_record(1, 1 << 20, 1), good, W, H)
+
+
+# ---- round 3: Golomb-Rice packets of the independent encoder, planar YCbCr streams, colour conversion, YUV4MPEG2 --------------------------
+@pytest.mark.parametrize("nh,nv,alpha", [(1, 1, False), (2, 2, False), (1, 3, True)])
+def test_ffv1_decodes_golomb_rice_packets_of_an_independent_encoder(nh, nv, alpha):
+    """coder_type 0 (what libavcodec picks for 8-bit video and what the C encoder writes) from the SECOND encoder: run mode, adaptive Rice
+    parameter, escape codes -- the C decoder is no longer checked against its own encoder only."""
+    from tests import ffv1_pyenc as PY
+    H, W = 14, 19
+    rng = np.random.default_rng(nh + 3 * nv)
+    a = rng.integers(0, 256, (H, W), dtype=np.uint8) if alpha else None
+    cfg = PY.config_record(0, nh, nv, alpha=alpha)
+    for kind in ("smooth", "flat", "noise"):
+        f = _frames(1, H, W, 4, kind)[0]
+        f[7, 11] = (0, 255, 0)                                       # an outlier: escape-coded residuals
+        assert np.array_equal(FIO.ffv1_decode(cfg, PY.encode_frame(f, 0, nh, nv, alpha=a), W, H), f), kind
+
+
+def _ycbcr_planes(H, W, hs, vs, seed, kind):
+    rng = np.random.default_rng(seed)
+    ch, cw = (H + (1 << vs) - 1) >> vs, (W + (1 << hs) - 1) >> hs
+    if kind == "noise":
+        return tuple(rng.integers(0, 256, s, dtype=np.uint8) for s in ((H, W), (ch, cw), (ch, cw)))
+    ys, xs = np.mgrid[0:H, 0:W]
+    y = np.clip(16 + (xs * 5 + ys * 3) % 220 + rng.integers(-1, 2, (H, W)), 0, 255).astype(np.uint8)
+    cys, cxs = np.mgrid[0:ch, 0:cw]
+    cb = np.clip(128 + 40 * np.sin(cxs / 3.0) + rng.integers(-1, 2, (ch, cw)), 0, 255).astype(np.uint8)
+    cr = np.full((ch, cw), 90, np.uint8)                              # flat plane: the run mode across whole lines
+    return y, cb, cr
+
+
+@pytest.mark.parametrize("coder", [0, 1, 2])
+@pytest.mark.parametrize("hs,vs,nh,nv,alpha", [(1, 1, 1, 1, False), (1, 1, 2, 2, False), (1, 0, 1, 2, False), (0, 0, 2, 1, True), (2, 0, 1, 1, False)])
+def test_ffv1_decodes_planar_ycbcr_streams(coder, hs, vs, nh, nv, alpha):
+    """colorspace_type 0 (yuv420p / 422p / 444p / 411p): planes, shared chroma states, subsampled slice grid -- packets of the independent
+    encoder decode bit-exactly; odd sizes exercise the rounded-up chroma planes."""
+    from tests import ffv1_pyenc as PY
+    H, W = 13, 22 if (nh > 1 or nv > 1) else 21
+    for kind in ("smooth", "noise"):
+        y, cb, cr = _ycbcr_planes(H, W, hs, vs, 7 + coder, kind)
+        a = np.random.default_rng(1).integers(0, 256, (H, W), dtype=np.uint8) if alpha else None
+        cfg = PY.config_record(coder, nh, nv, alpha=alpha, colorspace=0, hshift=hs, vshift=vs)
+        info = FIO.ffv1_stream_info(cfg)
+        assert (info["colorspace"], info["hshift"], info["vshift"], info["alpha"], info["bits"]) == (0, hs, vs, int(alpha), 8)
+        pkt = PY.encode_frame_ycbcr(y, cb, cr, coder, nh, nv, hs, vs, alpha=a)
+        gy, gcb, gcr = FIO.ffv1_decode_planes(cfg, pkt, W, H)
+        assert np.array_equal(gy, y) and np.array_equal(gcb, cb) and np.array_equal(gcr, cr), (kind, coder)
+    # a gray stream (no chroma planes): chroma comes back neutral
+    cfg = PY.config_record(coder, 1, 1, colorspace=0, chroma_planes=False)
+    gy, gcb, gcr = FIO.ffv1_decode_planes(cfg, PY.encode_frame_ycbcr(y, None, None, coder, 1, 1, 0, 0), W, H)
+    assert np.array_equal(gy, y) and (gcb == 128).all() and (gcr == 128).all()
+    # the RGB entry point refuses a YCbCr stream instead of mis-decoding it (and ffv1_decode converts)
+    assert FIO.ffv1_decode(cfg, PY.encode_frame_ycbcr(y, None, None, coder, 1, 1, 0, 0), W, H).shape == (H, W, 3)
+
+
+def _ycbcr_to_rgb_ref(y, cb, cr, hs, vs, full):
+    """numpy restatement of the conversion contract (include/vvio.h): bilinear chroma in 1/16 units, BT.601, 16.16 fixed point."""
+    H, W = y.shape
+    CH, CW = cb.shape
+    X, Y = np.meshgrid(np.arange(W), np.arange(H))
+
+    def up(c):
+        c = c.astype(np.int64)
+        x0 = X >> hs
+        x1 = np.where((hs == 1) & (X & 1 == 1), np.minimum(x0 + 1, CW - 1), x0)
+        wx1 = np.where((hs == 1) & (X & 1 == 1), 2, 0)
+        wx0 = 4 - wx1
+        y0 = Y >> vs
+        if vs == 1:
+            y1 = np.where(Y & 1 == 1, np.minimum(y0 + 1, CH - 1), np.maximum(y0 - 1, 0))
+            wy0, wy1 = 3, 1
+        else:
+            y1, wy0, wy1 = y0, 4, 0
+        return wy0 * (wx0 * c[y0, x0] + wx1 * c[y0, x1]) + wy1 * (wx0 * c[y1, x0] + wx1 * c[y1, x1])
+    u, v = up(cb) - 2048, up(cr) - 2048
+    ky, yoff, krv, kgu, kgv, kbu = (65536, 0, 91881, 22554, 46802, 116130) if full else (76309, 16, 104597, 25675, 53279, 132201)
+    yy = 16 * ky * (y.astype(np.int64) - yoff)
+    r, g, b = (yy + krv * v + (1 << 19)) >> 20, (yy - kgu * u - kgv * v + (1 << 19)) >> 20, (yy + kbu * u + (1 << 19)) >> 20
+    return np.clip(np.stack([r, g, b], -1), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("hs,vs", [(1, 1), (1, 0), (0, 0), (2, 0)])
+@pytest.mark.parametrize("full", [False, True])
+def test_ycbcr_to_rgb_host_conversion(hs, vs, full):
+    H, W = 17, 23
+    y, cb, cr = _ycbcr_planes(H, W, hs, vs, 3, "noise")
+    got = FIO.ycbcr_to_rgb(y, cb, cr, hs, vs, full, device=False)
+    assert np.array_equal(got, _ycbcr_to_rgb_ref(y, cb, cr, hs, vs, full))
+    # against the BT.601 definition in floating point with the same chroma interpolation: within one level
+    ch = lambda c: np.kron(c, np.ones((1 << vs, 1 << hs)))[:H, :W] if (hs, vs) == (0, 0) else None
+    if (hs, vs) == (0, 0):
+        Y_, U_, V_ = y.astype(np.float64), cb.astype(np.float64) - 128, cr.astype(np.float64) - 128
+        if full:
+            ref = np.stack([Y_ + 1.402 * V_, Y_ - 0.344136 * U_ - 0.714136 * V_, Y_ + 1.772 * U_], -1)
+        else:
+            ref = np.stack([1.164383 * (Y_ - 16) + 1.596027 * V_, 1.164383 * (Y_ - 16) - 0.391762 * U_ - 0.812968 * V_, 1.164383 * (Y_ - 16) + 2.017232 * U_], -1)
+        assert np.abs(got.astype(np.float64) - np.clip(np.rint(ref), 0, 255)).max() <= 1
+
+
+def test_ycbcr_known_colours():
+    one = lambda Y, U, V, full=False: tuple(int(v) for v in FIO.ycbcr_to_rgb(np.full((2, 2), Y, np.uint8), np.full((1, 1), U, np.uint8), np.full((1, 1), V, np.uint8), 1, 1, full, device=False)[0, 0])
+    assert one(16, 128, 128) == (0, 0, 0) and one(235, 128, 128) == (255, 255, 255) and one(126, 128, 128) == (128, 128, 128)
+    near = lambda a, b: max(abs(x - y) for x, y in zip(a, b)) <= 1             # the 8-bit YCbCr codes of the primaries are themselves rounded
+    assert near(one(81, 90, 240), (255, 0, 0)) and near(one(145, 54, 34), (0, 255, 0)) and near(one(41, 240, 110), (0, 0, 255))      # BT.601, limited range
+    assert one(0, 128, 128, True) == (0, 0, 0) and one(255, 128, 128, True) == (255, 255, 255) and near(one(76, 85, 255, True), (255, 0, 0))
+
+
+def test_y4m_and_ycbcr_mkv_loading(tmp_path):
+    """`.y4m` (what `ffmpeg -i clip.mp4 clip.y4m` writes) and a yuv420p FFV1 track in Matroska through the reference's loader API."""
+    from tests import ffv1_pyenc as PY
+    H, W, T = 12, 20, 3
+    planes = [_ycbcr_planes(H, W, 1, 1, 20 + t, "smooth") for t in range(T)]
+    want = [_ycbcr_to_rgb_ref(y, cb, cr, 1, 1, False) for y, cb, cr in planes]
+    p = str(tmp_path / "clip.y4m")
+    with open(p, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F30000:1001 Ip A1:1 C420mpeg2\n" % (W, H))
+        for y, cb, cr in planes:
+            f.write(b"FRAME\n" + y.tobytes() + cb.tobytes() + cr.tobytes())
+    frames, fps = FIO.load_video_frames_from_path(p)
+    assert abs(fps - 30000 / 1001) < 1e-9 and len(frames) == T and all(np.array_equal(a, b) for a, b in zip(frames, want))
+    part, _ = FIO.load_video_frames_from_path(p, start_frame=1, max_frames=1)
+    assert len(part) == 1 and np.array_equal(part[0], want[1])
+    with pytest.raises(RuntimeError, match="not supported"):
+        open(str(tmp_path / "x.y4m"), "wb").write(b"YUV4MPEG2 W4 H4 F25:1 C420p10\nFRAME\n" + bytes(100))
+        FIO.load_video_frames_from_path(str(tmp_path / "x.y4m"))
+    mkv = str(tmp_path / "clip420.mkv")
+    cfg = PY.config_record(0, 1, 2, colorspace=0, hshift=1, vshift=1)
+    FIO.write_mkv_packets(mkv, W, H, cfg, [PY.encode_frame_ycbcr(y, cb, cr, 0, 1, 2, 1, 1) for y, cb, cr in planes], 25.0)
+    frames, fps = FIO.load_video_frames_from_path(mkv)
+    assert abs(fps - 25.0) < 1e-6 and len(frames) == T and all(np.array_equal(a, b) for a, b in zip(frames, want))

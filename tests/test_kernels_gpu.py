@@ -476,3 +476,28 @@ def test_precise_split_conv_and_linear(gpu, dname, tol):
     err = ((got - ref).abs().max() / ref.abs().max()).item()
     print(f"linear {dname} precise: rel max err {err:.2e}")
     assert err <= tol
+
+
+@pytest.mark.parametrize("hs,vs", [(1, 1), (1, 0), (0, 0), (2, 0)])
+def test_ycbcr_to_rgb_gpu_equals_host(gpu, hs, vs, tmp_path):
+    """row n3, GPU-side colour conversion: vv_ycbcr_to_rgb is bit for bit the host routine vvio_ycbcr_to_rgb (and through it the numpy
+    restatement in tests/test_frameio_cpu.py); the frame loader takes the GPU path when a device is visible."""
+    from videovanish_amd import frameio as FIO
+    from videovanish_amd import hip
+    rng = np.random.default_rng(11)
+    T, H, W = 3, 37, 53
+    ch, cw = (H + (1 << vs) - 1) >> vs, (W + (1 << hs) - 1) >> hs
+    y, cb, cr = (rng.integers(0, 256, s, dtype=np.uint8) for s in ((T, H, W), (T, ch, cw), (T, ch, cw)))
+    for full in (False, True):
+        host = FIO.ycbcr_to_rgb(y, cb, cr, hs, vs, full, device=False)
+        dev = hip.ycbcr_to_rgb(torch.from_numpy(y).to(gpu), torch.from_numpy(cb).to(gpu), torch.from_numpy(cr).to(gpu), hs, vs, full).cpu().numpy()
+        assert np.array_equal(dev, host)
+        assert np.array_equal(FIO.ycbcr_to_rgb(y, cb, cr, hs, vs, full), host)          # default: the GPU path of the loader
+    if (hs, vs) == (1, 1):
+        p = str(tmp_path / "clip.y4m")
+        with open(p, "wb") as f:
+            f.write(b"YUV4MPEG2 W%d H%d F25:1 C420jpeg\n" % (W, H))
+            for t in range(T):
+                f.write(b"FRAME\n" + y[t].tobytes() + cb[t].tobytes() + cr[t].tobytes())
+        frames, fps = FIO.load_video_frames_from_path(p)
+        assert fps == 25.0 and all(np.array_equal(a, b) for a, b in zip(frames, FIO.ycbcr_to_rgb(y, cb, cr, 1, 1, False, device=False)))

@@ -372,7 +372,8 @@ static int parse_config(const uint8_t* rec, int len, Config* cf) {
     cf->ec = get_symbol(&c, state, 0, &err);
     if (cf->version > 2 && cf->micro > 2) cf->intra = get_symbol(&c, state, 0, &err);
     if (err) return -7;
-    if (cf->colorspace != 1 || (cf->bits != 0 && cf->bits != 8)) return -8;       /* 8-bit RGB (JPEG 2000 RCT) only */
+    if ((cf->colorspace != 0 && cf->colorspace != 1) || (cf->bits != 0 && cf->bits != 8)) return -8;       /* 8 bits per sample only */
+    if (cf->colorspace == 0 && (cf->hshift < 0 || cf->hshift > 2 || cf->vshift < 0 || cf->vshift > 2 || (cf->alpha && !cf->chroma_planes))) return -8;
     if (cf->nh < 1 || cf->nv < 1 || cf->nh > 64 || cf->nv > 64 || cf->ec < 0 || cf->ec > 2) return -8;
     return 0;
 }
@@ -430,7 +431,7 @@ static int encode_slice(const uint8_t* rgb, int W, int stride, int y0, int h, in
             if (y == 0) { memset(last - 3, 0, sizeof(int16_t) * LW); memset(last2 - 3, 0, sizeof(int16_t) * LW); }
             else if (y == 1) memset(last2 - 3, 0, sizeof(int16_t) * LW);
             cur[-1] = last[0]; last[W] = last[W - 1];
-            cur[-2] = cur[-1];       /* (only read by 5-input sets, never by this encoder's own tables) */
+            cur[-2] = 0;             /* RFC 9043 3.2: the additional column to the left is 0 (only read by 5-input sets, never by this encoder's own tables) */
             int run_count = 0, run_mode = 0;
             for (int x = 0; x < W; ++x) {
                 int context = get_context(q, cur + x, last + x, last2 + x);
@@ -484,7 +485,63 @@ int vvio_ffv1_encode_frame(const uint8_t* rgb, int W, int H, int num_v_slices, u
     return pos;
 }
 
-static int decode_slice(const Config* cf, const uint8_t* data, int len, int first, int W, int H, uint8_t* rgb) {
+/* one plane of a planar 8-bit (YCbCr) slice: RFC 9043 3.1-3.8 on unsigned 8-bit samples; the run index restarts with every plane, the
+ * context states of a plane index are shared by the planes that use it (Cb and Cr) */
+typedef struct { int ac; RangeCoder* c; BitR* br; } SampleSrc;
+static int decode_plane8(SampleSrc* src, const QuantSet* q, VlcState* vs, uint8_t* rst, uint8_t* dst, int stride, int w, int h) {
+    const int LW = w + 6;
+    int16_t* lines = (int16_t*)calloc((size_t)3 * LW, sizeof(int16_t));
+    if (!lines) return -23;
+    int run_index = 0, err = 0;
+    for (int y = 0; y < h && !err; ++y) {
+        int16_t *cur = lines + (size_t)((y + 3) % 3) * LW + 3, *last = lines + (size_t)((y + 2) % 3) * LW + 3, *last2 = lines + (size_t)((y + 1) % 3) * LW + 3;
+        if (y == 0) { memset(last - 3, 0, sizeof(int16_t) * LW); memset(last2 - 3, 0, sizeof(int16_t) * LW); }
+        else if (y == 1) memset(last2 - 3, 0, sizeof(int16_t) * LW);
+        cur[-1] = last[0]; last[w] = last[w - 1];
+        cur[-2] = 0;
+        int run_count = 0, run_mode = 0;
+        for (int x = 0; x < w; ++x) {
+            int context = get_context(q, cur + x, last + x, last2 + x), sign = 0, diff;
+            if (context < 0) { context = -context; sign = 1; }
+            if (context >= q->context_count) { err = 1; break; }
+            if (src->ac) {
+                diff = get_symbol(src->c, rst + (size_t)context * CONTEXT_SIZE, 1, &err);
+                if (err) break;
+            } else {
+                if (context == 0 && run_mode == 0) run_mode = 1;
+                if (run_mode) {
+                    if (run_count == 0 && run_mode == 1) {
+                        if (br_get1(src->br)) {
+                            run_count = 1 << log2_run[run_index];
+                            if (x + run_count <= w) run_index++;
+                        } else {
+                            run_count = log2_run[run_index] ? (int)br_get(src->br, log2_run[run_index]) : 0;
+                            if (run_index) run_index--;
+                            run_mode = 2;
+                        }
+                    }
+                    run_count--;
+                    if (run_count < 0) {
+                        run_mode = 0; run_count = 0;
+                        diff = get_vlc_symbol(src->br, &vs[context], 8);
+                        if (diff >= 0) diff++;
+                    } else {
+                        diff = 0;
+                    }
+                } else {
+                    diff = get_vlc_symbol(src->br, &vs[context], 8);
+                }
+            }
+            if (sign) diff = -diff;
+            cur[x] = (int16_t)((mid_pred(cur[x - 1], cur[x - 1] + last[x] - last[x - 1], last[x]) + diff) & 0xFF);
+        }
+        if (!err) for (int x = 0; x < w; ++x) dst[(size_t)y * stride + x] = (uint8_t)cur[x];
+    }
+    free(lines);
+    return err ? -25 : 0;
+}
+
+static int decode_slice(const Config* cf, const uint8_t* data, int len, int first, int W, int H, uint8_t* rgb, uint8_t* const* yuv) {
     RangeCoder c;
     uint8_t state[CONTEXT_SIZE];
     int err = 0;
@@ -532,6 +589,28 @@ static int decode_slice(const Config* cf, const uint8_t* data, int len, int firs
             for (int i = 0; i < n; ++i) { vlc[p][i].drift = 0; vlc[p][i].error_sum = 4; vlc[p][i].bias = 0; vlc[p][i].count = 1; }
         }
     }
+    if (!fail && cf->colorspace == 0) {
+        /* planar YCbCr: Y (set 0), then Cb and Cr (set 1, shared states) on the subsampled grid, then alpha (set 2; decoded, dropped) */
+        SampleSrc src = {ac, &c, &br};
+        const int cw = cf->chroma_planes ? (w + (1 << cf->hshift) - 1) >> cf->hshift : 0, chh = cf->chroma_planes ? (h + (1 << cf->vshift) - 1) >> cf->vshift : 0;
+        const int cx = x0 >> cf->hshift, cy = y0 >> cf->vshift;
+        const int CW = (W + (1 << cf->hshift) - 1) >> cf->hshift, CH = (H + (1 << cf->vshift) - 1) >> cf->vshift;
+        int r = decode_plane8(&src, qs[0], vlc[0], rst[0], yuv[0] + (size_t)y0 * W + x0, W, w, h);
+        if (!r && cf->chroma_planes) {
+            if (cx + cw > CW || cy + chh > CH) r = -21;
+            if (!r) r = decode_plane8(&src, qs[1], vlc[1], rst[1], yuv[1] + (size_t)cy * CW + cx, CW, cw, chh);
+            if (!r) r = decode_plane8(&src, qs[1], vlc[1], rst[1], yuv[2] + (size_t)cy * CW + cx, CW, cw, chh);
+        }
+        if (!r && cf->alpha) {
+            uint8_t* scratch = (uint8_t*)malloc((size_t)w * h);
+            if (!scratch) r = -23;
+            else { r = decode_plane8(&src, qs[2], vlc[2], rst[2], scratch, w, w, h); free(scratch); }
+        }
+        for (int p = 0; p < 3; ++p) { free(vlc[p]); free(rst[p]); }
+        if (r) return r;
+        if (ac) return c.overflow > 2 ? -24 : 0;
+        return br.overflow ? -24 : 0;
+    }
     const int LW = w + 6;
     int16_t* lines = fail ? 0 : (int16_t*)calloc((size_t)4 * 3 * LW, sizeof(int16_t));
     if (!lines) { for (int p = 0; p < 3; ++p) { free(vlc[p]); free(rst[p]); } return -23; }
@@ -547,7 +626,7 @@ static int decode_slice(const Config* cf, const uint8_t* data, int len, int firs
             if (y == 0) { memset(last - 3, 0, sizeof(int16_t) * LW); memset(last2 - 3, 0, sizeof(int16_t) * LW); }
             else if (y == 1) memset(last2 - 3, 0, sizeof(int16_t) * LW);
             cur[-1] = last[0]; last[w] = last[w - 1];
-            cur[-2] = cur[-1];
+            cur[-2] = 0;                               /* RFC 9043 3.2 (border): one left column = the row above shifted down, the ADDITIONAL left column is 0 */
             int run_count = 0, run_mode = 0;
             for (int x = 0; x < w; ++x) {
                 int context = get_context(q, cur + x, last + x, last2 + x), sign = 0, diff;
@@ -602,13 +681,13 @@ static int decode_slice(const Config* cf, const uint8_t* data, int len, int firs
     return br.overflow ? -24 : 0;
 }
 
-/* FFV1 packet + configuration record -> RGB24 (W*H*3 bytes).  0 = ok, negative = error code */
-int vvio_ffv1_decode_frame(const uint8_t* cfg, int cfglen, const uint8_t* data, int len, int W, int H, uint8_t* rgb) {
+static int decode_frame_any(const uint8_t* cfg, int cfglen, const uint8_t* data, int len, int W, int H, uint8_t* rgb, uint8_t* const* yuv) {
     Config* cf = (Config*)malloc(sizeof(Config));
     if (!cf) return -1;
     if (cfglen < 5 || crc32_mpeg(cfg, cfglen) != 0) { free(cf); return -10; }
     int r = parse_config(cfg, cfglen - 4, cf);
     if (r < 0) { free(cf); return r; }
+    if ((cf->colorspace == 0) != (yuv != 0)) { free(cf); return -9; }      /* the caller asked for the other colour model (vvio_ffv1_stream_info) */
     /* walk the slices from the END of the packet: [... slice][size:3][status:1 crc:4 when ec] */
     const int trailer = 3 + (cf->ec ? 5 : 0);
     int end = len, nslices = 0;
@@ -624,11 +703,74 @@ int vvio_ffv1_decode_frame(const uint8_t* cfg, int cfglen, const uint8_t* data, 
         end -= total;
     }
     for (int i = nslices - 1, k = 0; i >= 0; --i, ++k) {
-        r = decode_slice(cf, data + starts[i], lens[i], k == 0, W, H, rgb);
+        r = decode_slice(cf, data + starts[i], lens[i], k == 0, W, H, rgb, yuv);
         if (r < 0) { free(cf); return r; }
     }
     free(cf);
     return 0;
 }
 
-int vvio_abi_version(void) { return 1; }
+/* FFV1 packet + configuration record -> RGB24 (W*H*3 bytes).  0 = ok, negative = error code */
+int vvio_ffv1_decode_frame(const uint8_t* cfg, int cfglen, const uint8_t* data, int len, int W, int H, uint8_t* rgb) {
+    return decode_frame_any(cfg, cfglen, data, len, W, H, rgb, 0);
+}
+
+/* info[6] = colorspace_type (0 YCbCr, 1 RGB), chroma_planes, log2_h_chroma_subsample, log2_v_chroma_subsample, extra_plane, bits_per_raw_sample */
+int vvio_ffv1_stream_info(const uint8_t* cfg, int cfglen, int* info) {
+    Config* cf = (Config*)malloc(sizeof(Config));
+    if (!cf || !info) { free(cf); return -1; }
+    if (cfglen < 5 || crc32_mpeg(cfg, cfglen) != 0) { free(cf); return -10; }
+    const int r = parse_config(cfg, cfglen - 4, cf);
+    if (r == 0) { info[0] = cf->colorspace; info[1] = cf->chroma_planes; info[2] = cf->hshift; info[3] = cf->vshift; info[4] = cf->alpha; info[5] = cf->bits ? cf->bits : 8; }
+    free(cf);
+    return r;
+}
+
+/* planar 8-bit YCbCr stream (colorspace_type 0) -> Y [H][W], Cb / Cr [ceil(H >> vshift)][ceil(W >> hshift)] (gray streams: Cb = Cr = 128) */
+int vvio_ffv1_decode_frame_yuv(const uint8_t* cfg, int cfglen, const uint8_t* data, int len, int W, int H, uint8_t* y, uint8_t* cb, uint8_t* cr) {
+    int info[6];
+    int r = vvio_ffv1_stream_info(cfg, cfglen, info);
+    if (r < 0) return r;
+    if (!y || !cb || !cr) return -1;
+    if (!info[1]) {
+        const size_t n = (size_t)((W + (1 << info[2]) - 1) >> info[2]) * (size_t)((H + (1 << info[3]) - 1) >> info[3]);
+        memset(cb, 128, n); memset(cr, 128, n);
+    }
+    uint8_t* planes[3] = {y, cb, cr};
+    return decode_frame_any(cfg, cfglen, data, len, W, H, 0, planes);
+}
+
+/* ---------------------------------------------------------------------------------------------------------- colour conversion */
+/* YCbCr (ITU-R BT.601 matrix; limited range 16..235 / 16..240, or full range) -> RGB24 in integer arithmetic -- the SAME arithmetic as the HIP
+ * kernel vv_ycbcr_to_rgb (videovanish_amd/csrc/vv_image.hip), bit for bit.  Chroma siting of MPEG-2 / H.264 4:2:0: co-sited with the even luma
+ * columns, midway between two luma rows; bilinear chroma interpolation in 1/16 units (weights 4 | 2+2 horizontally, 1+3 | 3+1 vertically);
+ * subsampling factors above 2 replicate.  What cv2.VideoCapture hands the reference (tools.py:17-21) comes out of libswscale (bicubic chroma,
+ * its own fixed point): PARITY UNPINNED against it. */
+static inline int clamp_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+static inline int chroma16(const uint8_t* c, int CW, int CH, int X, int Y, int hs, int vs) {
+    int x0 = X >> hs, x1 = x0, wx0 = 4, wx1 = 0, y0 = Y >> vs, y1 = y0, wy0 = 4, wy1 = 0;
+    if (hs == 1 && (X & 1)) { x1 = x0 + 1 < CW ? x0 + 1 : x0; wx0 = 2; wx1 = 2; }
+    if (vs == 1) {
+        if (Y & 1) { y1 = y0 + 1 < CH ? y0 + 1 : y0; wy0 = 3; wy1 = 1; }
+        else { y1 = y0 > 0 ? y0 - 1 : y0; wy0 = 3; wy1 = 1; }
+    }
+    return wy0 * (wx0 * c[(size_t)y0 * CW + x0] + wx1 * c[(size_t)y0 * CW + x1]) + wy1 * (wx0 * c[(size_t)y1 * CW + x0] + wx1 * c[(size_t)y1 * CW + x1]);
+}
+int vvio_ycbcr_to_rgb(const uint8_t* y, const uint8_t* cb, const uint8_t* cr, int W, int H, int hshift, int vshift, int full_range, uint8_t* rgb) {
+    if (!y || !cb || !cr || !rgb || W < 1 || H < 1 || hshift < 0 || hshift > 2 || vshift < 0 || vshift > 2) return -1;
+    const int CW = (W + (1 << hshift) - 1) >> hshift, CH = (H + (1 << vshift) - 1) >> vshift;
+    const int ky = full_range ? 65536 : 76309, yoff = full_range ? 0 : 16;
+    const int krv = full_range ? 91881 : 104597, kgu = full_range ? 22554 : 25675, kgv = full_range ? 46802 : 53279, kbu = full_range ? 116130 : 132201;
+    for (int Y = 0; Y < H; ++Y)
+        for (int X = 0; X < W; ++X) {
+            const int yy = 16 * ky * ((int)y[(size_t)Y * W + X] - yoff);
+            const int u = chroma16(cb, CW, CH, X, Y, hshift, vshift) - 2048, v = chroma16(cr, CW, CH, X, Y, hshift, vshift) - 2048;
+            uint8_t* o = rgb + ((size_t)Y * W + X) * 3;
+            o[0] = (uint8_t)clamp_u8((yy + krv * v + (1 << 19)) >> 20);
+            o[1] = (uint8_t)clamp_u8((yy - kgu * u - kgv * v + (1 << 19)) >> 20);
+            o[2] = (uint8_t)clamp_u8((yy + kbu * u + (1 << 19)) >> 20);
+        }
+    return 0;
+}
+
+int vvio_abi_version(void) { return 2; }

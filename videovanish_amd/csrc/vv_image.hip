@@ -220,6 +220,45 @@ extern "C" int vv_resize_bilinear_u8(const uint8_t* src, int T, int Hs, int Ws, 
     return VV_OK;
 }
 
+// ---- planar YCbCr (BT.601, limited or full range) -> RGB24: the GPU side of the frame loader.  Integer arithmetic, bit for bit
+// the host routine vvio_ycbcr_to_rgb (vv_ffv1.c): chroma in 1/16 units (MPEG-2 4:2:0 siting: co-sited with even luma columns, midway between two
+// luma rows; bilinear), 16.16 fixed-point matrix, round to nearest, clamp.  One thread per pixel, 3 output bytes per thread: HBM bound (4.5 B/pixel).
+namespace {
+__device__ __forceinline__ int ycc_chroma16(const uint8_t* __restrict__ c, int CW, int CH, int X, int Y, int hs, int vs) {
+    int x0 = X >> hs, x1 = x0, wx0 = 4, wx1 = 0, y0 = Y >> vs, y1 = y0, wy0 = 4, wy1 = 0;
+    if (hs == 1 && (X & 1)) { x1 = x0 + 1 < CW ? x0 + 1 : x0; wx0 = 2; wx1 = 2; }
+    if (vs == 1) {
+        if (Y & 1) { y1 = y0 + 1 < CH ? y0 + 1 : y0; wy0 = 3; wy1 = 1; }
+        else { y1 = y0 > 0 ? y0 - 1 : y0; wy0 = 3; wy1 = 1; }
+    }
+    return wy0 * (wx0 * c[(int64_t)y0 * CW + x0] + wx1 * c[(int64_t)y0 * CW + x1]) + wy1 * (wx0 * c[(int64_t)y1 * CW + x0] + wx1 * c[(int64_t)y1 * CW + x1]);
+}
+__global__ __launch_bounds__(EB) void ycbcr_to_rgb_kernel(const uint8_t* __restrict__ y, const uint8_t* __restrict__ cb, const uint8_t* __restrict__ cr, int T, int H,
+                                                           int W, int hs, int vs, int full, uint8_t* __restrict__ rgb) {
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= (int64_t)T * H * W) return;
+    const int X = (int)(i % W), Y = (int)((i / W) % H), t = (int)(i / ((int64_t)W * H));
+    const int CW = (W + (1 << hs) - 1) >> hs, CH = (H + (1 << vs) - 1) >> vs;
+    const int ky = full ? 65536 : 76309, yoff = full ? 0 : 16;
+    const int krv = full ? 91881 : 104597, kgu = full ? 22554 : 25675, kgv = full ? 46802 : 53279, kbu = full ? 116130 : 132201;
+    const int yy = 16 * ky * ((int)y[i] - yoff);
+    const uint8_t* cbt = cb + (int64_t)t * CW * CH;
+    const uint8_t* crt = cr + (int64_t)t * CW * CH;
+    const int u = ycc_chroma16(cbt, CW, CH, X, Y, hs, vs) - 2048, v = ycc_chroma16(crt, CW, CH, X, Y, hs, vs) - 2048;
+    const int r = (yy + krv * v + (1 << 19)) >> 20, g = (yy - kgu * u - kgv * v + (1 << 19)) >> 20, b = (yy + kbu * u + (1 << 19)) >> 20;
+    uint8_t* o = rgb + i * 3;
+    o[0] = (uint8_t)min(max(r, 0), 255); o[1] = (uint8_t)min(max(g, 0), 255); o[2] = (uint8_t)min(max(b, 0), 255);
+}
+}  // namespace
+
+extern "C" int vv_ycbcr_to_rgb(const uint8_t* y, const uint8_t* cb, const uint8_t* cr, int T, int H, int W, int hshift, int vshift, int full_range, uint8_t* rgb,
+                               void* stream) {
+    if (!y || !cb || !cr || !rgb || T <= 0 || H <= 0 || W <= 0 || hshift < 0 || hshift > 2 || vshift < 0 || vshift > 2) VV_FAIL(VV_E_ARG, "vv_ycbcr_to_rgb: bad args");
+    hipLaunchKernelGGL(ycbcr_to_rgb_kernel, grid_for((int64_t)T * H * W), dim3(EB), 0, (hipStream_t)stream, y, cb, cr, T, H, W, hshift, vshift, full_range, rgb);
+    VV_CHECK_LAUNCH("vv_ycbcr_to_rgb");
+    return VV_OK;
+}
+
 extern "C" int vv_resize_nearest_u8(const uint8_t* src, int T, int Hs, int Ws, int ch, uint8_t* dst, int Hd, int Wd, void* stream) {
     if (!src || !dst || T <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0 || ch <= 0) VV_FAIL(VV_E_ARG, "vv_resize_nearest_u8: bad args");
     hipLaunchKernelGGL(resize_nearest_kernel, grid_for((int64_t)T * Hd * Wd), dim3(EB), 0, (hipStream_t)stream, src, T, Hs, Ws, ch, dst, Hd, Wd);

@@ -8,9 +8,11 @@ The reference goes through cv2 (ffmpeg): `VideoWriter_fourcc(*"FFV1")` into an .
 Python (EBML is a few dozen lines) and the codec is the plain-C FFV1 v3 intra codec in csrc/vv_ffv1.c (libvvio.so; Golomb-Rice
 coded 8-bit RGB, what ffmpeg emits for bgr0).  Frames are RGB in, RGB out: no BGR detour.
 
-Reading supports what this module writes (V_FFV1 or V_MS/VFW/FOURCC 'FFV1', version 3, Golomb-Rice, 8-bit RGB, no alpha) plus
-uncompressed RGB24/BGR24 Matroska tracks (V_UNCOMPRESSED) and `.npy` / `.npz` frame stacks; other codecs (H.264, ...) raise a
-clear error -- decoding them is out of scope (codec I/O is either side of the hot path).
+Reading supports FFV1 version 3 in Matroska (V_FFV1 or V_MS/VFW/FOURCC 'FFV1'): 8-bit RGB (what this module and cv2 write) AND planar
+8-bit YCbCr (yuv420p / 422p / 444p / gray, what ffmpeg writes by default), Golomb-Rice or range coded, with or without alpha; uncompressed
+RGB24/BGR24 tracks (V_UNCOMPRESSED); YUV4MPEG2 (`.y4m`); `.npy` / `.npz` frame stacks.  YCbCr is converted to RGB on the GPU when one is visible
+(vv_ycbcr_to_rgb, BT.601; the same integer arithmetic runs on the host otherwise).  Other codecs (H.264, ...) raise a clear error --
+decoding them is out of scope (codec I/O is either side of the hot path).
 PARITY UNPINNED against ffmpeg / cv2 (absent from the build image): pinned by lossless round trips and structure checks only.
 """
 import ctypes as C
@@ -29,7 +31,8 @@ def _io():
         if not os.path.isfile(_LIB_PATH):
             raise RuntimeError(f"videovanish_amd: frame I/O codec missing ({_LIB_PATH}); run videovanish_amd/csrc/build.sh")
         L = C.CDLL(_LIB_PATH)
-        for name in ("vvio_abi_version", "vvio_ffv1_config_record", "vvio_ffv1_encode_frame", "vvio_ffv1_decode_frame"):
+        for name in ("vvio_abi_version", "vvio_ffv1_config_record", "vvio_ffv1_encode_frame", "vvio_ffv1_decode_frame", "vvio_ffv1_stream_info",
+                     "vvio_ffv1_decode_frame_yuv", "vvio_ycbcr_to_rgb"):
             if not hasattr(L, name):
                 raise RuntimeError(f"libvvio.so does not export {name}")
         _lib = L
@@ -57,18 +60,140 @@ def ffv1_encode(frame_rgb, num_v_slices=1):
     return out[:n].tobytes()
 
 
+_REASONS = {-10: "configuration record CRC mismatch", -2: "FFV1 version < 3", -3: "bad coder_type / state-transition table",
+            -6: "coded initial states are not supported", -8: "only 8-bit streams (RGB, or YCbCr with subsampling factors <= 4) are supported",
+            -9: "stream colour model does not match the decoder entry point", -21: "slice header out of range", -25: "corrupt sample data",
+            -13: "slice CRC mismatch", -20: "not a key frame"}
+
+
+def ffv1_stream_info(config):
+    """{colorspace (0 YCbCr / 1 RGB), chroma_planes, hshift, vshift, alpha, bits} of an FFV1 configuration record."""
+    info = (C.c_int * 6)()
+    cfg = (C.c_uint8 * len(config)).from_buffer_copy(config)
+    r = _io().vvio_ffv1_stream_info(cfg, len(config), info)
+    if r != 0:
+        raise RuntimeError(f"FFV1 configuration record rejected ({r}): {_REASONS.get(r, 'malformed stream')}")
+    return dict(zip(("colorspace", "chroma_planes", "hshift", "vshift", "alpha", "bits"), list(info)))
+
+
+def ffv1_decode_planes(config, packet, W, H, info=None):
+    """a planar YCbCr FFV1 packet -> (Y [H, W], Cb, Cr [ceil(H >> vshift), ceil(W >> hshift)]) uint8."""
+    info = info or ffv1_stream_info(config)
+    cw, ch = (W + (1 << info["hshift"]) - 1) >> info["hshift"], (H + (1 << info["vshift"]) - 1) >> info["vshift"]
+    y, cb, cr = np.empty((H, W), np.uint8), np.empty((ch, cw), np.uint8), np.empty((ch, cw), np.uint8)
+    cfg = (C.c_uint8 * len(config)).from_buffer_copy(config)
+    pkt = (C.c_uint8 * len(packet)).from_buffer_copy(packet)
+    r = _io().vvio_ffv1_decode_frame_yuv(cfg, len(config), pkt, len(packet), W, H, y.ctypes.data_as(C.c_void_p), cb.ctypes.data_as(C.c_void_p),
+                                         cr.ctypes.data_as(C.c_void_p))
+    if r != 0:
+        raise RuntimeError(f"FFV1 decode failed ({r}): {_REASONS.get(r, 'malformed stream')}")
+    return y, cb, cr
+
+
+def ycbcr_to_rgb(y, cb, cr, hshift, vshift, full_range=False, device=None):
+    """planar YCbCr ([T,] H, W + subsampled chroma) -> RGB uint8 ([T,] H, W, 3).  On a machine with a visible GPU the conversion runs there
+    (vv_ycbcr_to_rgb: the frames are headed for the device anyway); otherwise on the host (vvio_ycbcr_to_rgb) -- the two are the same integer
+    arithmetic, bit for bit (tests/test_frameio_cpu.py, tests/test_kernels_gpu.py).  device=False forces the host path."""
+    y, cb, cr = (np.ascontiguousarray(a, dtype=np.uint8) for a in (y, cb, cr))
+    single = y.ndim == 2
+    if single:
+        y, cb, cr = y[None], cb[None], cr[None]
+    T, H, W = y.shape
+    use_gpu = False
+    if device is not False:
+        try:
+            import torch
+            use_gpu = torch.cuda.is_available()
+        except ImportError:
+            use_gpu = False
+    if use_gpu:
+        import torch
+        from . import hip
+        dev = torch.device("cuda", torch.cuda.current_device()) if device in (None, True) else torch.device(device)
+        out = hip.ycbcr_to_rgb(torch.from_numpy(y).to(dev), torch.from_numpy(cb).to(dev), torch.from_numpy(cr).to(dev), hshift, vshift, full_range).cpu().numpy()
+    else:
+        out = np.empty((T, H, W, 3), np.uint8)
+        for t in range(T):
+            r = _io().vvio_ycbcr_to_rgb(y[t].ctypes.data_as(C.c_void_p), cb[t].ctypes.data_as(C.c_void_p), cr[t].ctypes.data_as(C.c_void_p), W, H,
+                                        int(hshift), int(vshift), int(bool(full_range)), out[t].ctypes.data_as(C.c_void_p))
+            if r != 0:
+                raise RuntimeError("vvio_ycbcr_to_rgb failed")
+    return out[0] if single else out
+
+
 def ffv1_decode(config, packet, W, H):
+    """one FFV1 packet -> RGB uint8 [H, W, 3]; planar YCbCr streams are decoded to planes and colour converted (BT.601 limited range)."""
+    info = ffv1_stream_info(config)
+    if info["colorspace"] == 0:
+        y, cb, cr = ffv1_decode_planes(config, packet, W, H, info)
+        return ycbcr_to_rgb(y, cb, cr, info["hshift"], info["vshift"])
     out = np.empty((H, W, 3), np.uint8)
     cfg = (C.c_uint8 * len(config)).from_buffer_copy(config)
     pkt = (C.c_uint8 * len(packet)).from_buffer_copy(packet)
     r = _io().vvio_ffv1_decode_frame(cfg, len(config), pkt, len(packet), W, H, out.ctypes.data_as(C.c_void_p))
     if r != 0:
-        reasons = {-10: "configuration record CRC mismatch", -2: "FFV1 version < 3", -3: "bad coder_type / state-transition table",
-                   -6: "coded initial states are not supported", -8: "only 8-bit RGB streams (colorspace_type 1) are supported", -21: "slice header out of range",
-                   -25: "corrupt sample data",
-                   -13: "slice CRC mismatch", -20: "not a key frame"}
-        raise RuntimeError(f"FFV1 decode failed ({r}): {reasons.get(r, 'malformed stream')}")
+        raise RuntimeError(f"FFV1 decode failed ({r}): {_REASONS.get(r, 'malformed stream')}")
     return out
+
+
+# ---- YUV4MPEG2 (.y4m): uncompressed planar YCbCr, what `ffmpeg -i any.mp4 out.y4m` writes ---------------------------------------------
+_Y4M_SHIFTS = {"420": (1, 1), "420jpeg": (1, 1), "420mpeg2": (1, 1), "420paldv": (1, 1), "422": (1, 0), "444": (0, 0), "mono": None}
+
+
+def read_y4m(path, start_frame=0, max_frames=-1):
+    """-> (list of RGB uint8 frames, fps).  8-bit 4:2:0 / 4:2:2 / 4:4:4 / mono; limited range unless the header carries XCOLORRANGE=FULL."""
+    with open(path, "rb") as f:
+        head = f.readline()
+        if not head.startswith(b"YUV4MPEG2"):
+            raise RuntimeError(f"{path}: not a YUV4MPEG2 file")
+        W = H = None
+        fps, cs, full = 25.0, "420", False
+        for tok in head.decode("ascii", "replace").split()[1:]:
+            if tok[0] == "W":
+                W = int(tok[1:])
+            elif tok[0] == "H":
+                H = int(tok[1:])
+            elif tok[0] == "F":
+                n, d = tok[1:].split(":")
+                fps = float(n) / max(1.0, float(d))
+            elif tok[0] == "C":
+                cs = tok[1:]
+            elif tok == "XCOLORRANGE=FULL":
+                full = True
+        if not W or not H or W <= 0 or H <= 0:
+            raise RuntimeError(f"{path}: missing frame size")
+        if cs not in _Y4M_SHIFTS:
+            raise RuntimeError(f"{path}: chroma format C{cs} is not supported (8-bit 420 / 422 / 444 / mono)")
+        sh = _Y4M_SHIFTS[cs]
+        hs, vs = sh if sh else (0, 0)
+        cw, ch = (W + (1 << hs) - 1) >> hs, (H + (1 << vs) - 1) >> vs
+        ys, cbs, crs, idx = [], [], [], 0
+        while True:
+            line = f.readline()
+            if not line:
+                break
+            if not line.startswith(b"FRAME"):
+                raise RuntimeError(f"{path}: frame header expected")
+            n = W * H + (2 * cw * ch if sh else 0)
+            buf = f.read(n)
+            if len(buf) < n:
+                break
+            if idx >= start_frame:
+                a = np.frombuffer(buf, np.uint8)
+                ys.append(a[:W * H].reshape(H, W))
+                if sh:
+                    cbs.append(a[W * H:W * H + cw * ch].reshape(ch, cw))
+                    crs.append(a[W * H + cw * ch:].reshape(ch, cw))
+                else:
+                    cbs.append(np.full((ch, cw), 128, np.uint8))
+                    crs.append(np.full((ch, cw), 128, np.uint8))
+                if max_frames > 0 and len(ys) >= max_frames:
+                    break
+            idx += 1
+    if not ys:
+        return [], fps
+    rgb = ycbcr_to_rgb(np.stack(ys), np.stack(cbs), np.stack(crs), hs, vs, full)
+    return [np.ascontiguousarray(r) for r in rgb], fps
 
 
 # ---- EBML / Matroska -----------------------------------------------------------------------------------------------------
@@ -96,35 +221,41 @@ ID_PIXELW, ID_PIXELH, ID_COLOURSPACE = b"\xb0", b"\xba", b"\x2e\xb5\x24"
 ID_TIMECODE, ID_SIMPLEBLOCK, ID_BLOCKGROUP, ID_BLOCK = b"\xe7", b"\xa3", b"\xa0", b"\xa1"
 
 
-def write_mkv_ffv1(path, frames, fps, num_v_slices=None):
-    """frames: iterable of (H, W, 3) uint8 RGB arrays of one size."""
-    frames = list(frames)
-    H, W = frames[0].shape[:2]
-    nv = num_v_slices or max(1, min(H, (H + 539) // 540))       # bands of <= 540 rows keep a slice far below the 16 MB size field
+def write_mkv_packets(path, W, H, config, packets, fps):
+    """mux FFV1 packets (one key frame each) + their configuration record into a Matroska file (V_FFV1)."""
+    packets = list(packets)
     fps = float(fps) if fps and fps > 0 else 25.0
     dur_ns = int(round(1e9 / fps))
     head = _el(ID_EBML, _el(b"\x42\x86", _uint(1)) + _el(b"\x42\xf7", _uint(1)) + _el(b"\x42\xf2", _uint(4)) + _el(b"\x42\xf3", _uint(8)) +
                _el(b"\x42\x82", b"matroska") + _el(b"\x42\x87", _uint(4)) + _el(b"\x42\x85", _uint(2)))
     info = _el(ID_INFO, _el(ID_TIMECODESCALE, _uint(1000000)) + _el(ID_MUXAPP, b"videovanish_amd.frameio") + _el(ID_WRITEAPP, b"videovanish_amd.frameio") +
-               _el(ID_DURATION, struct.pack(">d", len(frames) * 1000.0 / fps)))
+               _el(ID_DURATION, struct.pack(">d", len(packets) * 1000.0 / fps)))
     video = _el(ID_VIDEO, _el(ID_PIXELW, _uint(W)) + _el(ID_PIXELH, _uint(H)))
     track = _el(ID_TRACKENTRY, _el(ID_TRACKNUM, _uint(1)) + _el(ID_TRACKUID, _uint(1)) + _el(ID_TRACKTYPE, _uint(1)) + _el(ID_FLAGLACING, _uint(0)) +
-                _el(ID_CODECID, b"V_FFV1") + _el(ID_CODECPRIVATE, ffv1_config_record(nv)) + _el(ID_DEFAULTDURATION, _uint(dur_ns)) + video)
+                _el(ID_CODECID, b"V_FFV1") + _el(ID_CODECPRIVATE, config) + _el(ID_DEFAULTDURATION, _uint(dur_ns)) + video)
     with open(path, "wb") as f:
         f.write(head)
         f.write(ID_SEGMENT + b"\x01\xff\xff\xff\xff\xff\xff\xff")          # unknown size: clusters are streamed
         f.write(info)
         f.write(_el(ID_TRACKS, track))
         per_cluster = max(1, int(round(fps)))                               # about one second per cluster
-        for c0 in range(0, len(frames), per_cluster):
+        for c0 in range(0, len(packets), per_cluster):
             t0 = int(round(c0 * 1000.0 / fps))
             blocks = []
-            for i in range(c0, min(len(frames), c0 + per_cluster)):
-                fr = frames[i]
-                assert fr.shape[:2] == (H, W), "all frames of a track must have one size"
+            for i in range(c0, min(len(packets), c0 + per_cluster)):
                 rel = int(round(i * 1000.0 / fps)) - t0
-                blocks.append(_el(ID_SIMPLEBLOCK, b"\x81" + struct.pack(">h", rel) + b"\x80" + ffv1_encode(fr, nv)))     # track 1, key frame
+                blocks.append(_el(ID_SIMPLEBLOCK, b"\x81" + struct.pack(">h", rel) + b"\x80" + packets[i]))     # track 1, key frame
             f.write(_el(ID_CLUSTER, _el(ID_TIMECODE, _uint(t0)) + b"".join(blocks)))
+
+
+def write_mkv_ffv1(path, frames, fps, num_v_slices=None):
+    """frames: iterable of (H, W, 3) uint8 RGB arrays of one size."""
+    frames = list(frames)
+    H, W = frames[0].shape[:2]
+    nv = num_v_slices or max(1, min(H, (H + 539) // 540))       # bands of <= 540 rows keep a slice far below the 16 MB size field
+    for fr in frames:
+        assert fr.shape[:2] == (H, W), "all frames of a track must have one size"
+    write_mkv_packets(path, W, H, ffv1_config_record(nv), [ffv1_encode(fr, nv) for fr in frames], fps)
 
 
 def _read_vint(buf, pos, is_id):
@@ -225,7 +356,7 @@ def _decode_payload(tr, payload):
         fourcc = tr.get("fourcc", b"RGB\x18")
         a = np.frombuffer(payload, np.uint8)[: H * W * 3].reshape(H, W, 3)
         return a[..., ::-1].copy() if fourcc.startswith(b"BGR") else a.copy()
-    raise RuntimeError(f"unsupported codec {codec!r}: this reader decodes FFV1 (v3, Golomb-Rice, 8-bit RGB) and uncompressed RGB Matroska only")
+    raise RuntimeError(f"unsupported codec {codec!r}: this reader decodes FFV1 (v3, 8-bit RGB or planar YCbCr) and uncompressed RGB in Matroska, and .y4m")
 
 
 # ---- the reference's tools.py API ----------------------------------------------------------------------------------------
@@ -248,6 +379,8 @@ def load_video_frames_from_path(video_path, start_frame=0, max_frames=-1):
         z = np.load(video_path)
         arr, fps = z["frames"], float(z["fps"]) if "fps" in z else 25.0
         frames = [f for f in arr[start_frame: (start_frame + max_frames) if max_frames > 0 else None]]
+    elif ext == ".y4m":
+        frames, fps = read_y4m(video_path, start_frame, max_frames)
     else:
         frames, fps = read_mkv(video_path, start_frame, max_frames)
     assert len(frames) > 0, "No frames read"

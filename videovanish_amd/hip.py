@@ -107,7 +107,7 @@ EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name
            # SAM 2 (row n4)
            "vv_u8_normalize", "vv_layernorm_ex", "vv_maxpool2x2", "vv_rope_apply", "vv_dwconv", "vv_pixel_shuffle2", "vv_resize_bilinear_f32",
            "vv_mask_mem_input", "vv_act", "vv_prompt_points", "vv_sine_pe_1d", "vv_sam_select", "vv_sam_pick", "vv_select_f32",
-           "vv_add_rowvec_unless", "vv_clamp_f32", "vv_fill_holes", "vv_hyper_masks", "vv_attention_merge"]
+           "vv_add_rowvec_unless", "vv_clamp_f32", "vv_fill_holes", "vv_hyper_masks", "vv_attention_merge", "vv_ycbcr_to_rgb"]
 
 
 def lib():
@@ -865,4 +865,13 @@ def attention_split_kv(dtype, q, k, v, out, *, heads, Nq, Nkv, D, S, q_rs, k_rs,
     attention(dtype, q, k, v, parts, B=S, heads=heads, Nq=Nq, Nkv=chunk, D=D, q_bs=0, k_bs=chunk * k_rs, v_bs=chunk * v_rs, o_bs=Nq * o_rs,
               q_rs=q_rs, k_rs=k_rs, v_rs=v_rs, o_rs=o_rs, q_hs=q_hs, k_hs=k_hs, v_hs=v_hs, scale=scale, lse=lse)
     _check(lib().vv_attention_merge(_p(parts), _p(lse), S, heads, Nq, D, o_rs, _p(out), dtype, _stream()), "vv_attention_merge")
+    return out
+
+
+def ycbcr_to_rgb(y, cb, cr, hshift, vshift, full_range=False):
+    """planar uint8 YCbCr on the device (y [T, H, W], cb / cr [T, ceil(H >> vshift), ceil(W >> hshift)]) -> RGB uint8 [T, H, W, 3] (row n3)."""
+    _need_cuda(y, cb, cr)
+    T, H, W = y.shape
+    out = torch.empty((T, H, W, 3), dtype=torch.uint8, device=y.device)
+    _check(lib().vv_ycbcr_to_rgb(_p(y), _p(cb), _p(cr), T, H, W, int(hshift), int(vshift), int(bool(full_range)), _p(out), _stream()), "vv_ycbcr_to_rgb")
     return out
