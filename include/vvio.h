@@ -1,5 +1,5 @@
 /* libvvio.so -- host-side frame codec of the MI355X VideoVanish build (plain C, no GPU): FFV1 version 3 (RFC 9043), 8-bit RGB
- * (JPEG 2000 RCT), Golomb-Rice coder, intra only, slice CRCs -- the codec the reference writes with
+ * (JPEG 2000 RCT) and planar YCbCr (decode), Golomb-Rice / range coder, intra only, slice CRCs -- the codec the reference writes with
  * cv2.VideoWriter(fourcc "FFV1") (reference tools.py:28-45) and reads back with cv2.VideoCapture (tools.py:4-25).
  * The Matroska container is written / parsed in Python (videovanish_amd/frameio.py); these entry points code single frames.
  * Source: videovanish_amd/csrc/vv_ffv1.c (built by csrc/build.sh with gcc); binding: videovanish_amd/frameio.py (ctypes).
