@@ -208,8 +208,14 @@ def main():
                     help="VAE decoder in one pass of h16 operands instead of split precision (3 MFMA passes per GEMM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--two-streams", action="store_true", help="lab: BrushNet backbone on a second HIP stream beside the UNet down / mid path "
+                    "(unet.Denoiser.OVERLAP; per-kernel event times overlap and are not reported: implies --no-kernel-events)")
     ap.add_argument("--dump-kernels", default=None, help="write the raw per-kernel table (launches, seconds, flops, bytes) to this JSON file")
     args = ap.parse_args()
+    if args.two_streams:
+        from videovanish_amd import unet as _unet
+        _unet.Denoiser.OVERLAP = True
+        args.no_kernel_events = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -443,3 +443,30 @@ def test_cli_main_on_the_hip_path(gpu, tmp_path, monkeypatch):
         assert len(part) == 2
     finally:
         diffuerase.configure(None)
+
+
+def test_two_stream_schedule_is_bit_identical(gpu):
+    """unet.Denoiser.OVERLAP (opt-in): the BrushNet backbone on a second HIP stream beside the UNet's down / mid path -- same kernels, same
+    inputs, only the issue order across streams changes: the result is bit-identical to the one-stream schedule, over several steps."""
+    from videovanish_amd.nn import Ctx
+    from videovanish_amd.unet import Denoiser
+    ucfg = SMALL_UNET
+    Fr, h, w, f = 4, 16, 24, 8
+    g = torch.Generator().manual_seed(3)
+    lat, cond = torch.randn(Fr, h, w, 4, generator=g).to(gpu), torch.randn(Fr, h, w, 4, generator=g).to(gpu)
+    mask = ((torch.rand(Fr, h * f, w * f, generator=g) > 0.6).to(torch.uint8) * 255).to(gpu)
+    ctx = Ctx("cuda:0", "fp16", 0)
+    den = Denoiser(ctx, ucfg, ctx.src.normal("text_states", (1, ucfg.text_len, ucfg.cross_dim)))
+    outs = {}
+    try:
+        for flag in (False, True, True):
+            Denoiser.OVERLAP = flag
+            x = lat
+            for t in (801, 401, 1):
+                x = den(x.contiguous(), cond, mask, t, Fr, h, w, h * f, w * f)
+            torch.cuda.synchronize()
+            outs.setdefault(flag, []).append(x.clone())
+    finally:
+        Denoiser.OVERLAP = False
+    assert torch.isfinite(outs[False][0]).all()
+    assert all(torch.equal(o, outs[False][0]) for o in outs[True])

@@ -157,14 +157,20 @@ class BrushNet(_Backbone):
         self.zm = Conv(ctx, "brushnet.brushnet_mid_block", cfg.block_out[-1], cfg.block_out[-1], k=1, gain=zg)
         self.zu = [Conv(ctx, f"brushnet.brushnet_up_blocks.{i}", c, c, k=1, gain=zg) for i, c in enumerate(self.up_ch)]
 
-    def __call__(self, x16, t, F, h, w, unet_skips, unet_mid, scale=1.0):
-        """x16: h16 [F*h*w,16] BrushNet input.  unet_skips / unet_mid: the UNet's own down skips and mid output;
-        the zero-conv GEMMs add them in their epilogue, so the returned tensors are already (skip + residual)."""
+    def backbone(self, x16, t, F, h, w):
+        """the part that does not depend on the UNet: down, mid and up path of the branch -> (down outputs, mid, up outputs, (H, W) at the bottom)."""
         st = self.temb(t)
         x, skips, (H, W) = self.run_down(x16, F, h, w, st)
         down_raw = list(skips)
         mid = self.run_mid(x, F, H, W, st)
         _, ups, _ = self.run_up(mid, F, H, W, skips, st, collect=True)
+        return down_raw, mid, ups, (H, W)
+
+    def __call__(self, x16, t, F, h, w, unet_skips, unet_mid, scale=1.0, pre=None):
+        """x16: h16 [F*h*w,16] BrushNet input.  unet_skips / unet_mid: the UNet's own down skips and mid output;
+        the zero-conv GEMMs add them in their epilogue, so the returned tensors are already (skip + residual).
+        pre: the result of backbone() when it was computed ahead (on another stream)."""
+        down_raw, mid, ups, (H, W) = pre if pre is not None else self.backbone(x16, t, F, h, w)
         new_skips = []
         for z, (s, sh, sw), (us, _, _) in zip(self.zd, down_raw, unet_skips):
             o, _, _ = z(s, F, sh, sw, res0=us, scale=scale)
@@ -202,12 +208,32 @@ class Denoiser:
         self.unet = UNetMotion(ctx, cfg, text_h16)
         self.brush = BrushNet(ctx, cfg, text_h16)
 
+    # Two-stream schedule (opt-in, measured in profiles/r3_two_stream_ab.txt): the BrushNet backbone does not depend on the UNet's down / mid path
+    # (only its zero convolutions add the UNet skips), so the two can share the GPU.  OFF by default: kernels of two streams overlap, which makes
+    # the per-kernel HIP-event durations the bench reports (roofline of the dominant kernel) meaningless.
+    OVERLAP = False
+
     def __call__(self, lat, cond, mask2d, t, F, h, w, H, W):
         """lat, cond: fp32 [F,h,w,4] device; mask2d: u8 [F,H,W]."""
         ctx = self.ctx
         lat8 = hip.pad_channels(ctx.dt, lat, 8).view(F * h * w, 8)
-        st, skips, mid, (Hm, Wm) = self.unet.down_mid(lat8, t, F, h, w)
         x16 = hip.brushnet_input(ctx.dt, lat, cond, mask2d, H, W).view(F * h * w, 16)
-        new_skips, new_mid, add_up = self.brush(x16, t, F, h, w, skips, mid)
+        pre = None
+        if Denoiser.OVERLAP:
+            main = torch.cuda.current_stream()
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=lat.device)
+            self._side.wait_stream(main)                       # x16 / t are ready
+            with torch.cuda.stream(self._side):
+                pre = self.brush.backbone(x16, t, F, h, w)
+            x16.record_stream(self._side)
+        st, skips, mid, (Hm, Wm) = self.unet.down_mid(lat8, t, F, h, w)
+        if pre is not None:
+            main.wait_stream(self._side)
+            for grp in (pre[0], pre[2]):                        # produced on the side stream, consumed on the main one
+                for ten, _, _ in grp:
+                    ten.record_stream(main)
+            pre[1].record_stream(main)
+        new_skips, new_mid, add_up = self.brush(x16, t, F, h, w, skips, mid, pre=pre)
         eps = self.unet.up_out(st, new_skips, new_mid, F, Hm, Wm, add_up)
         return eps.view(F, h, w, 4)
