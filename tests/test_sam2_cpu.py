@@ -188,3 +188,25 @@ def test_oracle_hole_filling_and_product_imports():
     for f in ("sam2_masker.py", "videovanish_amd/sam2_model.py", "videovanish_amd/sam2_predictor.py", "videovanish_amd/sam2_weights.py", "videovanish_amd/sam2_config.py"):
         src = open(os.path.join(os.path.dirname(GOLD), "..", f)).read()
         assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_reverse_tracking_and_reset_state():
+    from oracle.sam2_ref import OracleSam2
+    p = Sam2VideoPredictor(OracleSam2(TINY_SAM2, seed=2))
+    rng = np.random.default_rng(1)
+    frames = [rng.integers(0, 256, (64, 64, 3), dtype=np.uint8) for _ in range(5)]
+    st = p.init_state(video_path=frames)
+    p.add_new_points_or_box(st, 3, 1, points=np.array([[30.0, 30.0]], dtype=np.float32), labels=np.array([1], dtype=np.int32))
+    back = list(p.propagate_in_video(st, reverse=True))
+    assert [b[0] for b in back] == [3, 2, 1, 0] and all(tuple(b[2].shape) == (1, 1, 64, 64) for b in back)
+    assert all(v["reverse"] for t, v in st["frames_tracked_per_obj"][0].items())
+    fwd = list(p.propagate_in_video(st))                                   # then forward from the conditioning frame: 3 (as prompted), 4
+    assert [f[0] for f in fwd] == [3, 4] and torch.equal(fwd[0][2], back[0][2])
+    assert sorted(st["output_dict_per_obj"][0]["non_cond_frame_outputs"]) == [0, 1, 2, 4]
+    p.reset_state(st)
+    assert st["obj_ids"] == [] and st["num_frames"] == 5
+    with pytest.raises(RuntimeError, match="No input points or masks are provided for any object"):
+        next(p.propagate_in_video(st))
+    # reverse from frame 0: nothing to do
+    p.add_new_points_or_box(st, 0, 4, points=np.array([[10.0, 10.0]], dtype=np.float32), labels=np.array([1], dtype=np.int32))
+    assert list(p.propagate_in_video(st, reverse=True)) == []

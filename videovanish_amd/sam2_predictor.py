@@ -8,7 +8,8 @@ Kept from upstream: clicks / boxes are scaled from video to model resolution, a 
 prompt on a frame feeds the previous low-resolution logits (clamped to +-32) back as the mask prompt, prompted frames are conditioning
 frames whose memory is encoded in the preflight, tracking runs forward from the first conditioning frame (earlier frames are never yielded:
 the reference paints them black, sam2_masker.py:157), masks come back at video resolution as logits (> 0 = object).
-Not built (the reference never uses them): mask prompts, reverse tracking, `reset_state`, `remove_object`, CPU offloading.
+Not built (the reference never uses them): mask prompts from the caller, `remove_object`, CPU offloading.  Reverse tracking and `reset_state`
+are there for completeness of the API.
 """
 from collections import OrderedDict
 
@@ -38,6 +39,13 @@ class Sam2VideoPredictor:
                 "obj_id_to_idx": OrderedDict(), "obj_idx_to_id": OrderedDict(), "obj_ids": [],
                 "output_dict_per_obj": {}, "temp_output_dict_per_obj": {}, "frames_tracked_per_obj": {}}
 
+    def reset_state(self, inference_state):
+        """forget every prompt and tracking result, keep the frames (upstream reset_state)."""
+        st = inference_state
+        for k in ("point_inputs_per_obj", "cached_features", "output_dict_per_obj", "temp_output_dict_per_obj", "frames_tracked_per_obj"):
+            st[k] = {}
+        st["obj_id_to_idx"], st["obj_idx_to_id"], st["obj_ids"] = OrderedDict(), OrderedDict(), []
+
     def _obj_id_to_idx(self, st, obj_id):
         idx = st["obj_id_to_idx"].get(obj_id, None)
         if idx is not None:
@@ -54,13 +62,13 @@ class Sam2VideoPredictor:
         st["frames_tracked_per_obj"][idx] = {}
         return idx
 
-    def _image_feature(self, st, frame_idx):
+    def _image_feature(self, st, frame_idx, reverse=False):
         """upstream caches the most recent frame only and encodes one frame at a time; here a miss encodes `lookahead` consecutive frames in one
         batch when the model offers it (a single 1024^2 frame is too little work for the GEMMs of the trunk) -- same values, fewer launches."""
         hit = st["cached_features"].get(frame_idx, None)
         if hit is None:
             la = self.lookahead if hasattr(self.model, "encode_images") else 1
-            idx = list(range(frame_idx, min(frame_idx + max(1, la), st["num_frames"])))
+            idx = list(range(frame_idx, max(frame_idx - max(1, la), -1), -1)) if reverse else list(range(frame_idx, min(frame_idx + max(1, la), st["num_frames"])))
             if len(idx) > 1:
                 st["cached_features"] = dict(zip(idx, self.model.encode_images([st["images"][i] for i in idx])))
             else:
@@ -135,7 +143,7 @@ class Sam2VideoPredictor:
 
     def _run_single_frame_inference(self, st, output_dict, frame_idx, is_init_cond_frame, point_inputs, reverse, run_mem_encoder,
                                     prev_sam_mask_logits=None):
-        feats = self._image_feature(st, frame_idx)
+        feats = self._image_feature(st, frame_idx, reverse)
         cur = self.model.track_step(frame_idx, is_init_cond_frame, feats, point_inputs, output_dict, st["num_frames"],
                                     track_in_reverse=reverse, run_mem_encoder=run_mem_encoder, prev_sam_mask_logits=prev_sam_mask_logits)
         if self.fill_hole_area > 0:
@@ -163,26 +171,28 @@ class Sam2VideoPredictor:
 
     def propagate_in_video(self, inference_state, start_frame_idx=None, max_frame_num_to_track=None, reverse=False):
         st = inference_state
-        if reverse:
-            raise NotImplementedError("reverse tracking is not built (the reference never asks for it, sam2_masker.py:147)")
         self.propagate_in_video_preflight(st)
         n = st["num_frames"]
         if start_frame_idx is None:
             start_frame_idx = min(t for d in st["output_dict_per_obj"].values() for t in d["cond_frame_outputs"])
         if max_frame_num_to_track is None:
             max_frame_num_to_track = n
-        end = min(start_frame_idx + max_frame_num_to_track, n - 1)
+        if reverse:                                                  # (the reference tracks forward only, sam2_masker.py:147)
+            end = max(start_frame_idx - max_frame_num_to_track, 0)
+            order = range(start_frame_idx, end - 1, -1) if start_frame_idx > 0 else []
+        else:
+            order = range(start_frame_idx, min(start_frame_idx + max_frame_num_to_track, n - 1) + 1)
         H, W = st["video_height"], st["video_width"]
-        for frame_idx in range(start_frame_idx, end + 1):
+        for frame_idx in order:
             per_obj = []
             for obj_idx in range(len(st["obj_ids"])):
                 out_dict = st["output_dict_per_obj"][obj_idx]
                 if frame_idx in out_dict["cond_frame_outputs"]:
                     cur = out_dict["cond_frame_outputs"][frame_idx]
                 else:
-                    cur = self._run_single_frame_inference(st, out_dict, frame_idx, False, None, False, True)
+                    cur = self._run_single_frame_inference(st, out_dict, frame_idx, False, None, reverse, True)
                     out_dict["non_cond_frame_outputs"][frame_idx] = cur
-                st["frames_tracked_per_obj"][obj_idx][frame_idx] = {"reverse": False}
+                st["frames_tracked_per_obj"][obj_idx][frame_idx] = {"reverse": reverse}
                 per_obj.append(self.model.to_numpy(self.model.masks_to_video_res(cur["pred_masks"], H, W)).reshape(1, H, W))
             yield frame_idx, st["obj_ids"], torch.from_numpy(np.stack(per_obj, axis=0))       # [objects, 1, H, W] fp32 logits, as upstream
 
