@@ -28,6 +28,10 @@ IMG_STD = (0.229, 0.224, 0.225)
 _HEAD_DIMS = (32, 40, 64, 80, 128, 160, 256, 512)          # head dims vv_attention is built for
 
 
+def _up64(n):
+    return (n + 63) // 64 * 64
+
+
 def _pad_dim(d):
     for k in _HEAD_DIMS:
         if k >= d:
@@ -158,13 +162,18 @@ class HipSam2:
             dp = _pad_dim(d)
             wq, bq = W(n + ".attn.qkv.weight"), W(n + ".attn.qkv.bias")
             wq, bq = _pad_heads_rows(wq, bq, 3 * heads, d, dp)
-            L = dict(b, d=d, dp=dp,
+            # reduction lengths that are not multiples of 64 (144, 288; the attention output of stage 1: 2 x 80) would take vv_conv_gemm's generic
+            # register-staged loader, 5-10x slower than the LDS-DMA path on the 65536-token stage: the h16 operands carry zero-padded channels instead
+            k1, k2, ko = _up64(b["dim"]), _up64(b["dim_out"]), _up64(heads * dp)
+            padk = lambda w, k: torch.nn.functional.pad(w, (0, k - w.shape[1]))
+            L = dict(b, d=d, dp=dp, k1=k1, k2=k2, ko=ko,
                      n1=(dev(W(n + ".norm1.weight")), dev(W(n + ".norm1.bias"))), n2=(dev(W(n + ".norm2.weight")), dev(W(n + ".norm2.bias"))),
-                     qkv=_Lin(ctx, wq, bq), proj=_Lin(ctx, _pad_heads_cols(W(n + ".attn.proj.weight"), heads, d, dp), W(n + ".attn.proj.bias")),
-                     mlp0=_Lin(ctx, W(n + ".mlp.layers.0.weight"), W(n + ".mlp.layers.0.bias")),
+                     qkv=_Lin(ctx, padk(wq, k1), bq),
+                     proj=_Lin(ctx, padk(_pad_heads_cols(W(n + ".attn.proj.weight"), heads, d, dp), ko), W(n + ".attn.proj.bias")),
+                     mlp0=_Lin(ctx, padk(W(n + ".mlp.layers.0.weight"), k2), W(n + ".mlp.layers.0.bias")),
                      mlp1=_Lin(ctx, W(n + ".mlp.layers.1.weight"), W(n + ".mlp.layers.1.bias")))
             if b["dim"] != b["dim_out"]:
-                L["sc"] = _Lin(ctx, W(n + ".proj.weight"), W(n + ".proj.bias"))
+                L["sc"] = _Lin(ctx, padk(W(n + ".proj.weight"), k1), W(n + ".proj.bias"))
             self.hb.append(L)
         # ---- neck + the decoder's high-resolution 1x1 convolutions (SAM2Base.forward_image)
         dims = list(reversed(cfg.stage_dims))
@@ -292,7 +301,7 @@ class HipSam2:
     def _block(self, x, Bf, H, W, L):
         ctx, dt = self.ctx, self.ctx.dt
         heads, dp, ws = L["heads"], L["dp"], L["window"]
-        xn = self._ln(x, L["n1"], 1e-6)
+        xn = self._ln(x, L["n1"], 1e-6, cpad=L["k1"])
         sc = x
         if "sc" in L:
             sc = hip.maxpool2x2(L["sc"](xn), Bf, H, W)
@@ -314,16 +323,20 @@ class HipSam2:
             q_bs = heads * Nq * dp
         else:
             q, q_bs = qkv, 3 * blk
-        o = torch.empty((B * Nq, heads * dp), dtype=ctx.h16, device=x.device)
-        hip.attention(dt, q, qkv, qkv, o, B=B, heads=heads, Nq=Nq, Nkv=N, D=dp, q_bs=q_bs, k_bs=3 * blk, v_bs=3 * blk, o_bs=Nq * heads * dp,
-                      q_rs=dp, k_rs=dp, v_rs=dp, o_rs=heads * dp, k_off=blk, v_off=2 * blk, q_hs=Nq * dp, k_hs=N * dp, v_hs=N * dp,
+        ko = L["ko"]
+        if ko == heads * dp:
+            o = torch.empty((B * Nq, ko), dtype=ctx.h16, device=x.device)
+        else:           # padded row: the attention kernel writes the first heads * dp columns, the rest stays zero (one buffer per shape, reused)
+            o = self._index_free(("opad", B * Nq, ko), lambda: torch.zeros((B * Nq, ko), dtype=ctx.h16, device=x.device))
+        hip.attention(dt, q, qkv, qkv, o, B=B, heads=heads, Nq=Nq, Nkv=N, D=dp, q_bs=q_bs, k_bs=3 * blk, v_bs=3 * blk, o_bs=Nq * ko,
+                      q_rs=dp, k_rs=dp, v_rs=dp, o_rs=ko, k_off=blk, v_off=2 * blk, q_hs=Nq * dp, k_hs=N * dp, v_hs=N * dp,
                       scale=float(L["d"]) ** -0.5)
         if ws > 0:
             y = hip.gather_rows(L["proj"](o), self._unpart_idx(Bf, Ho, Wo, ws // 2 if L["q_stride"] else ws))
             x = hip.axpby(sc, y, 1.0, 1.0)
         else:
             x = L["proj"](o, res0=sc)
-        h = L["mlp0"](self._ln(x, L["n2"], 1e-6), out_dtype=ctx.h16)
+        h = L["mlp0"](self._ln(x, L["n2"], 1e-6, cpad=L["k2"]), out_dtype=ctx.h16)
         hip.act_inplace(h, hip.ACT_GELU)
         return L["mlp1"](h, res0=x), Ho, Wo
 
