@@ -422,6 +422,12 @@ int launch_cfg(const vv_conv_params& p, int M, hipStream_t st) {
 template <typename T, int MODE>
 int launch_t(const vv_conv_params& p, int M, hipStream_t st) {
     // tile choice: GEGLU needs an even number of N tiles per wave; N % 160 == 0 -> 128x160; tiny N -> 128x16
+#ifdef VV_AB      // lab: 128 x 320 tile (wave tile 64 x 160: 14 operand fragments per 40 MFMAs instead of 9 per 20; 2 blocks per CU), profiles/r3_gemm_n320_ab.txt
+    static const bool n320 = VV_AB_ENV("VV_GEMM_N320");
+    if constexpr (MODE != MODE_H16 && MODE != MODE_F32) {
+        if (n320 && p.Npad % 320 == 0 && M >= 4096) return launch_cfg<T, 2, 2, 4, 10, MODE>(p, M, st);
+    }
+#endif
     if (p.epilogue == VV_EPI_GEGLU) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, M, st);
     // N a multiple of both: the 128x128 tile runs 4 blocks per CU (128 VGPRs) against 3 for 128x160 -> +2..8 % on the LDS-DMA
     // loaders when there are enough row tiles (profiles/r1_gemm_ab.txt, eighth A/B)
