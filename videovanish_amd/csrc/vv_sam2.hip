@@ -59,6 +59,49 @@ __global__ __launch_bounds__(256) void layernorm_ex_kernel(const float* __restri
     }
 }
 
+// fast form: C % 4 == 0 and C <= 256 * NCH: the row lives in registers (float4 per lane and step), one read of x
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_ex_vec_kernel(const float* __restrict__ x, int64_t M, int C, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, int act, void* __restrict__ out, int out_f32, int cpad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int C4 = C >> 2;
+    const float4* xr = (const float4*)(x + row * C);
+    float4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < C4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        if (lane + 64 * i < C4) {
+            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    const int P4 = cpad >> 2;
+#pragma unroll
+    for (int i = 0; i < NCH + 1; ++i) {                              // one extra step covers the zero padding (cpad - C <= 252 columns)
+        const int c = lane + 64 * i;
+        if (c >= P4) continue;
+        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C4 && i < NCH) {
+            const float4 g = ((const float4*)gamma)[c], b = ((const float4*)beta)[c];
+            y.x = act_f((v[i].x - mean) * rstd * g.x + b.x, act); y.y = act_f((v[i].y - mean) * rstd * g.y + b.y, act);
+            y.z = act_f((v[i].z - mean) * rstd * g.z + b.z, act); y.w = act_f((v[i].w - mean) * rstd * g.w + b.w, act);
+        }
+        if (out_f32) ((float4*)out)[row * P4 + c] = y;
+        else ((uint2*)out)[row * P4 + c] = make_uint2(pack2<T>(y.x, y.y), pack2<T>(y.z, y.w));
+    }
+}
+
 // ---- 2x2 max pooling, NHWC ------------------------------------------------------------------------------------------------------
 template <typename T, bool F32>
 __global__ __launch_bounds__(256) void maxpool2_kernel(const void* __restrict__ x, int B, int H, int W, int C, int64_t in_bs, void* __restrict__ out) {
@@ -342,8 +385,18 @@ extern "C" int vv_layernorm_ex(const float* x, int64_t M, int C, const float* ga
     const int of32 = out_dtype == VV_F32;
     if (!of32 && out_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_layernorm_ex: out_dtype must be VV_F32 or the h16 dtype");
     hipStream_t st = (hipStream_t)stream;
-    SAM2_DT(hipLaunchKernelGGL(layernorm_ex_kernel<BF16>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, M, C, gamma, beta, eps, act, out, of32, cpad),
-            hipLaunchKernelGGL(layernorm_ex_kernel<F16>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, M, C, gamma, beta, eps, act, out, of32, cpad));
+    const dim3 grid((unsigned)((M + 3) / 4));
+#define LNX_VEC(NCH) SAM2_DT(hipLaunchKernelGGL((layernorm_ex_vec_kernel<BF16, NCH>), grid, dim3(256), 0, st, x, M, C, gamma, beta, eps, act, out, of32, cpad), \
+                            hipLaunchKernelGGL((layernorm_ex_vec_kernel<F16, NCH>), grid, dim3(256), 0, st, x, M, C, gamma, beta, eps, act, out, of32, cpad))
+    if (C % 4 == 0 && cpad % 4 == 0 && C >= 64 && cpad - C <= 252) {
+        if (C <= 256) { LNX_VEC(1); VV_CHECK_LAUNCH("vv_layernorm_ex"); return VV_OK; }
+        if (C <= 768) { LNX_VEC(3); VV_CHECK_LAUNCH("vv_layernorm_ex"); return VV_OK; }
+        if (C <= 1280) { LNX_VEC(5); VV_CHECK_LAUNCH("vv_layernorm_ex"); return VV_OK; }
+        if (C <= 2304) { LNX_VEC(9); VV_CHECK_LAUNCH("vv_layernorm_ex"); return VV_OK; }
+    }
+#undef LNX_VEC
+    SAM2_DT(hipLaunchKernelGGL(layernorm_ex_kernel<BF16>, grid, dim3(256), 0, st, x, M, C, gamma, beta, eps, act, out, of32, cpad),
+            hipLaunchKernelGGL(layernorm_ex_kernel<F16>, grid, dim3(256), 0, st, x, M, C, gamma, beta, eps, act, out, of32, cpad));
     VV_CHECK_LAUNCH("vv_layernorm_ex");
     return VV_OK;
 }
@@ -409,9 +462,29 @@ extern "C" int vv_mask_mem_input(const float* logits, int64_t n, int binarize, f
     return VV_OK;
 }
 
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void act_vec8_kernel(uint4* __restrict__ x, int64_t n8, int act) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float v[8];
+    unpack8<T>(x[i], v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act_f(v[e], act);
+    x[i] = pack8<T>(v);
+}
+}  // namespace
+
 extern "C" int vv_act(void* x, int x_dtype, int64_t n, int act, void* stream) {
     if (!x || n <= 0) VV_FAIL(VV_E_ARG, "vv_act: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    if (x_dtype != VV_F32 && n % 8 == 0 && ((uintptr_t)x & 15) == 0) {       // h16, 16 bytes per thread
+        if (x_dtype == VV_BF16) hipLaunchKernelGGL(act_vec8_kernel<BF16>, grid1(n / 8), dim3(256), 0, st, (uint4*)x, n / 8, act);
+        else if (x_dtype == VV_F16) hipLaunchKernelGGL(act_vec8_kernel<F16>, grid1(n / 8), dim3(256), 0, st, (uint4*)x, n / 8, act);
+        else VV_FAIL(VV_E_ARG, "vv_act: bad dtype");
+        VV_CHECK_LAUNCH("vv_act");
+        return VV_OK;
+    }
     if (x_dtype == VV_F32) hipLaunchKernelGGL((act_kernel<F16, true>), grid1(n), dim3(256), 0, st, x, n, act);
     else if (x_dtype == VV_BF16) hipLaunchKernelGGL((act_kernel<BF16, false>), grid1(n), dim3(256), 0, st, x, n, act);
     else if (x_dtype == VV_F16) hipLaunchKernelGGL((act_kernel<F16, false>), grid1(n), dim3(256), 0, st, x, n, act);
