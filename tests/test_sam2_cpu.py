@@ -210,3 +210,31 @@ def test_reverse_tracking_and_reset_state():
     # reverse from frame 0: nothing to do
     p.add_new_points_or_box(st, 0, 4, points=np.array([[10.0, 10.0]], dtype=np.float32), labels=np.array([1], dtype=np.int32))
     assert list(p.propagate_in_video(st, reverse=True)) == []
+
+
+def test_cli_main_with_a_recording_predictor(tmp_path, monkeypatch):
+    """reference sam2_masker.py:183-205 on the CPU side: argument names, default output name, start / max frame selection, FFV1 / Matroska out."""
+    import json
+    import sys
+    from videovanish_amd import frameio as FIO
+    H, W, T = 20, 28, 6
+    frames = [np.random.default_rng(t).integers(0, 256, (H, W, 3), dtype=np.uint8) for t in range(T)]
+    color, ann = str(tmp_path / "c.mkv"), str(tmp_path / "a.json")
+    FIO.write_video_frames_to_path(color, frames, 30.0, H, W)
+    json.dump({"keyframes": [{"frame_idx": 0, "pos_clicks": [{"x": 0.5, "y": 0.5}]}]}, open(ann, "w"))
+    monkeypatch.delitem(sys.modules, "tools", raising=False)
+    p = _RecordingPredictor(4, H, W)
+    try:
+        sam2_masker.configure(p)
+        monkeypatch.setattr(sys, "argv", ["sam2_masker.py", "--color_video", color, "--annotations", ann, "--start_frame", "2", "--max_frames", "4"])
+        sam2_masker.main()
+    finally:
+        sam2_masker.configure(None)
+    out, fps = FIO.load_video_frames_from_path(color + "_sam2_mask.mkv")
+    assert abs(fps - 30.0) < 1e-3 and len(out) == 4 and out[0].shape == (H, W, 3)
+    assert p.calls[0] == {"op": "init_state", "n_frames": 4, "shape": [H, W, 3]}
+    assert p.calls[1]["obj_id"] == 1 and p.calls[1]["points"] == [[14.0, 10.0]]                  # "obj" defaults to 1 (reference :113)
+    assert out[0].any() and not out[3].any()                                                    # the stub never yields the last frame
+    with pytest.raises(SystemExit):
+        monkeypatch.setattr(sys, "argv", ["sam2_masker.py", "--color_video", color])             # --annotations is required (reference :187)
+        sam2_masker.main()
