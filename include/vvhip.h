@@ -404,6 +404,13 @@ int vv_sam_pick(const float* masks, int HW, const int32_t* sel, float no_obj_sco
 int vv_select_f32(const float* a, const float* b, const int32_t* flag, int64_t n, float* out, void* stream);
 int vv_add_rowvec_unless(float* x, const float* vec, const float* score, int64_t M, int C, void* stream);
 int vv_clamp_f32(const float* x, int64_t n, float lo, float hi, float* out, void* stream);
+/* memory encoder, mask path, layers 0-4 of MaskDownSampler fused with what feeds them (sam2_base.py::_encode_new_memory): low-res logits [lo][lo]
+ * -> bilinear to [S][S] (torch semantics) -> (binarize ? x > 0 : sigmoid) * scale + bias -> conv 3x3 / 2 (1 -> 4) + LayerNorm2d + GELU -> mid h16
+ * [(S/2)^2][8] -> conv 3x3 / 2 (4 -> 16) + LayerNorm2d + GELU -> out h16 [(S/4)^2][16].  Weights fp32 [Cout][Cin][3][3]; the S x S intermediate
+ * never exists.  Replaces vv_resize_bilinear_f32 + vv_mask_mem_input + 2 x (vv_conv_gemm + vv_layernorm_ex) of the layer-by-layer path. */
+int vv_sam2_maskdown(const float* logits, int lo, int S, int binarize, float scale, float bias, const float* w1, const float* b1, const float* g1,
+                     const float* be1, const float* w2, const float* b2, const float* g2, const float* be2, float eps, void* mid, void* out, int dtype,
+                     void* stream);
 /* masks [nm][HW] = hyper [nm][C] @ up [HW][C]^T (fp32; the mask decoder's hypernetwork product), nm <= 8 */
 int vv_hyper_masks(const float* hyper, const float* up, int HW, int C, int nm, float* masks, void* stream);
 /* fill_holes_in_mask_scores: 8-connected components of (mask <= 0) with area <= max_area are set to 0.1; ws: 3*H*W int32 */

@@ -282,8 +282,14 @@ def test_image_encoder_and_prompted_frame(name):
         fm_o, _ = ora.encode_memory_from_low_res(fo, o["pred_masks"], torch.tensor([[score]]), from_pts)
         fm_h, _ = hipm.encode_memory_from_low_res(fh, o["pred_masks"].reshape(-1).contiguous().to(_dev()), torch.tensor([score]).to(_dev()), from_pts)
         e = _rel(fm_h, nhwc(fm_o))
-        print(f"sam2_memory_encoder[{name},binarised={from_pts},score={score}]: rel {e:.2e}")
-        assert e < 6e-3
+        type(hipm).FUSED_MASKDOWN = False                     # the layer-by-layer form of the mask path (resize, mask transform, 2 x (conv GEMM + LayerNorm))
+        try:
+            fm_l, _ = hipm.encode_memory_from_low_res(fh, o["pred_masks"].reshape(-1).contiguous().to(_dev()), torch.tensor([score]).to(_dev()), from_pts)
+        finally:
+            type(hipm).FUSED_MASKDOWN = True
+        e_l = _rel(fm_l, nhwc(fm_o))
+        print(f"sam2_memory_encoder[{name},binarised={from_pts},score={score}]: rel {e:.2e} (fused mask path), {e_l:.2e} (layer by layer)")
+        assert e < 6e-3 and e_l < 6e-3
     # one tracked frame on IDENTICAL memories (the oracle's, re-laid-out for the HIP model): memory attention + RoPE + object pointers
     f1 = _frames(2, S, S + 16)[1]
     fo1, fh1 = ora.encode_image(f1), hipm.encode_image(f1)

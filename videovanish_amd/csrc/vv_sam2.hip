@@ -361,6 +361,94 @@ __global__ __launch_bounds__(256) void hyper_masks_kernel(const float* __restric
     for (int j = 0; j < 8; ++j) if (j < nm) masks[(int64_t)j * HW + p] = acc[j];
 }
 
+// ---- memory encoder, mask path, first two layers fused (memory_encoder.py::MaskDownSampler layers 0-1 and 3-4 after sam2_base.py::_encode_new_memory):
+// layer 1: low-res logits [lo][lo] --bilinear (torch, align_corners = False)--> [S][S] --(binarise | sigmoid) * scale + bias--> conv 3x3 / stride 2 / pad 1
+// (1 -> C1 channels) --> LayerNorm over channels --> GELU --> h16 [S/2 * S/2][cpad].  One thread per output pixel: the 1024^2 intermediate never exists.
+template <typename T, int C1>
+__global__ __launch_bounds__(256) void maskdown1_kernel(const float* __restrict__ logits, int lo, int S, int binarize, float scale, float bias,
+                                                        const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ g,
+                                                        const float* __restrict__ be, float eps, unsigned short* __restrict__ out, int cpad) {
+    const int Ho = S >> 1;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Ho * Ho) return;
+    const int oy = i / Ho, ox = i - oy * Ho;
+    const float sc = (float)lo / (float)S;
+    float acc[C1];
+#pragma unroll
+    for (int c = 0; c < C1; ++c) acc[c] = b[c];
+    for (int ky = 0; ky < 3; ++ky) {
+        const int Y = 2 * oy + ky - 1;
+        if (Y < 0 || Y >= S) continue;
+        float fy = ((float)Y + 0.5f) * sc - 0.5f; fy = fy < 0.f ? 0.f : fy;
+        const int y0 = (int)fy, y1 = y0 + (y0 < lo - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, hy = 1.f - ly;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int X = 2 * ox + kx - 1;
+            if (X < 0 || X >= S) continue;
+            float fx = ((float)X + 0.5f) * sc - 0.5f; fx = fx < 0.f ? 0.f : fx;
+            const int x0 = (int)fx, x1 = x0 + (x0 < lo - 1 ? 1 : 0);
+            const float lx = fx - (float)x0, hx = 1.f - lx;
+            const float v = hy * (hx * logits[y0 * lo + x0] + lx * logits[y0 * lo + x1]) + ly * (hx * logits[y1 * lo + x0] + lx * logits[y1 * lo + x1]);
+            const float m = (binarize ? (v > 0.f ? 1.f : 0.f) : 1.0f / (1.0f + __expf(-v))) * scale + bias;
+#pragma unroll
+            for (int c = 0; c < C1; ++c) acc[c] = fmaf(m, w[(c * 3 + ky) * 3 + kx], acc[c]);
+        }
+    }
+    float mean = 0.f;
+#pragma unroll
+    for (int c = 0; c < C1; ++c) mean += acc[c];
+    mean /= (float)C1;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < C1; ++c) { const float d = acc[c] - mean; var += d * d; }
+    const float rstd = rsqrtf(var / (float)C1 + eps);
+    unsigned short* o = out + (int64_t)i * cpad;
+#pragma unroll
+    for (int c = 0; c < C1; ++c) o[c] = T::from_f32(gelu_f((acc[c] - mean) * rstd * g[c] + be[c]));
+    for (int c = C1; c < cpad; ++c) o[c] = 0;
+}
+
+// layers with a handful of channels: conv 3x3 / stride 2 / pad 1 (CIN -> COUT) + LayerNorm over channels + GELU, h16 [H*W][cin_pad] -> h16 [H/2*W/2][cpad]
+template <typename T, int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv3s2_ln_gelu_kernel(const unsigned short* __restrict__ x, int H, int W, int cin_pad, const float* __restrict__ w,
+                                                              const float* __restrict__ b, const float* __restrict__ g, const float* __restrict__ be, float eps,
+                                                              unsigned short* __restrict__ out, int cpad) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Ho * Wo) return;
+    const int oy = i / Wo, ox = i - oy * Wo;
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = b[c];
+    for (int ky = 0; ky < 3; ++ky) {
+        const int Y = 2 * oy + ky - 1;
+        if (Y < 0 || Y >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int X = 2 * ox + kx - 1;
+            if (X < 0 || X >= W) continue;
+            const unsigned short* px = x + ((int64_t)Y * W + X) * cin_pad;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float v = T::to_f32(px[ci]);
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, w[((c * CIN + ci) * 3 + ky) * 3 + kx], acc[c]);
+            }
+        }
+    }
+    float mean = 0.f;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) mean += acc[c];
+    mean /= (float)COUT;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) { const float d = acc[c] - mean; var += d * d; }
+    const float rstd = rsqrtf(var / (float)COUT + eps);
+    unsigned short* o = out + (int64_t)i * cpad;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) o[c] = T::from_f32(gelu_f((acc[c] - mean) * rstd * g[c] + be[c]));
+    for (int c = COUT; c < cpad; ++c) o[c] = 0;
+}
+
 inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
@@ -561,5 +649,19 @@ extern "C" int vv_hyper_masks(const float* hyper, const float* up, int HW, int C
     if (!hyper || !up || !masks || HW <= 0 || C <= 0 || nm <= 0 || nm > 8) VV_FAIL(VV_E_ARG, "vv_hyper_masks: bad arguments (nm <= 8)");
     hipLaunchKernelGGL(hyper_masks_kernel, grid1(HW), dim3(256), 0, (hipStream_t)stream, hyper, up, HW, C, nm, masks);
     VV_CHECK_LAUNCH("vv_hyper_masks");
+    return VV_OK;
+}
+
+extern "C" int vv_sam2_maskdown(const float* logits, int lo, int S, int binarize, float scale, float bias, const float* w1, const float* b1, const float* g1,
+                                const float* be1, const float* w2, const float* b2, const float* g2, const float* be2, float eps, void* mid, void* out, int dtype,
+                                void* stream) {
+    if (!logits || !w1 || !b1 || !g1 || !be1 || !w2 || !b2 || !g2 || !be2 || !mid || !out || lo <= 0 || S < 4 || (S & 3)) VV_FAIL(VV_E_ARG, "vv_sam2_maskdown: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int H1 = S / 2, H2 = S / 4;
+    SAM2_DT(hipLaunchKernelGGL((maskdown1_kernel<BF16, 4>), grid1((int64_t)H1 * H1), dim3(256), 0, st, logits, lo, S, binarize, scale, bias, w1, b1, g1, be1, eps, (unsigned short*)mid, 8),
+            hipLaunchKernelGGL((maskdown1_kernel<F16, 4>), grid1((int64_t)H1 * H1), dim3(256), 0, st, logits, lo, S, binarize, scale, bias, w1, b1, g1, be1, eps, (unsigned short*)mid, 8));
+    SAM2_DT(hipLaunchKernelGGL((conv3s2_ln_gelu_kernel<BF16, 4, 16>), grid1((int64_t)H2 * H2), dim3(256), 0, st, (const unsigned short*)mid, H1, H1, 8, w2, b2, g2, be2, eps, (unsigned short*)out, 16),
+            hipLaunchKernelGGL((conv3s2_ln_gelu_kernel<F16, 4, 16>), grid1((int64_t)H2 * H2), dim3(256), 0, st, (const unsigned short*)mid, H1, H1, 8, w2, b2, g2, be2, eps, (unsigned short*)out, 16));
+    VV_CHECK_LAUNCH("vv_sam2_maskdown");
     return VV_OK;
 }

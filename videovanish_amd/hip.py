@@ -107,7 +107,7 @@ EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name
            # SAM 2 (row n4)
            "vv_u8_normalize", "vv_layernorm_ex", "vv_maxpool2x2", "vv_rope_apply", "vv_dwconv", "vv_pixel_shuffle2", "vv_resize_bilinear_f32",
            "vv_mask_mem_input", "vv_act", "vv_prompt_points", "vv_sine_pe_1d", "vv_sam_select", "vv_sam_pick", "vv_select_f32",
-           "vv_add_rowvec_unless", "vv_clamp_f32", "vv_fill_holes", "vv_hyper_masks", "vv_attention_merge", "vv_ycbcr_to_rgb"]
+           "vv_add_rowvec_unless", "vv_clamp_f32", "vv_fill_holes", "vv_hyper_masks", "vv_attention_merge", "vv_ycbcr_to_rgb", "vv_sam2_maskdown"]
 
 
 def lib():
@@ -874,4 +874,14 @@ def ycbcr_to_rgb(y, cb, cr, hshift, vshift, full_range=False):
     T, H, W = y.shape
     out = torch.empty((T, H, W, 3), dtype=torch.uint8, device=y.device)
     _check(lib().vv_ycbcr_to_rgb(_p(y), _p(cb), _p(cr), T, H, W, int(hshift), int(vshift), int(bool(full_range)), _p(out), _stream()), "vv_ycbcr_to_rgb")
+    return out
+
+
+def sam2_maskdown(dtype, logits, lo, S, binarize, scale, bias, l1, l2, eps=1e-6):
+    """fused front of the SAM 2 memory encoder's mask path (vv_sam2_maskdown): logits fp32 [lo*lo] -> h16 [(S/4)^2, 16].  l1 / l2: (w, b, gamma, beta)."""
+    _need_cuda(logits, *l1, *l2)
+    mid = torch.empty(((S // 2) ** 2, 8), dtype=h16(dtype), device=logits.device)
+    out = torch.empty(((S // 4) ** 2, 16), dtype=h16(dtype), device=logits.device)
+    _check(lib().vv_sam2_maskdown(_p(logits), lo, S, int(bool(binarize)), _f(scale), _f(bias), _p(l1[0]), _p(l1[1]), _p(l1[2]), _p(l1[3]), _p(l2[0]), _p(l2[1]),
+                                  _p(l2[2]), _p(l2[3]), _f(eps), _p(mid), _p(out), dtype, _stream()), "vv_sam2_maskdown")
     return out

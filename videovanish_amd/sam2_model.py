@@ -202,6 +202,8 @@ class HipSam2:
                             dev(W(f"{n}.{3 * j + 1}.weight")), dev(W(f"{n}.{3 * j + 1}.bias")), c * 4))
             c *= 4
         self.md_out = _Lin(ctx, W(E + "mask_downsampler.encoder.12.weight").flatten(1), W(E + "mask_downsampler.encoder.12.bias"))
+        n = f"{E}mask_downsampler.encoder"
+        self.md_direct = [tuple(dev(W(f"{n}.{k}.{t}")) for k, t in ((3 * j, "weight"), (3 * j, "bias"), (3 * j + 1, "weight"), (3 * j + 1, "bias"))) for j in (0, 1)]
         self.pix_proj = _Lin(ctx, W(E + "pix_feat_proj.weight").flatten(1), W(E + "pix_feat_proj.bias"))
         self.fuser = []
         for i in range(cfg.fuser_layers):
@@ -414,10 +416,13 @@ class HipSam2:
         return self._memory_attention(feats["top"], torch.cat(mem, dim=0), torch.cat(pos, dim=0), n_ptr_tokens)
 
     # ---- memory encoder ------------------------------------------------------------------------------------------------------------
-    def _memory_encoder(self, pix_feat, mask_in, S):
+    FUSED_MASKDOWN = True     # class-level switch: tests compare the fused front of the mask path with the layer-by-layer one
+
+    def _memory_encoder(self, pix_feat, mask_in, S, first=0):
+        """mask_in: h16 [S*S, 8] (layer-by-layer form, first = 0) or the output of vv_sam2_maskdown ([(S/4)^2, 16], first = 2 layers done)."""
         ctx, fs = self.ctx, self.cfg.feat_size
-        m, H, W = mask_in, S, S
-        for conv, g, b, cout in self.md:
+        m, H, W = mask_in, S >> first, S >> first
+        for conv, g, b, cout in self.md[first:]:
             y, H, W = conv(m, H, W, 2, 1)
             m = hip.layernorm_ex(ctx.dt, y, g, b, 1e-6, act=hip.ACT_GELU, cpad=max(8, cout))
         x = self.pix_proj(pix_feat, res0=self.md_out(m))
@@ -431,10 +436,15 @@ class HipSam2:
     def encode_memory_from_low_res(self, feats, pred_masks, object_score_logits, is_mask_from_pts):
         cfg = self.cfg
         S, lo = cfg.image_size, 4 * cfg.feat_size
-        high = hip.resize_bilinear_f32(pred_masks.reshape(lo * lo, 1), lo, lo, S, S)
-        m = hip.mask_mem_input(self.ctx.dt, high, cfg.binarize_mask_from_pts_for_mem_enc and is_mask_from_pts, cfg.sigmoid_scale_for_mem_enc,
-                               cfg.sigmoid_bias_for_mem_enc)
-        f = self._memory_encoder(feats["top"], m, S)
+        binarize = cfg.binarize_mask_from_pts_for_mem_enc and is_mask_from_pts
+        if HipSam2.FUSED_MASKDOWN:
+            m = hip.sam2_maskdown(self.ctx.dt, pred_masks.reshape(-1), lo, S, binarize, cfg.sigmoid_scale_for_mem_enc, cfg.sigmoid_bias_for_mem_enc,
+                                  self.md_direct[0], self.md_direct[1])
+            f = self._memory_encoder(feats["top"], m, S, first=2)
+        else:
+            high = hip.resize_bilinear_f32(pred_masks.reshape(lo * lo, 1), lo, lo, S, S)
+            m = hip.mask_mem_input(self.ctx.dt, high, binarize, cfg.sigmoid_scale_for_mem_enc, cfg.sigmoid_bias_for_mem_enc)
+            f = self._memory_encoder(feats["top"], m, S)
         hip.add_rowvec_unless(f, self.no_obj_embed_spatial, object_score_logits)
         return f, self.mem_pos_plain
 
