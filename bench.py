@@ -333,7 +333,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
         cpu = cpu_baseline(H, W, args.denoise_steps, args.chunk, args.overlap)
     res = {
-        "metric": "inpainted frames/sec at 720p, 50 denoise steps", "value": round(distinct / dt, 5), "unit": "frames/s", "n_gpus": world,
+        "metric": f"inpainted frames/sec at {H}p, {args.denoise_steps} denoise steps", "value": round(distinct / dt, 5), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{ {480: 'c2', 720: 'c3', 1080: 'c4'}.get(H, 'custom') } chunk: {args.chunk}-frame {W}x{H} chunk, {args.denoise_steps} DDIM steps, {args.chunk}/{args.overlap} chunk/overlap, "
