@@ -10,8 +10,13 @@ image) -> 50 DDIM steps of BrushNet + motion-UNet -> VAE decode -> overlap blend
 (weak scaling; contiguous chunk blocks per rank; the 8-frame overlaps at rank boundaries are exchanged over RCCL at
 blend time).  Credited output = DISTINCT frames (24 new frames per chunk; overlap recompute is not credited).
 
-Prints ONE JSON line (rank 0) with the driver's contract fields + `roofline` (dominant kernel, HIP-event timed inside
-the timed region) + `cpu_baseline` (the fp32 oracle on the host cores, bounded sample).
+The timed region runs the product schedule (RunConfig.concurrent_chunks chunks in flight on their own HIP streams, BrushNet beside the
+UNet's down / mid path on a second stream: kernels overlap, so per-kernel durations mean nothing there).  `roofline` / `temporal_block` /
+`kernel_times_s` therefore come from a SECOND pass over ONE chunk of the same inputs in the same process, on ONE stream with every MFMA
+kernel launch bracketed by HIP events on its launch stream ("kernel_pricing": "single-stream pass"; rank 0 only).
+
+Prints ONE JSON line (rank 0) with the driver's contract fields + `roofline` (dominant kernel) + `cpu_baseline` (the fp32 oracle on the
+host cores, bounded sample).
 """
 import argparse
 import json
@@ -192,7 +197,7 @@ def cpu_baseline(H, W, steps, chunk, overlap, sample_hw=(256, 384), vae_hw=(192,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
@@ -208,14 +213,15 @@ def main():
                     help="VAE decoder in one pass of h16 operands instead of split precision (3 MFMA passes per GEMM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--two-streams", action="store_true", help="lab: BrushNet backbone on a second HIP stream beside the UNet down / mid path "
-                    "(unet.Denoiser.OVERLAP; per-kernel event times overlap and are not reported: implies --no-kernel-events)")
+    ap.add_argument("--lanes", type=int, default=None, help="chunks of one rank in flight at once, each on its own HIP stream "
+                    "(RunConfig.concurrent_chunks; default: the product default)")
+    ap.add_argument("--one-stream", action="store_true", help="A/B: the round-3 schedule (one chunk at a time, BrushNet and UNet on one stream)")
     ap.add_argument("--dump-kernels", default=None, help="write the raw per-kernel table (launches, seconds, flops, bytes) to this JSON file")
     args = ap.parse_args()
-    if args.two_streams:
+    if args.one_stream:
         from videovanish_amd import unet as _unet
-        _unet.Denoiser.OVERLAP = True
-        args.no_kernel_events = True
+        _unet.Denoiser.OVERLAP = False
+        args.lanes = 1
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -235,7 +241,7 @@ def main():
     from videovanish_amd.pipeline import DiffuEraserHIP, chunk_plan, shard_chunks
     ucfg, vcfg = {"full": (UNetConfig(), VAEConfig()), "small": (SMALL_UNET, SMALL_VAE), "tiny": (TINY_UNET, TINY_VAE)}[args.arch]
     run = RunConfig(steps=args.denoise_steps, chunk=args.chunk, overlap=args.overlap, seed=42, weight_seed=0, dtype=args.dtype, unet=ucfg, vae=vcfg,
-                    precise_decoder=args.precise_decoder)
+                    precise_decoder=args.precise_decoder, **({"concurrent_chunks": args.lanes} if args.lanes else {}))
     t_build = time.time()
     model = DiffuEraserHIP(run, f"cuda:{local_rank}")
     torch.cuda.synchronize()
@@ -275,14 +281,11 @@ def main():
         model.forward_device(fr, pr, mk, T, base, steps=args.denoise_steps, scheduler="ddim", dist=dist)
         del fr, pr, mk
     T, base, fr, pr, mk = resident_inputs(args.steps)
-    if not args.no_kernel_events:
-        hip.PROFILE = []
     barrier()
     t0 = time.time()
     out, (lo, hi) = model.forward_device(fr, pr, mk, T, base, steps=args.denoise_steps, scheduler="ddim", dist=dist)
     barrier()
     dt = time.time() - t0
-    prof, hip.PROFILE = hip.PROFILE, None
     if world > 1:
         import torch.distributed as td
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -296,7 +299,19 @@ def main():
             import torch.distributed as td
             td.destroy_process_group()
         return
-    # ---- roofline of the dominant kernel (HIP events recorded on the launch stream inside the timed region)
+    # ---- pricing pass (rank 0, after the timed region): ONE chunk of the same inputs on ONE stream, every launch bracketed by HIP events
+    prof, dt_priced = None, None
+    if not args.no_kernel_events:
+        one = chunk_plan(T, args.chunk, args.overlap)[shard_chunks(len(chunk_plan(T, args.chunk, args.overlap)), world)[rank][0]]
+        a, b = one[0] - base, one[1] - base
+        torch.cuda.synchronize()
+        hip.PROFILE = []
+        t1 = time.time()
+        model.forward_device(fr[a:b], pr[a:b], mk[a:b], args.chunk, 0, steps=args.denoise_steps, scheduler="ddim")
+        torch.cuda.synchronize()
+        dt_priced = time.time() - t1
+        prof, hip.PROFILE = hip.PROFILE, None
+    # ---- roofline of the dominant kernel (HIP events recorded on the launch stream in the pricing pass)
     roof = None
     kernels = {}
     if prof:
@@ -318,16 +333,16 @@ def main():
                 "traffic_source": "profiles/traffic_table.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; gfx950 x2 FETCH correction)" if traffic else None,
                 "launches": n,
                 "avg_launch_ms": round(tsec / n * 1e3, 4), "algorithmic_per_launch": (fl if mfma else by) / n,
-                "share_of_step_time": round(tsec / dt, 3)}
+                "share_of_step_time": round(tsec / dt_priced, 3)}
     # ---- the north star's own target: the fused temporal block (21 motion modules) against the MFMA roofline
     temporal = None
     t_motion = sum(v[1] for k, v in kernels.items() if k.startswith("motion:"))
     if t_motion > 0:
         from videovanish_amd import flops as _fl
         f8 = 2 ** (len(vcfg.block_out) - 1)
-        fl_motion = _fl.temporal_block_per_frame(H // f8, W // f8, args.chunk, ucfg) * args.chunk * args.denoise_steps * args.steps
+        fl_motion = _fl.temporal_block_per_frame(H // f8, W // f8, args.chunk, ucfg) * args.chunk * args.denoise_steps      # the priced pass is ONE chunk
         temporal = {"tflops": round(fl_motion / t_motion / 1e12, 1), "frac_of_mfma_peak": round(fl_motion / t_motion / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                    "seconds_per_step": round(t_motion / args.steps, 3), "share_of_step_time": round(t_motion / dt, 3),
+                    "seconds_per_step": round(t_motion, 3), "share_of_step_time": round(t_motion / dt_priced, 3),
                     "note": "all kernels launched by the motion modules (GroupNorm, LayerNorm+pos-emb, projections, temporal attention core, GEGLU FF)"}
     cpu = None
     if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
@@ -340,7 +355,12 @@ def main():
                                f"{args.arch} SD-1.5 UNet+BrushNet+motion / SD-VAE, random-init weights",
                    "frames_per_step": args.chunk, "credited_frames_per_step": stride, "chunks_per_rank": args.steps,
                    "parallelism": f"chunk-dp{world}", "model_build_s": round(t_build, 1), "precise_decoder": bool(args.precise_decoder),
+                   "concurrent_chunks": model.run.concurrent_chunks, "two_stream_denoiser": bool(__import__("videovanish_amd.unet", fromlist=["x"]).Denoiser.OVERLAP),
                    "parity": parity_summary()},
+        "kernel_pricing": None if not prof else {"how": "single-stream pass", "chunks": 1, "seconds": round(dt_priced, 3),
+                                                 "kernel_seconds": round(sum(v[1] for v in kernels.values()), 3),
+                                                 "note": "one chunk of the same resident inputs re-run after the timed region on ONE stream, every launch bracketed "
+                                                         "by HIP events on its launch stream; the timed region itself overlaps kernels of several streams"},
         "roofline": roof, "temporal_block": temporal, "cpu_baseline": cpu,
         "job_tflops": round(__import__("videovanish_amd.flops", fromlist=["x"]).per_output_frame(H, W, args.chunk, args.denoise_steps, ucfg, vcfg)
                             * args.chunk * args.steps * world / dt / 1e12, 1),

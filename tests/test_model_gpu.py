@@ -446,7 +446,7 @@ def test_cli_main_on_the_hip_path(gpu, tmp_path, monkeypatch):
 
 
 def test_two_stream_schedule_is_bit_identical(gpu):
-    """unet.Denoiser.OVERLAP (opt-in): the BrushNet backbone on a second HIP stream beside the UNet's down / mid path -- same kernels, same
+    """unet.Denoiser.OVERLAP (the default since round 4): the BrushNet backbone on a second HIP stream beside the UNet's down / mid path -- same kernels, same
     inputs, only the issue order across streams changes: the result is bit-identical to the one-stream schedule, over several steps."""
     from videovanish_amd.nn import Ctx
     from videovanish_amd.unet import Denoiser
@@ -467,6 +467,30 @@ def test_two_stream_schedule_is_bit_identical(gpu):
             torch.cuda.synchronize()
             outs.setdefault(flag, []).append(x.clone())
     finally:
-        Denoiser.OVERLAP = False
+        Denoiser.OVERLAP = True
+    assert Denoiser.OVERLAP is True
     assert torch.isfinite(outs[False][0]).all()
     assert all(torch.equal(o, outs[False][0]) for o in outs[True])
+
+
+def test_concurrent_chunks_are_bit_identical(gpu):
+    """RunConfig.concurrent_chunks: several chunks of one rank in flight on their own HIP streams (host threads pull chunks from a shared
+    counter).  Chunks are independent until blend time and their noise is seeded per chunk index, so the blended fp32 pixels equal the
+    one-chunk-at-a-time schedule bit for bit, whichever lane ran which chunk -- and the progress callback still counts every step once."""
+    from dataclasses import replace
+    from videovanish_amd.pipeline import DiffuEraserHIP, chunk_plan
+    T, H, W = 22, 32, 40
+    frames, masks, prior = _clip(T, H, W)
+    masks = [np.any(m > 0, axis=2).astype(np.uint8) * 255 for m in masks]
+    base = RunConfig(steps=2, chunk=8, overlap=2, seed=5, weight_seed=0, dtype="fp16", unet=TINY_UNET, vae=TINY_VAE)
+    outs = {}
+    for lanes in (1, 2, 3):
+        model = DiffuEraserHIP(replace(base, concurrent_chunks=lanes), "cuda:0")
+        ticks = []
+        pix, (lo, hi) = model.forward(frames, masks, prior, max_img_size=max(H, W), return_float=True, progress=lambda i, n: ticks.append((i, n)))
+        assert (lo, hi) == (0, T)
+        n_chunks = len(chunk_plan(T, 8, 2))
+        assert [i for i, _ in ticks] == list(range(1, n_chunks * 2 + 1)) and all(n == n_chunks * 2 for _, n in ticks)
+        outs[lanes] = pix
+    assert np.isfinite(outs[1]).all()
+    assert np.array_equal(outs[1], outs[2]) and np.array_equal(outs[1], outs[3])

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""A/B of the chunk schedules on ONE device, ONE model build: python tools/ab_schedule.py [chunks per config] [configs ...]
+config = "<lanes><o|s>": lanes = RunConfig.concurrent_chunks, o = BrushNet on a second stream (Denoiser.OVERLAP), s = one stream per chunk.
+Prints seconds per 32-frame 720p / 50-step chunk for every config, in the order given (repeat a config to see the box's drift)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from dataclasses import replace
+from videovanish_amd import unet
+from videovanish_amd.config import RunConfig
+from videovanish_amd.pipeline import DiffuEraserHIP, chunk_plan
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+configs = sys.argv[2:] or ["1s", "1o", "2o", "3o", "2s", "1s"]
+steps = int(os.environ.get("VV_AB_DENOISE_STEPS", "50"))
+H, W, chunk, overlap = 720, 1280, 32, 8
+run = RunConfig(steps=steps, chunk=chunk, overlap=overlap, seed=42, dtype="fp16")
+model = DiffuEraserHIP(run, "cuda:0")
+dev = model.ctx.device
+T = (chunk - overlap) * K + overlap
+assert len(chunk_plan(T, chunk, overlap)) == K
+fr, mk, pr = bench.synth_clip(T, H, W)
+fr, mk, pr = torch.from_numpy(fr).to(dev), torch.from_numpy(mk).to(dev), torch.from_numpy(pr).to(dev)
+model.forward_device(fr[:chunk], pr[:chunk], mk[:chunk], chunk, 0, steps=min(steps, 4), scheduler="ddim")      # warm-up
+torch.cuda.synchronize()
+ref = None
+for c in configs:
+    lanes, mode = int(c[:-1]), c[-1]
+    unet.Denoiser.OVERLAP = mode == "o"
+    model.run = replace(run, concurrent_chunks=lanes)
+    torch.cuda.synchronize(); t0 = time.time()
+    out, _ = model.forward_device(fr, pr, mk, T, 0, steps=steps, scheduler="ddim")
+    torch.cuda.synchronize(); dt = time.time() - t0
+    same = "" if ref is None else f" identical={bool(torch.equal(out, ref))}"
+    ref = out if ref is None else ref
+    print(f"{c}: {dt / K:8.3f} s/chunk  {(chunk - overlap) * K / dt:.4f} frames/s  ({K} chunks){same}", flush=True)

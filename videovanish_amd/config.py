@@ -57,5 +57,9 @@ class RunConfig:
     # "reference" = the third-party pipeline's own scheme (22-frame windows shifted on odd steps, value/count averaging, key-frame
     # pre-inference) -- single GPU only
     windowing: str = "chunks"
+    # chunks of one rank that are in flight at once, each on its own HIP stream (pipeline.forward_device): the memory-bound kernels of one
+    # chunk (GroupNorm, LayerNorm, the fp32-trunk GEMMs) run beside the MFMA-bound kernels of the other and kernel tails overlap.  Chunks are
+    # independent until blend time, so the result is bit-identical for every value (tests/test_model_gpu.py); the live set is ~10 GB per chunk
+    concurrent_chunks: int = 2
     unet: UNetConfig = field(default_factory=UNetConfig)
     vae: VAEConfig = field(default_factory=VAEConfig)

@@ -389,6 +389,8 @@ class MotionModule:
         self.pe = pe_table          # [max_seq, C] fp32 on device
 
     def __call__(self, x, F, H, W, res1=None, out_dtype=torch.float32):
+        if hip.PROFILE is None:          # (the tag is process-global state: only touched in bench.py's one-thread pricing pass)
+            return self._run(x, F, H, W, res1, out_dtype)
         prev, hip.PROFILE_TAG = hip.PROFILE_TAG, "motion:"
         try:
             return self._run(x, F, H, W, res1, out_dtype)

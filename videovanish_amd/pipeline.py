@@ -442,6 +442,51 @@ class DiffuEraserHIP:
         out = hip.blur_compose(pix, fr_orig, mk_orig, self.taps)
         return list(out.cpu().numpy())
 
+    def _run_chunks_concurrently(self, mine, lanes, run_chunk, pending, progress, nst):
+        """`lanes` host threads, each with its own HIP stream, pull this rank's chunks from a shared counter (RunConfig.concurrent_chunks).
+        Every chunk is computed by the same kernels on the same inputs as in the one-stream schedule (noise is seeded per chunk index),
+        so which lane ran it does not change a bit of the result.  The launching thread's stream waits for every lane at the end."""
+        import threading
+        dev = self.ctx.device
+        main = torch.cuda.current_stream()
+        pool = self.__dict__.setdefault("_lane_streams", [])
+        while len(pool) < lanes:
+            pool.append(torch.cuda.Stream(device=dev))
+        lock, nxt, done, errors = threading.Lock(), [0], [0], []
+        n_my = len(mine)
+
+        def step_done(i, n):
+            with lock:
+                done[0] += 1
+                progress(done[0], n_my * n)
+
+        def worker(stream):
+            try:
+                torch.cuda.set_device(dev)             # a new host thread starts on device 0: one process per GPU sets LOCAL_RANK's device
+                stream.wait_stream(main)               # the inputs were produced on the launching stream
+                with torch.cuda.stream(stream):
+                    while not errors:
+                        with lock:
+                            k = nxt[0]
+                            nxt[0] += 1
+                        if k >= n_my:
+                            break
+                        out = run_chunk(k, mine[k], step_done if progress is not None else None)
+                        out.record_stream(main)        # allocated on the lane's stream, consumed (blend / send) on the launching one
+                        pending[mine[k]] = out
+            except BaseException as exc:               # re-raised on the launching thread
+                errors.append(exc)
+
+        threads = [threading.Thread(target=worker, args=(pool[i],), name=f"vv-chunk-lane-{i}") for i in range(lanes)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for i in range(lanes):
+            main.wait_stream(pool[i])
+        if errors:
+            raise errors[0]
+
     def forward_device(self, fr, pr, mk, T, base, steps=None, scheduler="ddim", progress=None, dist=None, return_float=False, timings=None):
         """Device-resident core.  fr/pr: u8 [n,H,W,3], mk: u8 [n,H,W] hold frames [base, base+n) of a T-frame video at
         the inference size: exactly the frames covered by this rank's chunks.  Returns (u8 [hi-lo,H,W,3] device tensor of
@@ -457,19 +502,29 @@ class DiffuEraserHIP:
         H, W = (fr.shape[1], fr.shape[2]) if fr is not None else (0, 0)
         pending = {}       # chunk index -> decoded fp32 [F,H,W,3], kept until blended / sent
         n_my = len(mine)
-        for k, ci in enumerate(mine):
+        nst = steps or run.steps
+
+        def run_chunk(k, ci, cb):
             s, e = plan[ci]
             noise = chunk_noise(run.seed, ci, (e - s, 4, H // f, W // f)).permute(0, 2, 3, 1).contiguous().to(dev)
-            cb = None
-            if progress is not None:
-                cb = lambda i, n, k=k: progress(k * n + i, n_my * n)
             tcd_noise = None
             if scheduler == "tcd":      # TCD re-noising between steps: explicit, seeded per (chunk, step) like the initial noise
-                nst = steps or run.steps
                 tcd_noise = [chunk_noise(run.seed + 104729 * (i + 1), ci, (e - s, 4, H // f, W // f)).permute(0, 2, 3, 1).contiguous().to(dev)
                              for i in range(nst - 1)]
-            pending[ci] = self.denoise_chunk(fr[s - base:e - base], pr[s - base:e - base], mk[s - base:e - base], noise, steps=steps,
-                                             scheduler=scheduler, tcd_noise=tcd_noise, progress=cb)
+            return self.denoise_chunk(fr[s - base:e - base], pr[s - base:e - base], mk[s - base:e - base], noise, steps=steps,
+                                      scheduler=scheduler, tcd_noise=tcd_noise, progress=cb)
+
+        lanes = max(1, min(int(run.concurrent_chunks), n_my))
+        if hip.PROFILE is not None:
+            lanes = 1              # per-kernel HIP events only mean something on one stream
+        if lanes == 1:
+            for k, ci in enumerate(mine):
+                cb = None
+                if progress is not None:
+                    cb = lambda i, n, k=k: progress(k * n + i, n_my * n)
+                pending[ci] = run_chunk(k, ci, cb)
+        else:
+            self._run_chunks_concurrently(mine, lanes, run_chunk, pending, progress, nst)
         if timings is not None:
             import time
             torch.cuda.synchronize()

@@ -208,10 +208,19 @@ class Denoiser:
         self.unet = UNetMotion(ctx, cfg, text_h16)
         self.brush = BrushNet(ctx, cfg, text_h16)
 
-    # Two-stream schedule (opt-in, measured in profiles/r3_two_stream_ab.txt): the BrushNet backbone does not depend on the UNet's down / mid path
-    # (only its zero convolutions add the UNet skips), so the two can share the GPU.  OFF by default: kernels of two streams overlap, which makes
-    # the per-kernel HIP-event durations the bench reports (roofline of the dominant kernel) meaningless.
-    OVERLAP = False
+    # Two-stream schedule (default since round 4; measured in profiles/r3_two_stream_ab.txt: +2.4 %, bit-identical): the BrushNet backbone does
+    # not depend on the UNet's down / mid path (only its zero convolutions add the UNet skips), so the two share the GPU.  Kernels of two streams
+    # overlap, so per-kernel HIP-event durations are only meaningful on ONE stream: while hip.PROFILE is set (bench.py's pricing pass) the
+    # schedule falls back to one stream.
+    OVERLAP = True
+
+    def _side_stream(self, main):
+        """one side stream per launch stream (chunks of one rank may run on several streams at once: pipeline.forward_device)"""
+        sides = self.__dict__.setdefault("_sides", {})
+        key = main.cuda_stream
+        if key not in sides:
+            sides[key] = torch.cuda.Stream(device=self.ctx.device)
+        return sides[key]
 
     def __call__(self, lat, cond, mask2d, t, F, h, w, H, W):
         """lat, cond: fp32 [F,h,w,4] device; mask2d: u8 [F,H,W]."""
@@ -219,17 +228,16 @@ class Denoiser:
         lat8 = hip.pad_channels(ctx.dt, lat, 8).view(F * h * w, 8)
         x16 = hip.brushnet_input(ctx.dt, lat, cond, mask2d, H, W).view(F * h * w, 16)
         pre = None
-        if Denoiser.OVERLAP:
+        if Denoiser.OVERLAP and hip.PROFILE is None:
             main = torch.cuda.current_stream()
-            if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream(device=lat.device)
-            self._side.wait_stream(main)                       # x16 / t are ready
-            with torch.cuda.stream(self._side):
+            side = self._side_stream(main)
+            side.wait_stream(main)                             # x16 / t are ready
+            with torch.cuda.stream(side):
                 pre = self.brush.backbone(x16, t, F, h, w)
-            x16.record_stream(self._side)
+            x16.record_stream(side)
         st, skips, mid, (Hm, Wm) = self.unet.down_mid(lat8, t, F, h, w)
         if pre is not None:
-            main.wait_stream(self._side)
+            main.wait_stream(side)
             for grp in (pre[0], pre[2]):                        # produced on the side stream, consumed on the main one
                 for ten, _, _ in grp:
                     ten.record_stream(main)
