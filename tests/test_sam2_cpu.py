@@ -238,3 +238,58 @@ def test_cli_main_with_a_recording_predictor(tmp_path, monkeypatch):
     with pytest.raises(SystemExit):
         monkeypatch.setattr(sys, "argv", ["sam2_masker.py", "--color_video", color])             # --annotations is required (reference :187)
         sam2_masker.main()
+
+
+# ---- the oracle against an independent published implementation (transformers.models.sam2_video; vectors minted in the build container
+#      by tests/golden/make_sam2_hf_fixtures.py with the same name-seeded weights loaded into the HF model through an explicit name map)
+PIN_SAM2 = Sam2Config(image_size=128, embed_dim=32, num_heads=1, stages=(1, 2, 3, 1), global_att_blocks=(4,),
+                      window_pos_embed_bkg_spatial_size=(3, 3), window_spec=(8, 4, 4, 2), d_model=128, mem_dim=64, mem_attn_layers=2,
+                      mem_attn_ff=256, dec_heads=2, dec_mlp=256, mask_in_chans=8)
+
+
+def _close(got, want, tol=2e-5, what=""):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+    assert err <= tol, f"{what}: {err:.3e} > {tol:.1e}"
+    return err
+
+
+def test_oracle_matches_transformers_sam2_vectors():
+    """oracle/sam2_ref.py == transformers' Sam2VideoModel on the same weights and inputs, stage by stage, fp32 (<= 2e-5 of the output range):
+    Hiera trunk + FPN neck + conv_s0/s1, prompt encoder + two-way mask decoder (click / box + negative click / click + mask prompt; the
+    multimask choice and the stability rule included), memory encoder (binarised and sigmoid masks, occluded object), and a tracked frame
+    (memory selection, temporal encodings, object-pointer tokens, RoPE memory attention)."""
+    from oracle.sam2_ref import OracleSam2
+    v = np.load(os.path.join(GOLD, "sam2_hf_vectors.npz"))
+    cfg = PIN_SAM2
+    O = OracleSam2(cfg, Sam2Weights(cfg, int(v["seed"])))
+    fs, S = cfg.feat_size, cfg.image_size
+    with torch.no_grad():
+        feats = O.encode_image(v["frame"])
+        errs = {"enc_s0": _close(feats["fpn"][0], v["enc_s0"], what="s0"), "enc_s1": _close(feats["fpn"][1], v["enc_s1"], what="s1"),
+                "enc_top": _close(feats["fpn"][2], v["enc_top"], what="top"), "enc_pos": _close(feats["pos"], v["enc_pos"], what="pos")}
+        pix = feats["fpn"][2] + O.w("no_mem_embed").view(1, -1, 1, 1)
+        for k in ("click", "box", "reprompt"):
+            pts = {"point_coords": torch.tensor(v[f"sam_{k}_points"])[None], "point_labels": torch.tensor(v[f"sam_{k}_labels"])[None]}
+            mask_in = torch.tensor(v[f"sam_{k}_mask_in"]).reshape(1, 1, 4 * fs, 4 * fs) if f"sam_{k}_mask_in" in v else None
+            multi = bool(v[f"sam_{k}_multimask"])
+            assert O.use_multimask(True, pts) == multi
+            masks, ptr, obj = O.sam_heads(pix, feats["fpn"][:2], pts, mask_in, multi)
+            errs[f"sam_{k}_masks"] = _close(masks.reshape(-1), v[f"sam_{k}_masks"].reshape(-1), what=f"{k} masks")
+            errs[f"sam_{k}_ptr"] = _close(ptr.reshape(-1), v[f"sam_{k}_ptr"].reshape(-1), what=f"{k} pointer")
+            errs[f"sam_{k}_obj"] = _close(obj.reshape(-1), v[f"sam_{k}_obj"].reshape(-1), what=f"{k} object score")
+        low = torch.tensor(v["mem_low_res_in"])
+        for tag, from_pts in (("pts", True), ("trk", False)):
+            obj = torch.tensor(v[f"mem_{tag}_obj"])
+            f, pe = O.encode_memory_from_low_res(feats, low, obj, from_pts)
+            errs[f"mem_{tag}_pos"] = _close(pe, v[f"mem_{tag}_pos"], what="memory pos")
+            occl = (1.0 - (obj > 0).float())[..., None, None] * O.w("no_obj_embed_spatial")[..., None, None]
+            errs[f"mem_{tag}_feat"] = _close(f - occl, v[f"mem_{tag}_feat"], what="memory features")
+            _close(f, v[f"mem_{tag}_wrapped_bf16"], tol=2.0 ** -8, what="memory features as transformers stores them (bfloat16)")
+        T, cur = int(v["trk_num_frames"]), int(v["trk_frame_idx"])
+        entry = lambda t: {"maskmem_features": torch.tensor(v["trk_mem"][t]), "maskmem_pos_enc": torch.tensor(v["trk_mem_pos"][t]),
+                           "obj_ptr": torch.tensor(v["trk_ptr"][t])}
+        od = {"cond_frame_outputs": {0: entry(0)}, "non_cond_frame_outputs": {t: entry(t) for t in range(1, cur)}}
+        errs["tracked_frame"] = _close(O._memory_conditioned(cur, False, feats, od, T, False), v["trk_out"], what="memory-conditioned features")
+    print({k: f"{e:.1e}" for k, e in errs.items()})

@@ -242,7 +242,7 @@ def test_image_encoder_and_prompted_frame(name):
     nhwc = lambda t: t[0].permute(1, 2, 0).reshape(-1, t.shape[1])
     e_top, e_s1, e_s0 = _rel(fh["top"], nhwc(fo["fpn"][2])), _rel(fh["s1"], nhwc(fo["fpn"][1])), _rel(fh["s0"], nhwc(fo["fpn"][0]))
     print(f"sam2_image_encoder[{name}]: rel max-abs top {e_top:.2e} s1 {e_s1:.2e} s0 {e_s0:.2e}")
-    assert max(e_top, e_s1, e_s0) < 6e-3
+    assert max(e_top, e_s1, e_s0) < 2.1e-3                  # <= 2x the measured 1.03e-3 (profiles/r3_sam2_parity_gpu.txt)
     # a prompted (initial conditioning) frame: clicks -> multimask path, a box -> single-mask path with the stability test
     empty = lambda: {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
     lo = 4 * fs
@@ -262,21 +262,21 @@ def test_image_encoder_and_prompted_frame(name):
             iou = ora.last_decoder["iou"][0]
             edge = abs(ora.last_decoder.get("stability", 0.0) - cfg.stability_thresh) < 5e-3 or float(iou[1:].topk(2).values.diff().abs()) < 5e-3
             note = f" [oracle on a decision edge: stability {ora.last_decoder.get('stability', float('nan')):.4f}, iou {[round(float(v), 4) for v in iou]}; HIP chose candidate {int(np.argmin(errs))}]"
-            assert edge and min(errs) < 1.5e-2, (errs, ora.last_decoder.get("stability"), iou)
+            assert edge and min(errs) < 3e-3, (errs, ora.last_decoder.get("stability"), iou)
             mo = cand[int(np.argmin(errs))]
             e_m = min(errs)
         flips = float(((mo > 0) != (mh > 0)).float().mean())
         print(f"sam2_prompted_frame[{name},{len(labs)} pts]: logits rel {e_m:.2e} sign flips {flips:.2e} obj_ptr rel {e_p:.2e} "
               f"object score {float(o['object_score_logits']):.3f} / {float(h['object_score_logits'].cpu()):.3f}{note}")
-        assert e_m < 1.5e-2 and flips < 5e-3 and e_p < 1.5e-2
-        assert abs(float(o["object_score_logits"]) - float(h["object_score_logits"].cpu())) < 2e-2 * max(1.0, abs(float(o["object_score_logits"])))
+        assert e_m < 2.8e-3 and flips < 4e-3 and e_p < 3.4e-3      # <= 2x the measured 1.40e-3 / 1.95e-3 / 1.68e-3
+        assert abs(float(o["object_score_logits"]) - float(h["object_score_logits"].cpu())) < 2e-3 * max(1.0, abs(float(o["object_score_logits"])))
         # re-prompt with the previous logits as the mask prompt (the prompt encoder's mask downscaling path)
         o2 = ora.track_step(0, True, fo, pi, empty(), 1, run_mem_encoder=False, prev_sam_mask_logits=ora.clamp_prev_logits(o["pred_masks"]))
         h2 = hipm.track_step(0, True, fh, pi, empty(), 1, run_mem_encoder=False,
                              prev_sam_mask_logits=hipm.clamp_prev_logits(o["pred_masks"].reshape(-1).contiguous().to(_dev())))
         e2 = _rel(h2["pred_masks"].cpu().reshape(-1), o2["pred_masks"].reshape(-1))
         print(f"sam2_mask_prompt[{name}]: logits rel {e2:.2e}")
-        assert e2 < 1.5e-2 and not torch.equal(o2["pred_masks"], o["pred_masks"])
+        assert e2 < 4.2e-3 and not torch.equal(o2["pred_masks"], o["pred_masks"])
     # memory encoder on IDENTICAL inputs (the oracle's logits): binarised (from clicks) and sigmoid (tracked frame) forms; an absent object
     for from_pts, score in ((True, 1.0), (False, 1.0), (False, -1.0)):
         fm_o, _ = ora.encode_memory_from_low_res(fo, o["pred_masks"], torch.tensor([[score]]), from_pts)
@@ -289,7 +289,7 @@ def test_image_encoder_and_prompted_frame(name):
             type(hipm).FUSED_MASKDOWN = True
         e_l = _rel(fm_l, nhwc(fm_o))
         print(f"sam2_memory_encoder[{name},binarised={from_pts},score={score}]: rel {e:.2e} (fused mask path), {e_l:.2e} (layer by layer)")
-        assert e < 6e-3 and e_l < 6e-3
+        assert e < 2.5e-3 and e_l < 2.5e-3
     # one tracked frame on IDENTICAL memories (the oracle's, re-laid-out for the HIP model): memory attention + RoPE + object pointers
     f1 = _frames(2, S, S + 16)[1]
     fo1, fh1 = ora.encode_image(f1), hipm.encode_image(f1)
@@ -306,7 +306,7 @@ def test_image_encoder_and_prompted_frame(name):
     mo, mh = o["pred_masks"].reshape(-1), h["pred_masks"].cpu().reshape(-1)
     e_m, flips = _rel(mh, mo), float(((mo > 0) != (mh > 0)).float().mean())
     print(f"sam2_tracked_frame[{name}]: logits rel {e_m:.2e} sign flips {flips:.2e} obj_ptr rel {_rel(h['obj_ptr'], o['obj_ptr']):.2e}")
-    assert float(mo.min()) > -1000 and e_m < 1.5e-2 and flips < 5e-3
+    assert float(mo.min()) > -1000 and e_m < 4.3e-3 and flips < 2e-3      # measured 2.12e-3 / 9.8e-4
 
 
 @pytest.mark.parametrize("name", ["tiny", "small"])
@@ -344,7 +344,7 @@ def test_tracking_through_the_predictor(name):
           f"least foreground fraction {painted:.2f}")
     # a flipped pixel of a binarised click mask changes that frame's memory for good: the recurrence is compared statistically, the arithmetic of
     # every stage is pinned on identical inputs in test_image_encoder_and_prompted_frame
-    assert worst < 5e-2 and flips < 2e-2
+    assert worst < 5e-2 and flips < 1.1e-2                     # measured: rel RMS 2.76e-2, 5.6e-3 of the pixels
 
 
 def test_drop_in_masker_on_the_hip_path():
@@ -371,7 +371,7 @@ def test_drop_in_masker_on_the_hip_path():
     differ = max(float((g != w).any(axis=2).mean()) for g, w in zip(got, want))
     painted = min(float(w.any(axis=2).mean()) for w in want[1:])
     print(f"sam2_drop_in[tiny]: worst fraction of differing pixels {differ:.2e}, least painted fraction {painted:.2f}")
-    assert differ < 1e-2 and painted > 0.02
+    assert differ < 2.3e-3 and painted > 0.02                  # measured 1.11e-3
     colours = {tuple(c) for w in got[1:] for c in np.unique(w.reshape(-1, 3), axis=0)}
     assert colours <= {(0, 0, 0)} | {sam2_masker.color_for_obj(i) for i in (1, 2, 3)}
 
@@ -390,7 +390,7 @@ def test_full_size_hiera_l():
     nhwc = lambda t: t[0].permute(1, 2, 0).reshape(-1, t.shape[1])
     e_top, e_s1, e_s0 = _rel(fh["top"], nhwc(fo["fpn"][2])), _rel(fh["s1"], nhwc(fo["fpn"][1])), _rel(fh["s0"], nhwc(fo["fpn"][0]))
     print(f"sam2_image_encoder[hiera_l,1024]: rel max-abs top {e_top:.2e} s1 {e_s1:.2e} s0 {e_s0:.2e} ({time.time() - t0:.0f} s)")
-    assert max(e_top, e_s1, e_s0) < 1e-2
+    assert max(e_top, e_s1, e_s0) < 2.2e-3                  # measured 1.06e-3
     empty = lambda: {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
     pi = {"point_coords": torch.tensor([[[0.4 * S, 0.5 * S]]], dtype=torch.float32), "point_labels": torch.tensor([[1]], dtype=torch.int32)}
     o = ora.track_step(0, True, fo, pi, empty(), 4, run_mem_encoder=True)
@@ -401,7 +401,7 @@ def test_full_size_hiera_l():
     fm_h, _ = hipm.encode_memory_from_low_res(fh, o["pred_masks"].reshape(-1).contiguous().to(_dev()), o["object_score_logits"].reshape(-1).to(_dev()), True)
     e_mem = _rel(fm_h, nhwc(o["maskmem_features"]))
     print(f"sam2_prompted_frame[hiera_l]: logits rel {e_m:.2e} sign flips {flips:.2e} obj_ptr rel {_rel(h['obj_ptr'], o['obj_ptr']):.2e}; memory encoder rel {e_mem:.2e}")
-    assert e_m < 2e-2 and flips < 5e-3 and e_mem < 1e-2
+    assert e_m < 4.2e-3 and flips < 1.4e-3 and e_mem < 2.8e-3      # measured 2.08e-3 / 6.7e-4 / 1.37e-3
     od_o, od_h = empty(), empty()
     od_o["cond_frame_outputs"][0] = o
     od_h["cond_frame_outputs"][0] = {"maskmem_features": nhwc(o["maskmem_features"]).contiguous().to(_dev()), "maskmem_pos_enc": None,
@@ -412,7 +412,7 @@ def test_full_size_hiera_l():
     mo, mh = o1["pred_masks"].reshape(-1), h1["pred_masks"].cpu().reshape(-1)
     e_m, flips = _rel(mh, mo), float(((mo > 0) != (mh > 0)).float().mean())
     print(f"sam2_tracked_frame[hiera_l]: logits rel {e_m:.2e} sign flips {flips:.2e} ({time.time() - t0:.0f} s)")
-    assert e_m < 2e-2 and flips < 5e-3
+    assert e_m < 4.1e-3 and flips < 1.1e-3                     # measured 2.03e-3 / 5.2e-4
 
 
 def test_batched_image_encoding_equals_frame_by_frame():
