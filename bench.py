@@ -355,7 +355,8 @@ def main():
                                f"{args.arch} SD-1.5 UNet+BrushNet+motion / SD-VAE, random-init weights",
                    "frames_per_step": args.chunk, "credited_frames_per_step": stride, "chunks_per_rank": args.steps,
                    "parallelism": f"chunk-dp{world}", "model_build_s": round(t_build, 1), "precise_decoder": bool(args.precise_decoder),
-                   "concurrent_chunks": model.run.concurrent_chunks, "two_stream_denoiser": bool(__import__("videovanish_amd.unet", fromlist=["x"]).Denoiser.OVERLAP),
+                   "concurrent_chunks": min(model.run.concurrent_chunks, args.steps),
+                   "streams_per_chunk": 2 if (min(model.run.concurrent_chunks, args.steps) == 1 and __import__("videovanish_amd.unet", fromlist=["x"]).Denoiser.OVERLAP) else 1,
                    "parity": parity_summary()},
         "kernel_pricing": None if not prof else {"how": "single-stream pass", "chunks": 1, "seconds": round(dt_priced, 3),
                                                  "kernel_seconds": round(sum(v[1] for v in kernels.values()), 3),

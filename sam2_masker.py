@@ -19,10 +19,19 @@ SAM2_MODEL_CFG = "configs/sam2.1/sam2.1_hiera_l.yaml"
 predictor = None
 
 
-def configure(predictor_=None, checkpoint=None, cfg=None, seed=None, dtype="fp16", device=None):
-    """predictor_: a ready Sam2VideoPredictor.  Otherwise one is built on the HIP path: from `checkpoint` (the published .pt), or -- only when
-    `seed` is given explicitly -- from seeded synthetic weights of configuration `cfg` (tests / benchmarks without network access)."""
+def configure(predictor_=None, checkpoint=None, cfg=None, seed=None, dtype=None, device=None, **kw):
+    """predictor_ (or the keyword `predictor=`): a ready Sam2VideoPredictor.  Otherwise one is built on the HIP path: from `checkpoint` (the
+    published .pt), or -- only when `seed` is given explicitly -- from seeded synthetic weights of configuration `cfg` (tests / benchmarks
+    without network access).  dtype: MFMA operand type; default "bf16" for a real checkpoint -- the reference runs SAM 2 under bfloat16
+    autocast (reference :76) and published-weight activations are not range-checked for fp16 here -- and "fp16" (11 significant bits, what the
+    parity tests measure) for synthetic weights."""
     global predictor
+    if "predictor" in kw:
+        predictor_ = kw.pop("predictor")
+    if kw:
+        raise TypeError(f"configure() got unexpected keyword arguments {sorted(kw)}")
+    if dtype is None:
+        dtype = "bf16" if checkpoint is not None else "fp16"
     if predictor_ is not None or (checkpoint is None and seed is None):
         predictor = predictor_
         return
@@ -75,6 +84,8 @@ def run_sam2_on_frames(frames_rgb, annotations, device=None, prog=None):
         predictor = build_sam2_video_predictor(SAM2_MODEL_CFG, os.environ.get("VV_SAM2_CHECKPOINT", SAM2_CHECKPOINT), device=device)
 
     if prog is not None: prog(25, "Loading frames in to sam2")
+    if hasattr(predictor, "trim_memory"):
+        predictor.trim_memory = True            # one forward pass after the prompts: outputs no later frame can select are freed as tracking advances
     inference_state = predictor.init_state(video_path=frames_rgb)
 
     # prompts in the order the reference issues them (reference :96-141): per keyframe (sorted by frame), the clicks of each object in one

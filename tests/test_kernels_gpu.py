@@ -492,7 +492,7 @@ def test_ycbcr_to_rgb_gpu_equals_host(gpu, hs, vs, tmp_path):
         host = FIO.ycbcr_to_rgb(y, cb, cr, hs, vs, full, device=False)
         dev = hip.ycbcr_to_rgb(torch.from_numpy(y).to(gpu), torch.from_numpy(cb).to(gpu), torch.from_numpy(cr).to(gpu), hs, vs, full).cpu().numpy()
         assert np.array_equal(dev, host)
-        assert np.array_equal(FIO.ycbcr_to_rgb(y, cb, cr, hs, vs, full), host)          # default: the GPU path of the loader
+        assert np.array_equal(FIO.ycbcr_to_rgb(y, cb, cr, hs, vs, full, device=True), host)          # the loader's explicit GPU path
     if (hs, vs) == (1, 1):
         p = str(tmp_path / "clip.y4m")
         with open(p, "wb") as f:

@@ -494,3 +494,31 @@ def test_concurrent_chunks_are_bit_identical(gpu):
         outs[lanes] = pix
     assert np.isfinite(outs[1]).all()
     assert np.array_equal(outs[1], outs[2]) and np.array_equal(outs[1], outs[3])
+
+
+def test_hoisted_time_embedding_is_bit_identical(gpu):
+    """Denoiser.prepare(ts): the time-embedding linears and every ResBlock's time_emb_proj run once for all timesteps as S-row GEMMs before the
+    denoise loop; a row of the batched GEMM is the one-row launch bit for bit, so the noise prediction does not change (both schedules)."""
+    from videovanish_amd.nn import Ctx
+    from videovanish_amd.unet import Denoiser
+    ucfg = SMALL_UNET
+    Fr, h, w, f = 3, 16, 24, 8
+    g = torch.Generator().manual_seed(9)
+    lat, cond = torch.randn(Fr, h, w, 4, generator=g).to(gpu), torch.randn(Fr, h, w, 4, generator=g).to(gpu)
+    mask = ((torch.rand(Fr, h * f, w * f, generator=g) > 0.6).to(torch.uint8) * 255).to(gpu)
+    ctx = Ctx("cuda:0", "fp16", 0)
+    text = ctx.src.normal("text_states", (1, ucfg.text_len, ucfg.cross_dim))
+    ts = [961, 481, 1]
+    plain = Denoiser(ctx, ucfg, text)
+    ref = [plain(lat, cond, mask, t, Fr, h, w, h * f, w * f).clone() for t in ts]
+    for overlap in (True, False):
+        Denoiser.OVERLAP = overlap
+        try:
+            den = Denoiser(ctx, ucfg, text)
+            den.prepare(ts)
+            assert len(den.unet._temb_tables) == len(ts) and len(den.brush._temb_tables) == len(ts)
+            got = [den(lat, cond, mask, t, Fr, h, w, h * f, w * f).clone() for t in ts]
+            torch.cuda.synchronize()
+        finally:
+            Denoiser.OVERLAP = True
+        assert all(torch.equal(a, b) for a, b in zip(got, ref))

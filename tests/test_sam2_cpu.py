@@ -293,3 +293,23 @@ def test_oracle_matches_transformers_sam2_vectors():
         od = {"cond_frame_outputs": {0: entry(0)}, "non_cond_frame_outputs": {t: entry(t) for t in range(1, cur)}}
         errs["tracked_frame"] = _close(O._memory_conditioned(cur, False, feats, od, T, False), v["trk_out"], what="memory-conditioned features")
     print({k: f"{e:.1e}" for k, e in errs.items()})
+
+
+def test_trim_memory_keeps_the_forward_pass_identical():
+    """Sam2VideoPredictor(trim_memory=True) (what the one-shot masking step uses): outputs that no later frame of the pass can select are
+    dropped as tracking advances -- the yielded logits equal the keep-everything predictor's bit for bit and the per-object store stays
+    bounded by max(num_maskmem, max_obj_ptrs_in_encoder) + 1 entries instead of growing with the clip."""
+    from dataclasses import replace
+    from oracle.sam2_ref import OracleSam2
+    cfg = replace(TINY_SAM2, max_obj_ptrs_in_encoder=4)          # window of 7 frames (num_maskmem) on a 14-frame clip
+    rng = np.random.default_rng(5)
+    frames = [rng.integers(0, 256, (64, 64, 3), dtype=np.uint8) for _ in range(14)]
+    outs, sizes = {}, {}
+    for trim in (False, True):
+        p = Sam2VideoPredictor(OracleSam2(cfg, seed=4), trim_memory=trim)
+        st = p.init_state(video_path=frames)
+        p.add_new_points_or_box(st, 1, 3, points=np.array([[30.0, 34.0]], dtype=np.float32), labels=np.array([1], dtype=np.int32))
+        outs[trim] = [m for _, _, m in p.propagate_in_video(st)]
+        sizes[trim] = len(st["output_dict_per_obj"][0]["non_cond_frame_outputs"])
+    assert len(outs[True]) == len(outs[False]) == 13 and all(torch.equal(a, b) for a, b in zip(outs[True], outs[False]))
+    assert sizes[False] == 12 and sizes[True] <= 8

@@ -27,7 +27,8 @@ torch.cuda.synchronize()
 ref = None
 for c in configs:
     lanes, mode = int(c[:-1]), c[-1]
-    unet.Denoiser.OVERLAP = mode == "o"
+    unet.Denoiser.OVERLAP = mode == "o"      # (with lanes > 1 the product keeps one stream per chunk whatever this says: profiles/r4_schedule_ab_*.txt
+                                             #  were measured before that rule went in)
     model.run = replace(run, concurrent_chunks=lanes)
     torch.cuda.synchronize(); t0 = time.time()
     out, _ = model.forward_device(fr, pr, mk, T, 0, steps=steps, scheduler="ddim")

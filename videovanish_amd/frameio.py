@@ -91,25 +91,21 @@ def ffv1_decode_planes(config, packet, W, H, info=None):
 
 
 def ycbcr_to_rgb(y, cb, cr, hshift, vshift, full_range=False, device=None):
-    """planar YCbCr ([T,] H, W + subsampled chroma) -> RGB uint8 ([T,] H, W, 3).  On a machine with a visible GPU the conversion runs there
-    (vv_ycbcr_to_rgb: the frames are headed for the device anyway); otherwise on the host (vvio_ycbcr_to_rgb) -- the two are the same integer
-    arithmetic, bit for bit (tests/test_frameio_cpu.py, tests/test_kernels_gpu.py).  device=False forces the host path."""
+    """planar YCbCr ([T,] H, W + subsampled chroma) -> RGB uint8 ([T,] H, W, 3).  Default (device None / False): the host routine
+    (vvio_ycbcr_to_rgb) -- file I/O never creates a HIP context by itself (under torchrun every rank loads the clip BEFORE its device is set,
+    and a per-frame host -> device -> host round trip is slower than the host loop).  device = True / "cuda:N" / a torch.device: the GPU kernel
+    (vv_ycbcr_to_rgb) for callers that batch a whole clip and want it there anyway.  The two are the same integer arithmetic, bit for bit
+    (tests/test_frameio_cpu.py, tests/test_kernels_gpu.py)."""
     y, cb, cr = (np.ascontiguousarray(a, dtype=np.uint8) for a in (y, cb, cr))
     single = y.ndim == 2
     if single:
         y, cb, cr = y[None], cb[None], cr[None]
     T, H, W = y.shape
-    use_gpu = False
-    if device is not False:
-        try:
-            import torch
-            use_gpu = torch.cuda.is_available()
-        except ImportError:
-            use_gpu = False
+    use_gpu = device not in (None, False)
     if use_gpu:
         import torch
         from . import hip
-        dev = torch.device("cuda", torch.cuda.current_device()) if device in (None, True) else torch.device(device)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is True else torch.device(device)
         out = hip.ycbcr_to_rgb(torch.from_numpy(y).to(dev), torch.from_numpy(cb).to(dev), torch.from_numpy(cr).to(dev), hshift, vshift, full_range).cpu().numpy()
     else:
         out = np.empty((T, H, W, 3), np.uint8)

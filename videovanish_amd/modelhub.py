@@ -14,7 +14,6 @@ No network access: `root` mirrors the hub ids as directories (what `huggingface-
 [UNVERIFIED-3P]: the file names inside the third-party repositories are recalled from their public layouts; a missing file is reported with
 the path that was tried, a tensor that does not fit the architecture with its name and both shapes.
 """
-import contextlib
 import math
 import os
 
@@ -72,41 +71,22 @@ class _ShapeCtx:
         return t
 
 
-@contextlib.contextmanager
-def _shape_only_packing():
-    """The constructors pack weights for the MFMA kernels; on meta tensors that is replaced by identity functions for the duration."""
-    from . import nn as vnn
-    from . import packing
-    saved = {n: getattr(packing, n) for n in ("pack_matrix", "pack_conv", "geglu_interleave", "pack_motion_stream")}
-    call = vnn.Linear.__call__
-    packing.pack_matrix = lambda w, h16, geglu=False: w
-    packing.pack_conv = lambda w, h16, cin_pad=None: (w, w.shape[1] * w.shape[2] * w.shape[3])
-    packing.geglu_interleave = lambda w, b: (w, b)
-    packing.pack_motion_stream = lambda w, h16, heads=8: (w["proj_in.w"], w["proj_in.b"])
-    vnn.Linear.__call__ = lambda self, *a, **k: None       # CrossAttention projects the text K/V at build time
-    try:
-        yield
-    finally:
-        for n, f in saved.items():
-            setattr(packing, n, f)
-        vnn.Linear.__call__ = call
-
-
 def manifest(ucfg=None, vcfg=None, components=("unet", "brushnet", "vae")):
     """{internal parameter name: shape} of the denoiser / VAE the HIP host modules construct for these configs (CPU, meta tensors)."""
     from .config import UNetConfig, VAEConfig
     ucfg, vcfg = ucfg or UNetConfig(), vcfg or VAEConfig()
     ctx = _ShapeCtx()
-    with _shape_only_packing():
-        from .unet import BrushNet, UNetMotion
-        from .vae import VAE
-        text = torch.empty((ucfg.text_len, ucfg.cross_dim), device="meta")
-        if "unet" in components:
-            UNetMotion(ctx, ucfg, text)
-        if "brushnet" in components:
-            BrushNet(ctx, ucfg, text)
-        if "vae" in components:
-            VAE(ctx, vcfg)
+    # (the packers in packing.py and nn.Linear / nn.Conv recognise meta tensors themselves: no process-global state is patched, so a model
+    #  that another thread builds or runs meanwhile -- the GUI runs jobs on worker threads -- is not affected)
+    from .unet import BrushNet, UNetMotion
+    from .vae import VAE
+    text = torch.empty((ucfg.text_len, ucfg.cross_dim), device="meta")
+    if "unet" in components:
+        UNetMotion(ctx, ucfg, text)
+    if "brushnet" in components:
+        BrushNet(ctx, ucfg, text)
+    if "vae" in components:
+        VAE(ctx, vcfg)
     return dict(ctx.src.seen)
 
 

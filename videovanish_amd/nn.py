@@ -135,6 +135,8 @@ class Linear:
 
     def __call__(self, x, res0=None, res1=None, out_dtype=torch.float32, rows_per_frame=None, out=None, split=None):
         """split = (heads, head_dim, tokens_per_batch): head-major store of a fused QKV projection (hip.conv_gemm split_heads)."""
+        if x.device.type == "meta":          # shape-only construction (modelhub.manifest): CrossAttention projects the text K/V at build time
+            return None
         M = x.shape[0]
         kw = dict(split_heads=split[0], split_dim=split[1], split_tokens=split[2]) if split else {}
         if self.precise:
@@ -180,13 +182,23 @@ class ResBlock:
         self.conv2 = Conv(ctx, name + ".conv2", cout, cout, precise=precise)
         self.short = Conv(ctx, name + ".conv_shortcut", cin, cout, k=1, precise=precise) if cin != cout else None
 
+    def temb_bias(self, silu_temb):
+        """[S, temb_dim] -> [S, cout]: conv1 bias + time_emb_proj(silu(temb)), one row per timestep (rows are independent GEMM rows: the
+        row of a batch of timesteps equals the single-timestep launch bit for bit)."""
+        S = silu_temb.shape[0]
+        res = self.conv1.b.view(1, -1) if S == 1 else self.conv1.b.view(1, -1).repeat(S, 1)
+        return self.temb(silu_temb, res0=res)
+
     def __call__(self, x0, F, H, W, x1=None, silu_temb=None, res1=None, out_dtype=torch.float32):
         HW = H * W
         h = self.norm1(x0, F, HW, x1=x1, silu=True)
         b1 = None
         if self.temb is not None:
             # conv1 bias + time_emb_proj(silu(temb)) is the same vector for every frame -> fold into the bias
-            b1 = self.temb(silu_temb, res0=self.conv1.b.view(1, -1)).view(-1)
+            if isinstance(silu_temb, dict):      # hoisted out of the denoise loop (unet._Backbone.prepare_temb): this block's row for this timestep
+                b1 = silu_temb[id(self)]
+            else:
+                b1 = self.temb_bias(silu_temb).view(-1)
         h, _, _ = self.conv1(h, F, H, W, bias_override=b1)
         h = self.norm2(h, F, HW, silu=True)
         if self.short is not None:

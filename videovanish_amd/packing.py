@@ -21,6 +21,8 @@ def npad_for(N, geglu=False):
 def pack_matrix(w2d, h16, geglu=False):
     """[N][K] fp32 -> zero-padded [Npad][Kpad] h16 (Kpad % 64 == 0)."""
     N, K = w2d.shape
+    if w2d.device.type == "meta":          # shape-only construction (modelhub.manifest): nothing to pack
+        return w2d
     out = torch.zeros((npad_for(N, geglu), _round_up(K, 64)), dtype=h16)
     out[:N, :K] = w2d.to(h16)
     return out
@@ -31,6 +33,8 @@ def pack_conv(w, h16, cin_pad=None):
     the input channels (conv_in layers whose activations are stored with padded channels)."""
     cout, cin, kh, kw = w.shape
     cp = cin if cin_pad is None else cin_pad
+    if w.device.type == "meta":
+        return w, kh * kw * cp
     t = torch.zeros((cout, kh, kw, cp), dtype=torch.float32)
     t[..., :cin] = w.permute(0, 2, 3, 1)
     return pack_matrix(t.reshape(cout, kh * kw * cp), h16), kh * kw * cp
@@ -40,6 +44,8 @@ def geglu_interleave(w, b):
     """GEGLU projection [2*inner][K] (rows: values then gates) -> rows interleaved in blocks of 16
     [v0..15 | g0..15 | v16..31 | g16..31 ...] so that value and gate of one output land in the same lane."""
     two_inner, K = w.shape
+    if w.device.type == "meta":
+        return w, b
     inner = two_inner // 2
     assert inner % 16 == 0
     wv, wg = w[:inner].reshape(inner // 16, 16, K), w[inner:].reshape(inner // 16, 16, K)
@@ -85,6 +91,8 @@ def pack_motion_stream(w, h16, heads=8):
     """w: dict of fp32 tensors of one motion module at C = 320 -- proj_in/proj_out (.w [C,C], .b), attn1/attn2 (q, k, v, o weights, o bias),
     ln1..3 (g, b), ff1 (w [8C, C], b), ff2 (w [C, 4C], b), pe [32, C].  Returns (stream [670, 64, 64] h16, params [16320] fp32) in the
     consumption order of vv_motion.hip."""
+    if w["proj_in.w"].device.type == "meta":
+        return w["proj_in.w"], w["proj_in.b"]
     C = w["proj_in.w"].shape[0]
     D = C // heads
     assert C == 320 and D == 40

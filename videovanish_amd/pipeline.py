@@ -260,6 +260,7 @@ class DiffuEraserHIP:
         lat = hip.axpby(prior_lat, noise, a0 ** 0.5, (1 - a0) ** 0.5)
         if trace is not None:
             trace.update(prior_lat=prior_lat.clone(), cond_lat=cond_lat.clone(), lat0=lat.clone())
+        self.denoiser.prepare(ts)
         for i, t in enumerate(ts):
             eps = self.denoiser(lat, cond_lat, mask_u8, t, F, h, w, H, W)
             if trace is not None and i == 0:
@@ -369,6 +370,7 @@ class DiffuEraserHIP:
     def _denoise_windows(self, lat, cond, mask_u8, ts, steps, H, W, nframes, overlap, progress=None):
         n, h, w, _ = lat.shape
         ctxs, swap = reference_contexts(n, nframes, overlap)
+        self.denoiser.prepare(ts)
         for i, t in enumerate(ts):
             value = torch.zeros_like(lat)
             count = np.zeros(n, np.float32)
@@ -463,6 +465,7 @@ class DiffuEraserHIP:
         def worker(stream):
             try:
                 torch.cuda.set_device(dev)             # a new host thread starts on device 0: one process per GPU sets LOCAL_RANK's device
+                Denoiser.lane.concurrent = True        # (thread-local) one stream per chunk while several chunks are in flight
                 stream.wait_stream(main)               # the inputs were produced on the launching stream
                 with torch.cuda.stream(stream):
                     while not errors:

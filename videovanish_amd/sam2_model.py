@@ -377,6 +377,13 @@ class HipSam2:
         f0, f1, top = feats[-3:]
         s0, s1 = self.conv_s0(f0), self.conv_s1(f1)
         n0, n1, nt = s0.shape[0] // Bf, s1.shape[0] // Bf, top.shape[0] // Bf
+        if getattr(self.W, "sd", None) is not None and not getattr(self, "_range_checked", False):
+            # a real checkpoint: the first encoded batch is range-checked once (fp16 operands saturate to inf above 65504; every parity result of
+            # this build was measured on synthetic weights) -- fail loudly instead of painting garbage masks
+            self._range_checked = True
+            if not bool(torch.isfinite(top).all()):
+                raise RuntimeError("SAM 2 image encoder produced non-finite features with this checkpoint: configure(dtype=\"bf16\") "
+                                   "(the reference's own autocast type) instead of fp16 operands")
         return [{"s0": s0[f * n0:(f + 1) * n0], "s1": s1[f * n1:(f + 1) * n1], "top": top[f * nt:(f + 1) * nt]} for f in range(Bf)]
 
     def encode_image(self, frame_u8):

@@ -18,9 +18,14 @@ import torch
 
 
 class Sam2VideoPredictor:
-    def __init__(self, model, fill_hole_area=None, lookahead=8):
+    def __init__(self, model, fill_hole_area=None, lookahead=8, trim_memory=False):
+        """trim_memory: a tracking pass drops every non-conditioning output that no later frame of THE SAME pass can select any more (older than
+        max(num_maskmem, max_obj_ptrs_in_encoder) frames: ~1.25 MiB of device memory per frame and object otherwise stay alive for the whole
+        clip).  Upstream keeps them all (a later reverse pass or a correction click may read them): off by default, the one-shot masking step
+        (`sam2_masker.run_sam2_on_frames`: prompts, then ONE forward pass) switches it on."""
         self.model = model
         self.lookahead = lookahead
+        self.trim_memory = trim_memory
         self.cfg = model.cfg
         self.image_size = model.cfg.image_size
         self.fill_hole_area = model.cfg.fill_hole_area if fill_hole_area is None else fill_hole_area
@@ -194,10 +199,16 @@ class Sam2VideoPredictor:
                     out_dict["non_cond_frame_outputs"][frame_idx] = cur
                 st["frames_tracked_per_obj"][obj_idx][frame_idx] = {"reverse": reverse}
                 per_obj.append(self.model.to_numpy(self.model.masks_to_video_res(cur["pred_masks"], H, W)).reshape(1, H, W))
+            if self.trim_memory:
+                keep = max(self.cfg.num_maskmem, self.cfg.max_obj_ptrs_in_encoder)
+                for out_dict in st["output_dict_per_obj"].values():
+                    nc = out_dict["non_cond_frame_outputs"]
+                    for t in [t for t in nc if (t > frame_idx + keep if reverse else t < frame_idx - keep)]:
+                        del nc[t]
             yield frame_idx, st["obj_ids"], torch.from_numpy(np.stack(per_obj, axis=0))       # [objects, 1, H, W] fp32 logits, as upstream
 
 
-def build_sam2_video_predictor(config_file=None, ckpt_path=None, device=None, model=None, dtype="fp16"):
+def build_sam2_video_predictor(config_file=None, ckpt_path=None, device=None, model=None, dtype="bf16"):
     """Same call as the reference makes (sam2_masker.py:88).  `config_file` is accepted for signature compatibility: the architecture is
     the SAM 2.1 Hiera-L configuration it names.  `ckpt_path`: the published `.pt`; a missing file is an error (no silent random weights) unless
     `model` is handed in."""

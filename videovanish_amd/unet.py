@@ -1,6 +1,7 @@
 """Motion-UNet and BrushNet branch on HIP kernels (architecture: SURVEY App. D.1-D.3; the reference reaches them
 through `DiffuEraser.forward`, call site reference diffuerase.py:62-67)."""
 import math
+import threading
 
 import torch
 
@@ -85,10 +86,38 @@ class _Backbone:
                 self.ups.append(Conv(ctx, f"{pre}.up_blocks.{i}.upsamplers.0.conv", cout, cout))
                 self.up_ch.append(cout)
 
-    def temb(self, t):
+    def temb(self, t, key=None):
+        """SiLU(time embedding) of timestep t -- or, after prepare_temb(), the table {id(ResBlock): conv1 bias + time_emb_proj row} of t.
+        key: the stream the tables were prepared on (default: the current one; the two-stream schedule passes its main stream)."""
+        hit = self.__dict__.get("_temb_tables", {}).get((torch.cuda.current_stream().cuda_stream if key is None else key, int(t)))
+        if hit is not None:
+            return hit
         e = self.ctx.dev(timestep_embedding(t, self.cfg.block_out[0]))
         e = hip.silu(self.t1(e))
         return hip.silu(self.t2(e))            # every consumer applies SiLU first (ResnetBlock2D.time_emb_proj)
+
+    def resblocks(self):
+        out = [r for layers in self.down for (r, _, _) in layers] + [self.mid_r0, self.mid_r1]
+        return out + [r for layers in self.up for (r, _, _) in layers]
+
+    def prepare_temb(self, ts):
+        """Hoist the time-embedding work out of the denoise loop: nothing in it depends on the latents, so the two embedding linears and the
+        time_emb_proj of every ResBlock run ONCE for all S timesteps of the schedule as GEMMs with S rows (instead of ~27 one-row launches of
+        ~50 us latency each per backbone and step: 0.7 % of a step).  Row s of an S-row GEMM is computed exactly like the one-row launch
+        (same tile kernel, same k order), so the values are bit-identical.  Tables are kept per launch stream (chunks of one rank may run
+        on several streams: a table is produced and consumed on the same stream, or on its side stream behind a wait)."""
+        ts = [int(t) for t in ts]
+        key = torch.cuda.current_stream().cuda_stream
+        tables = self.__dict__.setdefault("_temb_tables", {})
+        if all((key, t) in tables for t in ts):
+            return
+        for k in [k for k in tables if k[0] == key]:
+            del tables[k]                           # another schedule on this stream: drop the old rows
+        e = self.ctx.dev(torch.cat([timestep_embedding(t, self.cfg.block_out[0]) for t in ts], 0))
+        st = hip.silu(self.t2(hip.silu(self.t1(e))))
+        rows = {id(r): r.temb_bias(st) for r in self.resblocks()}
+        for i, t in enumerate(ts):
+            tables[(key, t)] = {rid: b[i] for rid, b in rows.items()}
 
     def run_down(self, x_in, F, h, w, st):
         """x_in: h16 [F*h*w, in_pad].  Returns (x, skips=[(tensor,H,W)...], (H,W))."""
@@ -157,9 +186,9 @@ class BrushNet(_Backbone):
         self.zm = Conv(ctx, "brushnet.brushnet_mid_block", cfg.block_out[-1], cfg.block_out[-1], k=1, gain=zg)
         self.zu = [Conv(ctx, f"brushnet.brushnet_up_blocks.{i}", c, c, k=1, gain=zg) for i, c in enumerate(self.up_ch)]
 
-    def backbone(self, x16, t, F, h, w):
+    def backbone(self, x16, t, F, h, w, temb_key=None):
         """the part that does not depend on the UNet: down, mid and up path of the branch -> (down outputs, mid, up outputs, (H, W) at the bottom)."""
-        st = self.temb(t)
+        st = self.temb(t, temb_key)
         x, skips, (H, W) = self.run_down(x16, F, h, w, st)
         down_raw = list(skips)
         mid = self.run_mid(x, F, H, W, st)
@@ -213,6 +242,15 @@ class Denoiser:
     # overlap, so per-kernel HIP-event durations are only meaningful on ONE stream: while hip.PROFILE is set (bench.py's pricing pass) the
     # schedule falls back to one stream.
     OVERLAP = True
+    # set by the chunk lanes of pipeline.forward_device: with two chunks in flight the GPU is already shared by two streams and a third / fourth
+    # stream per chunk measured slower (profiles/r4_schedule_ab_*.txt: 2 lanes x 1 stream 20.2 s per chunk, 2 lanes x 2 streams 20.4 s, 1 lane x 2
+    # streams 20.7 s, 1 lane x 1 stream 21.2 s) -- the second stream pays only when a rank runs ONE chunk at a time
+    lane = threading.local()
+
+    def prepare(self, ts):
+        """once per schedule, before the denoise loop (pipeline.denoise_chunk): see _Backbone.prepare_temb"""
+        self.unet.prepare_temb(ts)
+        self.brush.prepare_temb(ts)
 
     def _side_stream(self, main):
         """one side stream per launch stream (chunks of one rank may run on several streams at once: pipeline.forward_device)"""
@@ -228,12 +266,12 @@ class Denoiser:
         lat8 = hip.pad_channels(ctx.dt, lat, 8).view(F * h * w, 8)
         x16 = hip.brushnet_input(ctx.dt, lat, cond, mask2d, H, W).view(F * h * w, 16)
         pre = None
-        if Denoiser.OVERLAP and hip.PROFILE is None:
+        if Denoiser.OVERLAP and hip.PROFILE is None and not getattr(Denoiser.lane, "concurrent", False):
             main = torch.cuda.current_stream()
             side = self._side_stream(main)
             side.wait_stream(main)                             # x16 / t are ready
             with torch.cuda.stream(side):
-                pre = self.brush.backbone(x16, t, F, h, w)
+                pre = self.brush.backbone(x16, t, F, h, w, temb_key=main.cuda_stream)
             x16.record_stream(side)
         st, skips, mid, (Hm, Wm) = self.unet.down_mid(lat8, t, F, h, w)
         if pre is not None:
