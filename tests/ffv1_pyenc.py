@@ -1,9 +1,14 @@
-"""Test infrastructure: a second, independent FFV1 version-3 ENCODER in pure Python, written from RFC 9043 (range coder 3.8.1,
+"""Test infrastructure: a second, independent FFV1 ENCODER (version 3, and the version 0 / 1 bitstream) in pure Python, written from RFC 9043 (range coder 3.8.1,
 default_state_transition 3.8.1.5, alternative table 3.8.1.6, configuration record 4.2, slice header 4.5, sample coding 3.8 with
 the median predictor 3.3 and the context model 3.4-3.5, JPEG 2000 RCT 3.7.2, slice footer 4.8).  It emits what libavcodec's
 defaults look like -- RANGE-CODED samples (coder_type 1 or 2), a num_h_slices x num_v_slices grid, two quantisation-table sets
 (3 and 5 context inputs), optional extra (alpha) plane, optional CRC -- i.e. streams the C encoder in csrc/vv_ffv1.c cannot produce.
-The C DECODER is checked against these packets (tests/test_frameio_cpu.py).  Slow (pure Python): tiny images only."""
+The C DECODER is checked against these packets (tests/test_frameio_cpu.py).  Slow (pure Python): tiny images only.
+
+Round 4: `keyframe=False` + `persist` (a dict that carries the adaptive context states from frame to frame, per slice) write NON-KEY frames
+(RFC 9043 4.4: key-frame bit 0, no header, states continue), `intra=0` in the configuration record; `legacy=0 | 1` writes FFV1 VERSION 0 / 1 frames
+(RFC 9043 4.2 "Parameters" inside every key frame instead of a configuration record, ONE quantisation-table set, one slice, no slice header, no
+slice footer, no CRC)."""
 import numpy as np
 
 # RFC 9043 3.8.1.6: the alternative state transition table (coder_type 2 streams carry it as deltas to the default table)
@@ -158,11 +163,11 @@ def _put_quant_table(rc, tab):
     rc.put_symbol(st, i - last - 1, False)
 
 
-def config_record(coder, nh, nv, alpha=False, ec=1, sets=None, colorspace=1, chroma_planes=True, hshift=0, vshift=0):
+def config_record(coder, nh, nv, alpha=False, ec=1, sets=None, colorspace=1, chroma_planes=True, hshift=0, vshift=0, intra=1, version=3, micro=4):
     rc = RangeEncoder()
     st = [128] * 32
-    rc.put_symbol(st, 3, False)            # version
-    rc.put_symbol(st, 4, False)            # micro_version
+    rc.put_symbol(st, version, False)      # version
+    rc.put_symbol(st, micro, False)        # micro_version
     rc.put_symbol(st, coder, False)
     if coder == 2:
         d = default_state_transition()
@@ -187,7 +192,7 @@ def config_record(coder, nh, nv, alpha=False, ec=1, sets=None, colorspace=1, chr
     for _ in sets:
         rc.put(st, 0, 0)                   # states_coded = 0
     rc.put_symbol(st, ec, False)
-    rc.put_symbol(st, 1, False)            # intra
+    rc.put_symbol(st, intra, False)        # intra: 1 = every frame is a key frame
     body = rc.terminate()
     return body + crc32_mpeg(body).to_bytes(4, "big")
 
@@ -317,9 +322,29 @@ def _line_symbols(P, qs, y, w, bits):
     return out
 
 
-def _slice_header(rc, first, coder, sx, sy, qidx):
+def _legacy_header(rc, version, coder, colorspace, chroma_planes, hshift, vshift, alpha, qset):
+    """versions 0 / 1: the parameters + the ONE quantisation-table set, in the frame's own range coder right behind the key-frame bit"""
+    st = [128] * 32
+    rc.put_symbol(st, version, False)
+    rc.put_symbol(st, coder, False)
+    if coder == 2:
+        d = default_state_transition()
+        for i in range(1, 256):
+            rc.put_symbol(st, ALT_STATE[i] - d[i], True)
+    rc.put_symbol(st, colorspace, False)
+    if version > 0:
+        rc.put_symbol(st, 8, False)        # bits_per_raw_sample (version 0 has no such field: 8 bits)
+    rc.put(st, 0, 1 if chroma_planes else 0)
+    rc.put_symbol(st, hshift, False)
+    rc.put_symbol(st, vshift, False)
+    rc.put(st, 0, 1 if alpha else 0)
+    for t in range(5):
+        _put_quant_table(rc, qset[t])
+
+
+def _slice_header(rc, first, coder, sx, sy, qidx, keyframe=True):
     if first:
-        rc.put([128], 0, 1)        # keyframe
+        rc.put([128], 0, 1 if keyframe else 0)        # key-frame bit
     if coder == 2:
         rc.set_table(ALT_STATE)
     st = [128] * 32
@@ -332,12 +357,15 @@ def _slice_header(rc, first, coder, sx, sy, qidx):
     rc.put_symbol(st, 0, False)
 
 
-def _finish_slice(rc, bw, ec):
+def _finish_slice(rc, bw, ec, legacy=None):
     if bw is not None:                                   # Golomb-Rice: the range coder only carried the header
-        rc.put([129], 0, 0)
+        if legacy is None:
+            rc.put([129], 0, 0)                          # (version >= 3.2 only)
         body = rc.terminate() + bw.tobytes()
     else:
         body = rc.terminate()
+    if legacy is not None:
+        return bytearray(body)                           # versions 0 / 1: no slice footer
     sl = bytearray(body) + len(body).to_bytes(3, "big")
     if ec:
         sl += b"\x00"
@@ -345,13 +373,16 @@ def _finish_slice(rc, bw, ec):
     return sl
 
 
-def encode_frame(rgb, coder, nh, nv, alpha=None, ec=1, set_luma=0, set_chroma=1, set_alpha=0):
+def encode_frame(rgb, coder, nh, nv, alpha=None, ec=1, set_luma=0, set_chroma=1, set_alpha=0, keyframe=True, persist=None, legacy=None):
     """rgb: (H, W, 3) uint8; alpha: optional (H, W) uint8.  coder 1 / 2: range-coded samples (default / custom state table); coder 0:
     Golomb-Rice.  Returns the FFV1 packet (all slices).  RGB mode codes the planes G, B-G, R-G (9 bits) line by line, interleaved."""
     sets, counts = quant_tables()
     H, W = rgb.shape[:2]
     pkt = bytearray()
     first = True
+    persist = {} if persist is None else persist
+    if legacy is not None:
+        assert nh == nv == 1 and set_luma == set_chroma == set_alpha, "versions 0 / 1: one slice, one quantisation-table set"
     for sy in range(nv):
         for sx in range(nh):
             y0, y1 = sy * H // nv, (sy + 1) * H // nv
@@ -359,7 +390,14 @@ def encode_frame(rgb, coder, nh, nv, alpha=None, ec=1, set_luma=0, set_chroma=1,
             w, h = x1 - x0, y1 - y0
             rc = RangeEncoder()
             qidx = [set_luma, set_chroma] + ([set_alpha] if alpha is not None else [])
-            _slice_header(rc, first, coder, sx, sy, qidx)
+            if legacy is None:
+                _slice_header(rc, first, coder, sx, sy, qidx, keyframe)
+            else:
+                rc.put([128], 0, 1 if keyframe else 0)
+                if keyframe:
+                    _legacy_header(rc, legacy, coder, 1, True, 0, 0, alpha is not None, sets[set_luma])
+                if coder == 2:
+                    rc.set_table(ALT_STATE)
             first = False
             plane_set = [qidx[0], qidx[1], qidx[1]] + ([qidx[2]] if alpha is not None else [])
             px = rgb[y0:y1, x0:x1].astype(np.int32)
@@ -372,13 +410,16 @@ def encode_frame(rgb, coder, nh, nv, alpha=None, ec=1, set_luma=0, set_chroma=1,
             planes = [g, b, r] + ([alpha[y0:y1, x0:x1].astype(np.int32)] if alpha is not None else [])
             # one state array per plane INDEX (0 luma, 1 both chroma planes, 2 alpha), even when two indices name the same table set
             nidx = 3 if alpha is not None else 2
+            if keyframe or (sy, sx) not in persist:          # a key frame resets the adaptive states; a non-key frame continues from the previous frame's
+                persist[(sy, sx)] = ([[VlcState() for _ in range(counts[plane_set[[0, 1, 3][i]]])] for i in range(nidx)] if coder == 0 else
+                                     [[128] * (32 * counts[plane_set[[0, 1, 3][i]]]) for i in range(nidx)])
             if coder == 0:
                 bw = BitWriter()
                 gl = GolombLineCoder(bw, 9)
-                vst = [[VlcState() for _ in range(counts[plane_set[[0, 1, 3][i]]])] for i in range(nidx)]
+                vst = persist[(sy, sx)]
             else:
                 bw = None
-                sarr = [[128] * (32 * counts[plane_set[[0, 1, 3][i]]]) for i in range(nidx)]
+                sarr = persist[(sy, sx)]
             for y in range(h):
                 for p, P in enumerate(planes):
                     syms = _line_symbols(P, sets[plane_set[p]], y, w, 9)
@@ -388,11 +429,12 @@ def encode_frame(rgb, coder, nh, nv, alpha=None, ec=1, set_luma=0, set_chroma=1,
                         arr = sarr[(p + 1) // 2]
                         for ctx, diff in syms:
                             rc.put_symbol(arr, diff, True, base=32 * ctx)
-            pkt += _finish_slice(rc, bw, ec)
+            pkt += _finish_slice(rc, bw, ec, legacy)
     return bytes(pkt)
 
 
-def encode_frame_ycbcr(y, cb, cr, coder, nh, nv, hshift, vshift, alpha=None, ec=1, set_luma=0, set_chroma=1, set_alpha=0):
+def encode_frame_ycbcr(y, cb, cr, coder, nh, nv, hshift, vshift, alpha=None, ec=1, set_luma=0, set_chroma=1, set_alpha=0, keyframe=True, persist=None,
+                       legacy=None):
     """planar 8-bit YCbCr (colorspace_type 0): y (H, W), cb / cr (ceil(H >> vshift), ceil(W >> hshift)) or None for a gray stream.  Per slice
     the planes are coded one after the other (Y, Cb, Cr [, alpha]); Cb and Cr share the context states of plane index 1; the run index of the
     Golomb-Rice coder restarts with every plane (RFC 9043 4.7 / 3.8.2.2)."""
@@ -401,6 +443,9 @@ def encode_frame_ycbcr(y, cb, cr, coder, nh, nv, hshift, vshift, alpha=None, ec=
     chroma = cb is not None
     pkt = bytearray()
     first = True
+    persist = {} if persist is None else persist
+    if legacy is not None:
+        assert nh == nv == 1 and set_luma == set_chroma == set_alpha, "versions 0 / 1: one slice, one quantisation-table set"
     for sy in range(nv):
         for sx in range(nh):
             y0, y1 = sy * H // nv, (sy + 1) * H // nv
@@ -408,7 +453,14 @@ def encode_frame_ycbcr(y, cb, cr, coder, nh, nv, hshift, vshift, alpha=None, ec=
             w, h = x1 - x0, y1 - y0
             rc = RangeEncoder()
             qidx = [set_luma] + ([set_chroma] if chroma else []) + ([set_alpha] if alpha is not None else [])
-            _slice_header(rc, first, coder, sx, sy, qidx)
+            if legacy is None:
+                _slice_header(rc, first, coder, sx, sy, qidx, keyframe)
+            else:
+                rc.put([128], 0, 1 if keyframe else 0)
+                if keyframe:
+                    _legacy_header(rc, legacy, coder, 0, chroma, hshift, vshift, alpha is not None, sets[set_luma])
+                if coder == 2:
+                    rc.set_table(ALT_STATE)
             first = False
             cw, ch = (w + (1 << hshift) - 1) >> hshift, (h + (1 << vshift) - 1) >> vshift
             cx, cy = x0 >> hshift, y0 >> vshift
@@ -418,7 +470,9 @@ def encode_frame_ycbcr(y, cb, cr, coder, nh, nv, hshift, vshift, alpha=None, ec=
             if alpha is not None:
                 jobs.append((alpha[y0:y1, x0:x1].astype(np.int32), 2, set_alpha))
             bw = BitWriter() if coder == 0 else None
-            states = {}
+            if keyframe or (sy, sx) not in persist:
+                persist[(sy, sx)] = {}
+            states = persist[(sy, sx)]
             for P, idx, si in jobs:
                 if idx not in states:
                     states[idx] = [VlcState() for _ in range(counts[si])] if coder == 0 else [128] * (32 * counts[si])
@@ -430,5 +484,5 @@ def encode_frame_ycbcr(y, cb, cr, coder, nh, nv, hshift, vshift, alpha=None, ec=
                     else:
                         for ctx, diff in syms:
                             rc.put_symbol(states[idx], diff, True, base=32 * ctx)
-            pkt += _finish_slice(rc, bw, ec)
+            pkt += _finish_slice(rc, bw, ec, legacy)
     return bytes(pkt)

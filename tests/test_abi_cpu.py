@@ -42,8 +42,9 @@ def test_vvio_header_symbols_are_exported():
     ver = int(re.search(r"#define VVIO_ABI_VERSION (\d+)", src).group(1))
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = sorted(set(re.findall(r"\b(vvio_[a-z0-9_]+)\s*\(", src)))
-    assert names == ["vvio_abi_version", "vvio_ffv1_config_record", "vvio_ffv1_decode_frame", "vvio_ffv1_decode_frame_yuv", "vvio_ffv1_encode_frame",
-                     "vvio_ffv1_stream_info", "vvio_ycbcr_to_rgb"]
+    assert names == ["vvio_abi_version", "vvio_ffv1_config_record", "vvio_ffv1_decode_frame", "vvio_ffv1_decode_frame_yuv", "vvio_ffv1_decoder_close",
+                     "vvio_ffv1_decoder_decode", "vvio_ffv1_decoder_info", "vvio_ffv1_decoder_open", "vvio_ffv1_encode_frame", "vvio_ffv1_stream_info",
+                     "vvio_ycbcr_to_rgb"]
     io = ctypes.CDLL(os.path.join(ROOT, "videovanish_amd", "csrc", "libvvio.so"))
     for n in names:
         assert hasattr(io, n), f"{n} declared in include/vvio.h but not exported"

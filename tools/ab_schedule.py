@@ -26,10 +26,11 @@ model.forward_device(fr[:chunk], pr[:chunk], mk[:chunk], chunk, 0, steps=min(ste
 torch.cuda.synchronize()
 ref = None
 for c in configs:
-    lanes, mode = int(c[:-1]), c[-1]
+    c0, _, stag = c.partition("@")              # "2s@0.4": lane k starts 0.4 k seconds late (RunConfig.lane_stagger_s)
+    lanes, mode = int(c0[:-1]), c0[-1]
     unet.Denoiser.OVERLAP = mode == "o"      # (with lanes > 1 the product keeps one stream per chunk whatever this says: profiles/r4_schedule_ab_*.txt
                                              #  were measured before that rule went in)
-    model.run = replace(run, concurrent_chunks=lanes)
+    model.run = replace(run, concurrent_chunks=lanes, lane_stagger_s=float(stag or 0.0))
     torch.cuda.synchronize(); t0 = time.time()
     out, _ = model.forward_device(fr, pr, mk, T, 0, steps=steps, scheduler="ddim")
     torch.cuda.synchronize(); dt = time.time() - t0

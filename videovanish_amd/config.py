@@ -61,5 +61,8 @@ class RunConfig:
     # chunk (GroupNorm, LayerNorm, the fp32-trunk GEMMs) run beside the MFMA-bound kernels of the other and kernel tails overlap.  Chunks are
     # independent until blend time, so the result is bit-identical for every value (tests/test_model_gpu.py); the live set is ~10 GB per chunk
     concurrent_chunks: int = 2
+    # lane k starts k * lane_stagger_s seconds after lane 0 (host-side delay before its first launch): identical chunks otherwise run in lockstep,
+    # MFMA-bound kernels beside MFMA-bound kernels; an offset puts one chunk's memory-bound phases beside the other's matrix-bound ones
+    lane_stagger_s: float = 0.0
     unet: UNetConfig = field(default_factory=UNetConfig)
     vae: VAEConfig = field(default_factory=VAEConfig)

@@ -1,4 +1,5 @@
-/* vv_ffv1.c -- host-side FFV1 (RFC 9043) version 3 intra codec for the frame I/O on either side of the hot path
+/* vv_ffv1.c -- host-side FFV1 (RFC 9043) codec for the frame I/O on either side of the hot path: version 3 encoder (intra), version 0 / 1 / 3
+ * decoder incl. non-key frames
  * (reference tools.py:30-45 writes FFV1 in Matroska through cv2/ffmpeg).  Plain C, no GPU: codec I/O is CPU
  * work outside the timed path.  Built into libvvio.so by build.sh; bound by videovanish_amd/frameio.py.
  *
@@ -10,8 +11,14 @@
  * (the 2 x 2 slice grid libavcodec picks by default); range-coded sample data -- coder_type 1 (RFC 9043 3.8.1.5
  * default_state_transition = the table build_rac_states() computes, checked against the RFC's listing in the tests) and
  * coder_type 2 (custom table: deltas to the default in the configuration record); an extra (alpha) plane, decoded and dropped.
- * Refused with an error code: YCbCr streams (colorspace_type 0), more than 8 bits per sample, coded initial states, inter
- * (non-key) frames.  Every header field read from the file is range-checked before it is used.
+ * Round 4: planar YCbCr streams (round 3), FFV1 VERSION 0 / 1 streams (no configuration record: the parameters and ONE quantisation-table
+ * set travel in the range-coded header of every key frame, one slice per frame, no slice header / footer / CRC -- what libavcodec's encoder
+ * picks by itself for frames up to 720 x 576) and NON-KEY frames of every version (a frame whose key-frame bit is 0 carries no header and
+ * continues from the adaptive context states the previous frame left behind, slice by slice -- what an encoder with gop_size > 1 emits,
+ * e.g. cv2.VideoWriter's default of 12 [UNVERIFIED-3P]) through the stateful decoder object (vvio_ffv1_decoder_*).
+ * Refused with an error code: more than 8 bits per sample, coded initial states, version 2 (experimental, never released) and versions
+ * above 3 (different slice header / context handling), a non-key frame without a preceding key frame.  Every header field read from the
+ * file is range-checked before it is used.
  *
  * PARITY UNPINNED against a real FFV1 decoder (no ffmpeg / cv2 in the build image): restated from RFC 9043 and the public
  * libavcodec ffv1 sources; pinned here only by lossless round trips and structural checks (tests/test_frameio_cpu.py).
@@ -335,8 +342,10 @@ static int parse_config(const uint8_t* rec, int len, Config* cf) {
     memset(state, 128, sizeof(state));
     rc_init_dec(&c, rec, len);
     cf->version = get_symbol(&c, state, 0, &err);
-    if (cf->version < 3) return -2;
+    if (cf->version < 3) return -2;            /* versions 0 / 1 have no configuration record (their header is in the key frames); 2 was never released */
+    if (cf->version > 3) return -26;           /* version 4+: other slice header fields / context handling -- not decoded with version 3 rules */
     cf->micro = get_symbol(&c, state, 0, &err);
+    if (err || cf->micro < 0 || cf->micro > 4) return -26;     /* micro_version beyond what RFC 9043 describes */
     cf->coder = get_symbol(&c, state, 0, &err);
     if (err || cf->coder < 0 || cf->coder > 2) return -3;
     if (cf->coder == 2) {                      /* custom table = default_state_transition (what build_rac_states made) + coded deltas */
@@ -541,61 +550,74 @@ static int decode_plane8(SampleSrc* src, const QuantSet* q, VlcState* vs, uint8_
     return err ? -25 : 0;
 }
 
-static int decode_slice(const Config* cf, const uint8_t* data, int len, int first, int W, int H, uint8_t* rgb, uint8_t* const* yuv) {
-    RangeCoder c;
-    uint8_t state[CONTEXT_SIZE];
+/* adaptive context states of one slice, kept from frame to frame (a key frame resets them): one array per plane index (0 luma, 1 both chroma
+ * planes, 2 alpha); Golomb-Rice streams keep VlcStates, range-coded streams CONTEXT_SIZE bytes per context */
+typedef struct { VlcState* vlc[3]; uint8_t* rst[3]; int n[3]; int ac; int live; } SliceCtx;
+#define MAX_SLICES 1024
+typedef struct {
+    Config cf;
+    int have_cf;                       /* configuration known (version 3: from the record; versions 0 / 1: from the last key frame's header) */
+    int legacy;                        /* versions 0 / 1 */
+    int key_ok;                        /* a key frame has been decoded */
+    SliceCtx sl[MAX_SLICES];
+} Decoder;
+
+static void slice_ctx_free(SliceCtx* s) {
+    for (int p = 0; p < 3; ++p) { free(s->vlc[p]); free(s->rst[p]); s->vlc[p] = 0; s->rst[p] = 0; s->n[p] = 0; }
+    s->live = 0;
+}
+/* key frame: (re)allocate and reset; non-key frame: the states of the previous frame must be there with the same shape */
+static int slice_ctx_prepare(SliceCtx* s, const QuantSet* const* qs, int ac, int keyframe) {
+    if (!keyframe) {
+        if (!s->live || s->ac != ac) return -20;
+        for (int p = 0; p < 3; ++p) if (s->n[p] != qs[p]->context_count) return -20;
+        return 0;
+    }
+    for (int p = 0; p < 3; ++p) {
+        const int n = qs[p]->context_count;
+        if (n < 1 || n > MAX_CTX) return -21;
+        if (s->n[p] != n || s->ac != ac || !s->live) {
+            free(s->vlc[p]); free(s->rst[p]); s->vlc[p] = 0; s->rst[p] = 0; s->n[p] = 0;
+            if (ac) s->rst[p] = (uint8_t*)malloc((size_t)n * CONTEXT_SIZE);
+            else s->vlc[p] = (VlcState*)malloc(sizeof(VlcState) * (size_t)n);
+            if (!s->rst[p] && !s->vlc[p]) { s->live = 0; return -23; }
+            s->n[p] = n;
+        }
+        if (ac) memset(s->rst[p], 128, (size_t)n * CONTEXT_SIZE);
+        else for (int i = 0; i < n; ++i) { s->vlc[p][i].drift = 0; s->vlc[p][i].error_sum = 4; s->vlc[p][i].bias = 0; s->vlc[p][i].count = 1; }
+    }
+    s->ac = ac; s->live = 1;
+    return 0;
+}
+
+/* the sample data of one slice.  c: the slice's range coder, positioned behind everything that precedes the samples (key-frame bit, frame
+ * header of versions 0 / 1, slice header of version 3); data / len: the slice's bytes; (x0, y0, w, h): its rectangle; qi: quantisation-table
+ * set per plane index */
+static int decode_slice_samples(const Config* cf, SliceCtx* sc, RangeCoder* pc, const uint8_t* data, int len, int x0, int y0, int w, int h, const int* qi,
+                                int keyframe, int W, int H, uint8_t* rgb, uint8_t* const* yuv) {
+    RangeCoder c = *pc;
     int err = 0;
     const int ac = cf->coder != 0;                     /* sample data range coded (coder_type 1 / 2) instead of Golomb-Rice */
     const int nplanes = 3 + (cf->alpha ? 1 : 0);       /* G, B-G, R-G (JPEG 2000 RCT) [, alpha: decoded, dropped] */
-    const int nqi = 1 + (cf->chroma_planes ? 1 : 0) + (cf->alpha ? 1 : 0);
-    rc_init_dec(&c, data, len);
-    if (first) { uint8_t keystate = 128; if (!get_rac(&c, &keystate)) return -20; }    /* intra-only streams: every frame is a key frame */
-    if (cf->coder == 2)                                /* custom state transitions: from here on (libavcodec ff_ffv1_init_slice_state) */
-        for (int i = 1; i < 256; ++i) { c.one_state[i] = cf->one_state[i]; c.zero_state[256 - i] = (uint8_t)(256 - cf->one_state[i]); }
-    memset(state, 128, sizeof(state));
-    const int sx = get_symbol(&c, state, 0, &err), sy = get_symbol(&c, state, 0, &err);
-    const int sw = get_symbol(&c, state, 0, &err) + 1, sh = get_symbol(&c, state, 0, &err) + 1;
-    int qi[3] = {0, 0, 0};
-    for (int i = 0; i < nqi; ++i) qi[i] = get_symbol(&c, state, 0, &err);
-    if (!cf->chroma_planes) { qi[2] = qi[1]; qi[1] = qi[0]; }
-    (void)get_symbol(&c, state, 0, &err); (void)get_symbol(&c, state, 0, &err); (void)get_symbol(&c, state, 0, &err);
-    /* every field came from the file: refuse anything outside the slice grid / the table sets before it indexes memory */
-    if (err || sx < 0 || sy < 0 || sw < 1 || sh < 1 || sx > cf->nh - sw || sy > cf->nv - sh) return -21;
-    for (int i = 0; i < 3; ++i) if (qi[i] < 0 || qi[i] >= cf->nsets) return -21;
-    const int y0 = (int)((int64_t)sy * H / cf->nv), h = (int)((int64_t)(sy + sh) * H / cf->nv) - y0;
-    const int x0 = (int)((int64_t)sx * W / cf->nh), w = (int)((int64_t)(sx + sw) * W / cf->nh) - x0;
-    if (w < 1 || h < 1 || x0 + w > W || y0 + h > H) return -21;
     BitR br = {data, 0, 0, 0};
     if (!ac) {
-        if (cf->micro > 1) { uint8_t st = 129; (void)get_rac(&c, &st); }
+        if (cf->version == 3 && cf->micro > 1) { uint8_t st = 129; (void)get_rac(&c, &st); }
         const int ac_bytes = (int)(c.ptr - c.start) - 1;
         if (ac_bytes < 0 || ac_bytes > len) return -22;
         br.buf = data + ac_bytes; br.nbits = (int64_t)(len - ac_bytes) * 8;
     }
     const QuantSet* qs[3] = {&cf->sets[qi[0]], &cf->sets[qi[1]], &cf->sets[qi[2]]};
-    VlcState* vlc[3] = {0, 0, 0};
-    uint8_t* rst[3] = {0, 0, 0};                       /* range-coder mode: CONTEXT_SIZE adaptive states per context, initial value 128 */
-    int fail = 0;
-    for (int p = 0; p < 3; ++p) {
-        const int n = qs[p]->context_count;
-        if (n < 1 || n > MAX_CTX) { fail = 1; break; }
-        if (ac) {
-            rst[p] = (uint8_t*)malloc((size_t)n * CONTEXT_SIZE);
-            if (!rst[p]) { fail = 1; break; }
-            memset(rst[p], 128, (size_t)n * CONTEXT_SIZE);
-        } else {
-            vlc[p] = (VlcState*)malloc(sizeof(VlcState) * (size_t)n);
-            if (!vlc[p]) { fail = 1; break; }
-            for (int i = 0; i < n; ++i) { vlc[p][i].drift = 0; vlc[p][i].error_sum = 4; vlc[p][i].bias = 0; vlc[p][i].count = 1; }
-        }
-    }
-    if (!fail && cf->colorspace == 0) {
-        /* planar YCbCr: Y (set 0), then Cb and Cr (set 1, shared states) on the subsampled grid, then alpha (set 2; decoded, dropped) */
+    int r = slice_ctx_prepare(sc, qs, ac, keyframe);
+    if (r < 0) return r;
+    VlcState** vlc = sc->vlc;
+    uint8_t** rst = sc->rst;
+    if (cf->colorspace == 0) {
+        /* planar YCbCr: Y (index 0), then Cb and Cr (index 1, shared states) on the subsampled grid, then alpha (index 2; decoded, dropped) */
         SampleSrc src = {ac, &c, &br};
         const int cw = cf->chroma_planes ? (w + (1 << cf->hshift) - 1) >> cf->hshift : 0, chh = cf->chroma_planes ? (h + (1 << cf->vshift) - 1) >> cf->vshift : 0;
         const int cx = x0 >> cf->hshift, cy = y0 >> cf->vshift;
         const int CW = (W + (1 << cf->hshift) - 1) >> cf->hshift, CH = (H + (1 << cf->vshift) - 1) >> cf->vshift;
-        int r = decode_plane8(&src, qs[0], vlc[0], rst[0], yuv[0] + (size_t)y0 * W + x0, W, w, h);
+        r = decode_plane8(&src, qs[0], vlc[0], rst[0], yuv[0] + (size_t)y0 * W + x0, W, w, h);
         if (!r && cf->chroma_planes) {
             if (cx + cw > CW || cy + chh > CH) r = -21;
             if (!r) r = decode_plane8(&src, qs[1], vlc[1], rst[1], yuv[1] + (size_t)cy * CW + cx, CW, cw, chh);
@@ -606,14 +628,13 @@ static int decode_slice(const Config* cf, const uint8_t* data, int len, int firs
             if (!scratch) r = -23;
             else { r = decode_plane8(&src, qs[2], vlc[2], rst[2], scratch, w, w, h); free(scratch); }
         }
-        for (int p = 0; p < 3; ++p) { free(vlc[p]); free(rst[p]); }
         if (r) return r;
         if (ac) return c.overflow > 2 ? -24 : 0;
         return br.overflow ? -24 : 0;
     }
     const int LW = w + 6;
-    int16_t* lines = fail ? 0 : (int16_t*)calloc((size_t)4 * 3 * LW, sizeof(int16_t));
-    if (!lines) { for (int p = 0; p < 3; ++p) { free(vlc[p]); free(rst[p]); } return -23; }
+    int16_t* lines = (int16_t*)calloc((size_t)4 * 3 * LW, sizeof(int16_t));
+    if (!lines) return -23;
     int run_index = 0;
     for (int y = 0; y < h && !err; ++y) {
         int16_t* s[4][3];
@@ -621,7 +642,7 @@ static int decode_slice(const Config* cf, const uint8_t* data, int len, int firs
             for (int i = 0; i < 3; ++i) s[p][i] = lines + ((size_t)p * 3 + (size_t)((y + 3 - i) % 3)) * LW + 3;
         for (int p = 0; p < nplanes; ++p) {
             int16_t *cur = s[p][0], *last = s[p][1], *last2 = s[p][2];
-            const int set = (p + 1) / 2;               /* plane -> context set: 0, 1, 1, 2 */
+            const int set = (p + 1) / 2;               /* plane -> plane index: 0, 1, 1, 2 */
             const QuantSet* q = qs[set];
             if (y == 0) { memset(last - 3, 0, sizeof(int16_t) * LW); memset(last2 - 3, 0, sizeof(int16_t) * LW); }
             else if (y == 1) memset(last2 - 3, 0, sizeof(int16_t) * LW);
@@ -669,45 +690,203 @@ static int decode_slice(const Config* cf, const uint8_t* data, int len, int firs
         if (err) break;
         uint8_t* row = rgb + ((size_t)(y0 + y) * W + x0) * 3;
         for (int x = 0; x < w; ++x) {
-            int g = s[0][0][x], b = s[1][0][x], r = s[2][0][x];
-            b -= 256; r -= 256; g -= (b + r) >> 2; b += g; r += g;
-            row[3 * x] = (uint8_t)r; row[3 * x + 1] = (uint8_t)g; row[3 * x + 2] = (uint8_t)b;
+            int g = s[0][0][x], b = s[1][0][x], r2 = s[2][0][x];
+            b -= 256; r2 -= 256; g -= (b + r2) >> 2; b += g; r2 += g;
+            row[3 * x] = (uint8_t)r2; row[3 * x + 1] = (uint8_t)g; row[3 * x + 2] = (uint8_t)b;
         }
     }
     free(lines);
-    for (int p = 0; p < 3; ++p) { free(vlc[p]); free(rst[p]); }
     if (err) return -25;
     if (ac) return c.overflow > 2 ? -24 : 0;           /* the range decoder legitimately reads up to two bytes past the coded data */
     return br.overflow ? -24 : 0;
 }
 
-static int decode_frame_any(const uint8_t* cfg, int cfglen, const uint8_t* data, int len, int W, int H, uint8_t* rgb, uint8_t* const* yuv) {
-    Config* cf = (Config*)malloc(sizeof(Config));
-    if (!cf) return -1;
-    if (cfglen < 5 || crc32_mpeg(cfg, cfglen) != 0) { free(cf); return -10; }
-    int r = parse_config(cfg, cfglen - 4, cf);
-    if (r < 0) { free(cf); return r; }
-    if ((cf->colorspace == 0) != (yuv != 0)) { free(cf); return -9; }      /* the caller asked for the other colour model (vvio_ffv1_stream_info) */
+static void apply_custom_table(const Config* cf, RangeCoder* c) {     /* coder_type 2 (libavcodec ff_ffv1_init_slice_state) */
+    if (cf->coder == 2)
+        for (int i = 1; i < 256; ++i) { c->one_state[i] = cf->one_state[i]; c->zero_state[256 - i] = (uint8_t)(256 - cf->one_state[i]); }
+}
+
+/* one slice of a version-3 packet: [key-frame bit in the first slice] slice header, samples */
+static int decode_slice_v3(const Config* cf, SliceCtx* sc, const uint8_t* data, int len, int first, int* keyframe, int key_ok, int W, int H,
+                           uint8_t* rgb, uint8_t* const* yuv) {
+    RangeCoder c;
+    uint8_t state[CONTEXT_SIZE];
+    int err = 0;
+    const int nqi = 1 + (cf->chroma_planes ? 1 : 0) + (cf->alpha ? 1 : 0);
+    rc_init_dec(&c, data, len);
+    if (first) {
+        uint8_t keystate = 128;
+        *keyframe = get_rac(&c, &keystate);
+        if (!*keyframe && !key_ok) return -20;         /* a stream cannot start with a non-key frame */
+    }
+    apply_custom_table(cf, &c);
+    memset(state, 128, sizeof(state));
+    const int sx = get_symbol(&c, state, 0, &err), sy = get_symbol(&c, state, 0, &err);
+    const int sw = get_symbol(&c, state, 0, &err) + 1, sh = get_symbol(&c, state, 0, &err) + 1;
+    int qi[3] = {0, 0, 0};
+    for (int i = 0; i < nqi; ++i) qi[i] = get_symbol(&c, state, 0, &err);
+    if (!cf->chroma_planes) { qi[2] = qi[1]; qi[1] = qi[0]; }
+    (void)get_symbol(&c, state, 0, &err); (void)get_symbol(&c, state, 0, &err); (void)get_symbol(&c, state, 0, &err);
+    /* every field came from the file: refuse anything outside the slice grid / the table sets before it indexes memory */
+    if (err || sx < 0 || sy < 0 || sw < 1 || sh < 1 || sx > cf->nh - sw || sy > cf->nv - sh) return -21;
+    for (int i = 0; i < 3; ++i) if (qi[i] < 0 || qi[i] >= cf->nsets) return -21;
+    const int y0 = (int)((int64_t)sy * H / cf->nv), h = (int)((int64_t)(sy + sh) * H / cf->nv) - y0;
+    const int x0 = (int)((int64_t)sx * W / cf->nh), w = (int)((int64_t)(sx + sw) * W / cf->nh) - x0;
+    if (w < 1 || h < 1 || x0 + w > W || y0 + h > H) return -21;
+    return decode_slice_samples(cf, sc, &c, data, len, x0, y0, w, h, qi, *keyframe, W, H, rgb, yuv);
+}
+
+/* versions 0 / 1: the frame header (libavcodec ffv1dec.c read_header, version < 2) behind the key-frame bit of a key frame */
+static int parse_legacy_header(RangeCoder* c, Config* cf) {
+    uint8_t state[CONTEXT_SIZE];
+    int err = 0;
+    memset(cf, 0, sizeof(*cf));
+    memset(state, 128, sizeof(state));
+    cf->version = get_symbol(c, state, 0, &err);
+    if (err || cf->version < 0 || cf->version > 1) return -2;
+    cf->coder = get_symbol(c, state, 0, &err);
+    if (err || cf->coder < 0 || cf->coder > 2) return -3;
+    if (cf->coder == 2) {
+        for (int i = 1; i < 256; ++i) {
+            const int v = get_symbol(c, state, 1, &err) + c->one_state[i];
+            if (err || v < 1 || v > 255) return -3;
+            cf->one_state[i] = (uint8_t)v;
+        }
+    }
+    cf->colorspace = get_symbol(c, state, 0, &err);
+    cf->bits = cf->version > 0 ? get_symbol(c, state, 0, &err) : 8;
+    cf->chroma_planes = get_rac(c, state);
+    cf->hshift = get_symbol(c, state, 0, &err);
+    cf->vshift = get_symbol(c, state, 0, &err);
+    cf->alpha = get_rac(c, state);
+    cf->nh = cf->nv = 1; cf->nsets = 1; cf->ec = 0; cf->intra = 0;
+    int count = 1;
+    for (int t = 0; t < 5; ++t) {
+        const int r = read_quant_table(c, cf->sets[0].quant[t], count);
+        if (r < 0) return -5;
+        count *= r;
+        if (count > MAX_CTX) return -5;
+    }
+    cf->sets[0].context_count = (count + 1) / 2;
+    cf->sets[0].five = cf->sets[0].quant[3][127] || cf->sets[0].quant[4][127];
+    if (err) return -7;
+    if ((cf->colorspace != 0 && cf->colorspace != 1) || (cf->bits != 0 && cf->bits != 8)) return -8;
+    if (cf->colorspace == 0 && (cf->hshift < 0 || cf->hshift > 2 || cf->vshift < 0 || cf->vshift > 2 || (cf->alpha && !cf->chroma_planes))) return -8;
+    return 0;
+}
+
+static int decoder_decode(Decoder* d, const uint8_t* data, int len, int W, int H, uint8_t* rgb, uint8_t* const* yuv) {
+    int r;
+    if (len < 2 || W < 1 || H < 1) return -11;
+    if (d->legacy) {
+        /* versions 0 / 1: ONE range coder for the key-frame bit, the header (key frames) and -- range-coded streams -- the samples */
+        RangeCoder c;
+        uint8_t keystate = 128;
+        rc_init_dec(&c, data, len);
+        const int keyframe = get_rac(&c, &keystate);
+        if (keyframe) {
+            r = parse_legacy_header(&c, &d->cf);
+            if (r < 0) { d->have_cf = 0; d->key_ok = 0; return r; }
+            d->have_cf = 1;
+        } else if (!d->key_ok || !d->have_cf) {
+            return -20;
+        }
+        const Config* cf = &d->cf;
+        if (cf->colorspace == 0 ? !yuv : !rgb) return -9;
+        if (cf->colorspace == 0 && !cf->chroma_planes) {
+            const size_t n = (size_t)((W + (1 << cf->hshift) - 1) >> cf->hshift) * (size_t)((H + (1 << cf->vshift) - 1) >> cf->vshift);
+            memset(yuv[1], 128, n); memset(yuv[2], 128, n);
+        }
+        apply_custom_table(cf, &c);
+        const int qi[3] = {0, 0, 0};
+        r = decode_slice_samples(cf, &d->sl[0], &c, data, len, 0, 0, W, H, qi, keyframe, W, H, rgb, yuv);
+        d->key_ok = r == 0 ? 1 : 0;
+        return r;
+    }
+    const Config* cf = &d->cf;
+    if (cf->colorspace == 0 ? !yuv : !rgb) return -9;
+    if (cf->colorspace == 0 && !cf->chroma_planes) {
+        const size_t n = (size_t)((W + (1 << cf->hshift) - 1) >> cf->hshift) * (size_t)((H + (1 << cf->vshift) - 1) >> cf->vshift);
+        memset(yuv[1], 128, n); memset(yuv[2], 128, n);
+    }
     /* walk the slices from the END of the packet: [... slice][size:3][status:1 crc:4 when ec] */
     const int trailer = 3 + (cf->ec ? 5 : 0);
     int end = len, nslices = 0;
-    int starts[1024], lens[1024];
+    static const int cap = MAX_SLICES;
+    int* starts = (int*)malloc(sizeof(int) * 2 * (size_t)cap);
+    if (!starts) return -23;
+    int* lens = starts + cap;
+    r = 0;
     while (end > 0) {
-        if (end < trailer) { free(cf); return -11; }
+        if (end < trailer) { r = -11; break; }
         const uint8_t* t = data + end - trailer;
         const int size = (t[0] << 16) | (t[1] << 8) | t[2];
         const int total = size + trailer;
-        if (total > end || nslices >= 1024) { free(cf); return -12; }
-        if (cf->ec && crc32_mpeg(data + end - total, total) != 0) { free(cf); return -13; }
+        if (total > end || nslices >= cap) { r = -12; break; }
+        if (cf->ec && crc32_mpeg(data + end - total, total) != 0) { r = -13; break; }
         starts[nslices] = end - total; lens[nslices] = size; nslices++;
         end -= total;
     }
-    for (int i = nslices - 1, k = 0; i >= 0; --i, ++k) {
-        r = decode_slice(cf, data + starts[i], lens[i], k == 0, W, H, rgb, yuv);
-        if (r < 0) { free(cf); return r; }
-    }
-    free(cf);
+    int keyframe = 0;
+    for (int i = nslices - 1, k = 0; !r && i >= 0; --i, ++k)
+        r = decode_slice_v3(cf, &d->sl[k], data + starts[i], lens[i], k == 0, &keyframe, d->key_ok, W, H, rgb, yuv);
+    free(starts);
+    d->key_ok = r == 0 ? 1 : 0;
+    return r;
+}
+
+/* ---- the stateful decoder object (non-key frames continue from the previous frame's context states) ------------------------------------- */
+/* cfg / cfglen: the stream's configuration record (Matroska CodecPrivate) -- version 3; cfglen == 0: a version 0 / 1 stream (parameters in the
+ * key frames).  *status = 0 or the error code.  Returns an opaque handle or NULL */
+void* vvio_ffv1_decoder_open(const uint8_t* cfg, int cfglen, int* status) {
+    Decoder* d = (Decoder*)calloc(1, sizeof(Decoder));
+    int r = 0;
+    if (!d) r = -1;
+    else if (cfglen <= 0) d->legacy = 1;
+    else if (cfglen < 5 || crc32_mpeg(cfg, cfglen) != 0) r = -10;
+    else { r = parse_config(cfg, cfglen - 4, &d->cf); d->have_cf = r == 0; }
+    if (r < 0) { free(d); d = 0; }
+    if (status) *status = r;
+    return d;
+}
+void vvio_ffv1_decoder_close(void* h) {
+    Decoder* d = (Decoder*)h;
+    if (!d) return;
+    for (int i = 0; i < MAX_SLICES; ++i) slice_ctx_free(&d->sl[i]);
+    free(d);
+}
+/* info[7] = colorspace_type (0 YCbCr, 1 RGB), chroma_planes, log2_h_chroma_subsample, log2_v_chroma_subsample, extra_plane, bits_per_raw_sample,
+ * version; -30 while the parameters are not known yet (version 0 / 1 before the first key frame) */
+int vvio_ffv1_decoder_info(void* h, int* info) {
+    Decoder* d = (Decoder*)h;
+    if (!d || !info) return -1;
+    if (!d->have_cf) return -30;
+    const Config* cf = &d->cf;
+    info[0] = cf->colorspace; info[1] = cf->chroma_planes; info[2] = cf->hshift; info[3] = cf->vshift; info[4] = cf->alpha; info[5] = cf->bits ? cf->bits : 8;
+    info[6] = cf->version;
     return 0;
+}
+/* the next packet of the stream, in stream order.  RGB streams fill rgb (W*H*3) and return 0; planar YCbCr streams fill y / cb / cr and
+ * return 1 (gray streams: cb = cr = 128); negative = error code (both buffer kinds may be passed: the stream decides) */
+int vvio_ffv1_decoder_decode(void* h, const uint8_t* data, int len, int W, int H, uint8_t* rgb, uint8_t* y, uint8_t* cb, uint8_t* cr) {
+    Decoder* d = (Decoder*)h;
+    if (!d || !data) return -1;
+    uint8_t* planes[3] = {y, cb, cr};
+    const int r = decoder_decode(d, data, len, W, H, rgb, (y && cb && cr) ? planes : 0);
+    if (r < 0) return r;
+    return d->cf.colorspace == 0 ? 1 : 0;
+}
+
+/* ---- stateless entry points: one KEY frame of a version-3 stream ---------------------------------------------------------------------------- */
+static int decode_frame_any(const uint8_t* cfg, int cfglen, const uint8_t* data, int len, int W, int H, uint8_t* rgb, uint8_t* const* yuv) {
+    int r = 0;
+    if (cfglen <= 0) return -10;
+    Decoder* d = (Decoder*)vvio_ffv1_decoder_open(cfg, cfglen, &r);
+    if (!d) return r;
+    if ((d->cf.colorspace == 0) != (yuv != 0)) { vvio_ffv1_decoder_close(d); return -9; }      /* the caller asked for the other colour model (vvio_ffv1_stream_info) */
+    r = decoder_decode(d, data, len, W, H, rgb, yuv);
+    vvio_ffv1_decoder_close(d);
+    return r;
 }
 
 /* FFV1 packet + configuration record -> RGB24 (W*H*3 bytes).  0 = ok, negative = error code */
@@ -728,14 +907,7 @@ int vvio_ffv1_stream_info(const uint8_t* cfg, int cfglen, int* info) {
 
 /* planar 8-bit YCbCr stream (colorspace_type 0) -> Y [H][W], Cb / Cr [ceil(H >> vshift)][ceil(W >> hshift)] (gray streams: Cb = Cr = 128) */
 int vvio_ffv1_decode_frame_yuv(const uint8_t* cfg, int cfglen, const uint8_t* data, int len, int W, int H, uint8_t* y, uint8_t* cb, uint8_t* cr) {
-    int info[6];
-    int r = vvio_ffv1_stream_info(cfg, cfglen, info);
-    if (r < 0) return r;
     if (!y || !cb || !cr) return -1;
-    if (!info[1]) {
-        const size_t n = (size_t)((W + (1 << info[2]) - 1) >> info[2]) * (size_t)((H + (1 << info[3]) - 1) >> info[3]);
-        memset(cb, 128, n); memset(cr, 128, n);
-    }
     uint8_t* planes[3] = {y, cb, cr};
     return decode_frame_any(cfg, cfglen, data, len, W, H, 0, planes);
 }
@@ -773,4 +945,4 @@ int vvio_ycbcr_to_rgb(const uint8_t* y, const uint8_t* cb, const uint8_t* cr, in
     return 0;
 }
 
-int vvio_abi_version(void) { return 2; }
+int vvio_abi_version(void) { return 3; }

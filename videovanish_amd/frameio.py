@@ -32,9 +32,16 @@ def _io():
             raise RuntimeError(f"videovanish_amd: frame I/O codec missing ({_LIB_PATH}); run videovanish_amd/csrc/build.sh")
         L = C.CDLL(_LIB_PATH)
         for name in ("vvio_abi_version", "vvio_ffv1_config_record", "vvio_ffv1_encode_frame", "vvio_ffv1_decode_frame", "vvio_ffv1_stream_info",
-                     "vvio_ffv1_decode_frame_yuv", "vvio_ycbcr_to_rgb"):
+                     "vvio_ffv1_decode_frame_yuv", "vvio_ycbcr_to_rgb", "vvio_ffv1_decoder_open", "vvio_ffv1_decoder_info", "vvio_ffv1_decoder_decode",
+                     "vvio_ffv1_decoder_close"):
             if not hasattr(L, name):
                 raise RuntimeError(f"libvvio.so does not export {name}")
+        L.vvio_ffv1_decoder_open.restype = C.c_void_p
+        L.vvio_ffv1_decoder_open.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.vvio_ffv1_decoder_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.vvio_ffv1_decoder_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vvio_ffv1_decoder_close.argtypes = [C.c_void_p]
+        L.vvio_ffv1_decoder_close.restype = None
         _lib = L
     return _lib
 
@@ -60,10 +67,13 @@ def ffv1_encode(frame_rgb, num_v_slices=1):
     return out[:n].tobytes()
 
 
-_REASONS = {-10: "configuration record CRC mismatch", -2: "FFV1 version < 3", -3: "bad coder_type / state-transition table",
+_REASONS = {-10: "configuration record CRC mismatch", -2: "not an FFV1 version this entry point decodes (version 0 / 1 streams have no configuration record: "
+                                                           "use Ffv1Decoder; version 2 was never released)",
+            -26: "FFV1 version > 3 (or a micro_version beyond RFC 9043): other slice header / context rules, not decoded",
+            -30: "stream parameters not known before the first key frame", -3: "bad coder_type / state-transition table",
             -6: "coded initial states are not supported", -8: "only 8-bit streams (RGB, or YCbCr with subsampling factors <= 4) are supported",
             -9: "stream colour model does not match the decoder entry point", -21: "slice header out of range", -25: "corrupt sample data",
-            -13: "slice CRC mismatch", -20: "not a key frame"}
+            -13: "slice CRC mismatch", -20: "non-key frame without a preceding key frame (or with mismatching context states)"}
 
 
 def ffv1_stream_info(config):
@@ -130,6 +140,50 @@ def ffv1_decode(config, packet, W, H):
     if r != 0:
         raise RuntimeError(f"FFV1 decode failed ({r}): {_REASONS.get(r, 'malformed stream')}")
     return out
+
+
+class Ffv1Decoder:
+    """The decoder of ONE stream, fed packet by packet in stream order (vvio_ffv1_decoder_*): non-key frames continue from the context states the
+    previous frame left, and version 0 / 1 streams (config = b"": no configuration record) learn their parameters from the first key frame.
+    decode(packet) -> RGB uint8 [H, W, 3] (planar YCbCr streams are colour converted on the host, BT.601 limited range)."""
+
+    def __init__(self, config, W, H):
+        self.W, self.H = int(W), int(H)
+        st = C.c_int(0)
+        cfg = (C.c_uint8 * max(1, len(config))).from_buffer_copy(config if config else b"\x00")
+        self._h = _io().vvio_ffv1_decoder_open(cfg, len(config), C.byref(st))
+        if not self._h:
+            raise RuntimeError(f"FFV1 configuration record rejected ({st.value}): {_REASONS.get(st.value, 'malformed stream')}")
+
+    def info(self):
+        info = (C.c_int * 7)()
+        r = _io().vvio_ffv1_decoder_info(self._h, info)
+        if r != 0:
+            raise RuntimeError(f"FFV1 stream info unavailable ({r}): {_REASONS.get(r, 'malformed stream')}")
+        return dict(zip(("colorspace", "chroma_planes", "hshift", "vshift", "alpha", "bits", "version"), list(info)))
+
+    def decode(self, packet):
+        W, H = self.W, self.H
+        rgb = np.empty((H, W, 3), np.uint8)
+        y, cb, cr = np.empty((H, W), np.uint8), np.empty((H, W), np.uint8), np.empty((H, W), np.uint8)      # chroma: at most the luma size
+        pkt = (C.c_uint8 * max(1, len(packet))).from_buffer_copy(packet if packet else b"\x00")
+        r = _io().vvio_ffv1_decoder_decode(self._h, pkt, len(packet), W, H, rgb.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
+                                           cb.ctypes.data_as(C.c_void_p), cr.ctypes.data_as(C.c_void_p))
+        if r < 0:
+            raise RuntimeError(f"FFV1 decode failed ({r}): {_REASONS.get(r, 'malformed stream')}")
+        if r == 0:
+            return rgb
+        i = self.info()
+        cw, ch = (W + (1 << i["hshift"]) - 1) >> i["hshift"], (H + (1 << i["vshift"]) - 1) >> i["vshift"]
+        cbv, crv = cb.reshape(-1)[:cw * ch].reshape(ch, cw), cr.reshape(-1)[:cw * ch].reshape(ch, cw)
+        return ycbcr_to_rgb(y, cbv, crv, i["hshift"], i["vshift"])
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _io().vvio_ffv1_decoder_close(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 # ---- YUV4MPEG2 (.y4m): uncompressed planar YCbCr, what `ffmpeg -i any.mp4 out.y4m` writes ---------------------------------------------
@@ -217,7 +271,7 @@ ID_PIXELW, ID_PIXELH, ID_COLOURSPACE = b"\xb0", b"\xba", b"\x2e\xb5\x24"
 ID_TIMECODE, ID_SIMPLEBLOCK, ID_BLOCKGROUP, ID_BLOCK = b"\xe7", b"\xa3", b"\xa0", b"\xa1"
 
 
-def write_mkv_packets(path, W, H, config, packets, fps):
+def write_mkv_packets(path, W, H, config, packets, fps, key_frames=None):
     """mux FFV1 packets (one key frame each) + their configuration record into a Matroska file (V_FFV1)."""
     packets = list(packets)
     fps = float(fps) if fps and fps > 0 else 25.0
@@ -228,7 +282,7 @@ def write_mkv_packets(path, W, H, config, packets, fps):
                _el(ID_DURATION, struct.pack(">d", len(packets) * 1000.0 / fps)))
     video = _el(ID_VIDEO, _el(ID_PIXELW, _uint(W)) + _el(ID_PIXELH, _uint(H)))
     track = _el(ID_TRACKENTRY, _el(ID_TRACKNUM, _uint(1)) + _el(ID_TRACKUID, _uint(1)) + _el(ID_TRACKTYPE, _uint(1)) + _el(ID_FLAGLACING, _uint(0)) +
-                _el(ID_CODECID, b"V_FFV1") + _el(ID_CODECPRIVATE, config) + _el(ID_DEFAULTDURATION, _uint(dur_ns)) + video)
+                _el(ID_CODECID, b"V_FFV1") + (_el(ID_CODECPRIVATE, config) if config else b"") + _el(ID_DEFAULTDURATION, _uint(dur_ns)) + video)
     with open(path, "wb") as f:
         f.write(head)
         f.write(ID_SEGMENT + b"\x01\xff\xff\xff\xff\xff\xff\xff")          # unknown size: clusters are streamed
@@ -240,7 +294,8 @@ def write_mkv_packets(path, W, H, config, packets, fps):
             blocks = []
             for i in range(c0, min(len(packets), c0 + per_cluster)):
                 rel = int(round(i * 1000.0 / fps)) - t0
-                blocks.append(_el(ID_SIMPLEBLOCK, b"\x81" + struct.pack(">h", rel) + b"\x80" + packets[i]))     # track 1, key frame
+                key = key_frames is None or key_frames[i]
+                blocks.append(_el(ID_SIMPLEBLOCK, b"\x81" + struct.pack(">h", rel) + (b"\x80" if key else b"\x00") + packets[i]))     # track 1, key-frame flag
             f.write(_el(ID_CLUSTER, _el(ID_TIMECODE, _uint(t0)) + b"".join(blocks)))
 
 
@@ -327,8 +382,12 @@ def read_mkv(path, start_frame=0, max_frames=-1):
                     if num != want["num"]:
                         continue
                     payload = bytes(buf[p + 3: blk[1]])
-                    if idx >= start_frame and (max_frames <= 0 or len(frames) < max_frames):
-                        frames.append(_decode_payload(want, payload))
+                    # FFV1 streams may hold non-key frames (adaptive states continue from the previous frame): every packet up to the last wanted
+                    # one is decoded in order, the ones before start_frame are dropped
+                    if max_frames <= 0 or len(frames) < max_frames:
+                        fr = _decode_payload(want, payload, keep=idx >= start_frame)
+                        if idx >= start_frame:
+                            frames.append(fr)
                     idx += 1
                     if max_frames > 0 and len(frames) >= max_frames:
                         break
@@ -339,20 +398,28 @@ def read_mkv(path, start_frame=0, max_frames=-1):
     return frames, fps
 
 
-def _decode_payload(tr, payload):
+def _ffv1_track_decoder(tr, config):
+    if "_ffv1" not in tr:
+        tr["_ffv1"] = Ffv1Decoder(config, tr["W"], tr["H"])
+    return tr["_ffv1"]
+
+
+def _decode_payload(tr, payload, keep=True):
     codec, W, H = tr.get("codec", ""), tr["W"], tr["H"]
     if codec == "V_FFV1":
-        return ffv1_decode(tr["private"], payload, W, H)
+        return _ffv1_track_decoder(tr, tr.get("private", b"")).decode(payload)       # no CodecPrivate: an FFV1 version 0 / 1 stream
     if codec == "V_MS/VFW/FOURCC":
         priv = tr.get("private", b"")
         if len(priv) >= 40 and priv[16:20] == b"FFV1":
-            return ffv1_decode(priv[40:], payload, W, H)           # BITMAPINFOHEADER (40 bytes) + FFV1 configuration record
+            return _ffv1_track_decoder(tr, priv[40:]).decode(payload)               # BITMAPINFOHEADER (40 bytes) [+ FFV1 configuration record: version 3]
         raise RuntimeError(f"unsupported VFW codec {priv[16:20]!r}: this reader decodes FFV1 and uncompressed RGB only")
+    if not keep:
+        return None
     if codec == "V_UNCOMPRESSED":
         fourcc = tr.get("fourcc", b"RGB\x18")
         a = np.frombuffer(payload, np.uint8)[: H * W * 3].reshape(H, W, 3)
         return a[..., ::-1].copy() if fourcc.startswith(b"BGR") else a.copy()
-    raise RuntimeError(f"unsupported codec {codec!r}: this reader decodes FFV1 (v3, 8-bit RGB or planar YCbCr) and uncompressed RGB in Matroska, and .y4m")
+    raise RuntimeError(f"unsupported codec {codec!r}: this reader decodes FFV1 (versions 0 / 1 / 3, 8-bit RGB or planar YCbCr) and uncompressed RGB in Matroska, and .y4m")
 
 
 # ---- the reference's tools.py API ----------------------------------------------------------------------------------------

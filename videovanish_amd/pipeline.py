@@ -462,8 +462,11 @@ class DiffuEraserHIP:
                 done[0] += 1
                 progress(done[0], n_my * n)
 
-        def worker(stream):
+        def worker(stream, delay):
             try:
+                if delay > 0:
+                    import time
+                    time.sleep(delay)
                 torch.cuda.set_device(dev)             # a new host thread starts on device 0: one process per GPU sets LOCAL_RANK's device
                 Denoiser.lane.concurrent = True        # (thread-local) one stream per chunk while several chunks are in flight
                 stream.wait_stream(main)               # the inputs were produced on the launching stream
@@ -480,7 +483,7 @@ class DiffuEraserHIP:
             except BaseException as exc:               # re-raised on the launching thread
                 errors.append(exc)
 
-        threads = [threading.Thread(target=worker, args=(pool[i],), name=f"vv-chunk-lane-{i}") for i in range(lanes)]
+        threads = [threading.Thread(target=worker, args=(pool[i], i * float(self.run.lane_stagger_s)), name=f"vv-chunk-lane-{i}") for i in range(lanes)]
         for t in threads:
             t.start()
         for t in threads:
