@@ -217,6 +217,7 @@ def main():
                     "(RunConfig.concurrent_chunks; default: the product default)")
     ap.add_argument("--one-stream", action="store_true", help="A/B: the round-3 schedule (one chunk at a time, BrushNet and UNet on one stream)")
     ap.add_argument("--dump-kernels", default=None, help="write the raw per-kernel table (launches, seconds, flops, bytes) to this JSON file")
+    ap.add_argument("--profile-shapes", action="store_true", help="per-kernel keys carry the GEMM / attention shapes (M, N, K): tools/shape_table.py")
     args = ap.parse_args()
     if args.one_stream:
         from videovanish_amd import unet as _unet
@@ -237,6 +238,7 @@ def main():
         dist = (rank, world)
 
     from videovanish_amd import hip
+    hip.PROFILE_SHAPES = bool(args.profile_shapes)
     from videovanish_amd.config import SMALL_UNET, SMALL_VAE, TINY_UNET, TINY_VAE, RunConfig, UNetConfig, VAEConfig
     from videovanish_amd.pipeline import DiffuEraserHIP, chunk_plan, shard_chunks
     ucfg, vcfg = {"full": (UNetConfig(), VAEConfig()), "small": (SMALL_UNET, SMALL_VAE), "tiny": (TINY_UNET, TINY_VAE)}[args.arch]
@@ -368,7 +370,7 @@ def main():
         "kernel_times_s": {k: [v[0], round(v[1], 3), round(v[2] / v[1] / 1e12, 1) if v[2] else round(v[3] / v[1] / 1e9, 1)] for k, v in
                            sorted(kernels.items(), key=lambda kv: -kv[1][1])},
     }
-    if args.dump_kernels:      # raw per-key table (launches, seconds, flops, algorithmic bytes); with VV_PROFILE_SHAPES=1 the GEMM keys carry M,N,K
+    if args.dump_kernels:      # raw per-key table (launches, seconds, flops, algorithmic bytes); with --profile-shapes the GEMM keys carry M,N,K
         json.dump(kernels, open(args.dump_kernels, "w"))
     print(json.dumps(res))
     if world > 1:

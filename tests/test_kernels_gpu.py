@@ -501,3 +501,43 @@ def test_ycbcr_to_rgb_gpu_equals_host(gpu, hs, vs, tmp_path):
                 f.write(b"FRAME\n" + y[t].tobytes() + cb[t].tobytes() + cr[t].tobytes())
         frames, fps = FIO.load_video_frames_from_path(p)
         assert fps == 25.0 and all(np.array_equal(a, b) for a, b in zip(frames, FIO.ycbcr_to_rgb(y, cb, cr, 1, 1, False, device=False)))
+
+
+@pytest.mark.parametrize("orders", [12, 13, 16, 20])
+def test_attention_d40_heavy_tail(gpu, orders):
+    """The shape real softmax logits take and random-init weights never produce: N = 14400 keys, ONE key -- a member of the kernel's 64-key sample
+    (keys 0, 225, 450, ...) -- 12 .. 20 binary orders above a bulk of thousands of keys that still carries part of the softmax mass (12 / 13 orders:
+    78 % / 64 % of it; 16: 18 %; 20: 1.4 %).  The optimistic reference of attn40 / attn40q2 is fixed from the sample maximum: with P = 2^-4 there
+    (round 3) the bulk went subnormal / to zero in fp16; with P = 2^4 (round 4) it keeps full precision.  fp16, 6 ulp of the output range, against
+    an fp64 softmax; both kernels (N >= 1024 -> 64 queries per wave; the first 640 queries through a second, short launch -> 32 per wave)."""
+    from videovanish_amd import hip
+    td, dt, ulp = torch.float16, hip.F16, 2 ** -11
+    g = torch.Generator().manual_seed(100 + orders)
+    B, heads, N, D = 1, 8, 14400, 40
+    C = heads * D
+    u = torch.nn.functional.normalize(torch.randn(B, 1, heads, D, generator=g), dim=-1)
+    q = 3.0 * u + 0.05 * torch.randn(B, N, heads, D, generator=g)                 # every query looks along u: c q.u ~ 3 (log2 units after the scale below)
+    k = 0.3 * torch.randn(B, N, heads, D, generator=g)                            # the bulk: scores within a few binary orders of 0
+    v = torch.randn(B, N, heads, D, generator=g)
+    k[:, 225 * 7] = u[:, 0] * (orders / 3.0)                                      # the outlier (sampled: key 1575): c q.k ~ orders above the bulk
+    v[:, 225 * 7] = 5.0                                                           # ... with a value the bulk must pull away from
+    qs, k, v = (t.to(td).float() for t in (q, k, v))                              # q is used pre-scaled: scores = q.k directly, in log2 units
+    s = torch.einsum("bqhd,bkhd->bhqk", qs.double(), k.double())
+    gap = (s[..., 225 * 7] - s[..., :225].amax(-1)).min()
+    assert gap > orders - 4                                                       # the construction holds for every query
+    pr = torch.exp2(s - s.amax(-1, keepdim=True))
+    bulk_share = 1.0 - (pr[..., 225 * 7] / pr.sum(-1)).mean().item()
+    ref = torch.einsum("bhqk,bkhd->bqhd", pr / pr.sum(-1, keepdim=True), v.double()).float()
+    hm = torch.stack([qs, k, v], 1).permute(0, 1, 3, 2, 4).contiguous().to(td).to(gpu)
+    out = torch.empty(B, N, C, dtype=td, device=gpu)
+    args = dict(B=B, heads=heads, Nkv=N, D=D, q_bs=3 * N * C, k_bs=3 * N * C, v_bs=3 * N * C, o_bs=N * C, q_rs=D, k_rs=D, v_rs=D, o_rs=C, k_off=N * C,
+                v_off=2 * N * C, q_hs=N * D, k_hs=N * D, v_hs=N * D, q_prescaled=True)
+    hip.attention(dt, hm, hm, hm, out, Nq=N, **args)
+    got = out.float().cpu().reshape(B, N, heads, D)
+    out32 = torch.empty(B, N, C, dtype=td, device=gpu)
+    hip.attention(dt, hm, hm, hm, out32, Nq=640, **args)                          # Nq < 1024: the 32-queries-per-wave kernel (no own-key sample: Nq != Nkv)
+    got32 = out32.float().cpu().reshape(B, N, heads, D)[:, :640]
+    tol = 6 * ulp * max(1.0, ref.abs().max().item())
+    e64, e32 = (got - ref).abs().max().item(), (got32 - ref[:, :640]).abs().max().item()
+    print(f"attention d40 heavy tail [{orders} orders, bulk share {bulk_share:.3f}]: max-abs {e64:.2e} (64 q / wave), {e32:.2e} (32 q / wave), tol {tol:.2e}")
+    assert torch.isfinite(got).all() and e64 <= tol and e32 <= tol

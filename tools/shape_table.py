@@ -1,4 +1,4 @@
-"""Per-shape kernel table from `VV_PROFILE_SHAPES=1 python bench.py --dump-kernels F`: time against a simple floor
+"""Per-shape kernel table from `python bench.py --profile-shapes --dump-kernels F`: time against a simple floor
 max(flops / 1.25 PFLOP/s, algorithmic bytes / 6 TB/s) -- ranks the shapes by the time they spend above that floor.
     shape_table.py A.json [B.json sa sb]   with B: per-denoise-step table = (B - A) / (sb - sa)  (the VAE / prior kernels cancel)"""
 import json, sys

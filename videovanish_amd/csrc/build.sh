@@ -24,8 +24,14 @@ done
 # (no v_accvgpr_read/write traffic); large head dims need the AGPR half of the register file
 compile vv_attn vv_attn_small -DVV_ATTN_PART=0 -mllvm -amdgpu-mfma-vgpr-form $AB
 compile vv_attn vv_attn_large -DVV_ATTN_PART=1 $AB
+if [ -n "$VV_AB" ]; then      # lab build: every attention A/B variant and timing probe (VV_ATTN_VARIANT), kept out of the product sources
+  compile vv_attn_lab vv_attn_lab_small -DVV_ATTN_PART=0 -mllvm -amdgpu-mfma-vgpr-form $AB
+  compile vv_attn_lab vv_attn_lab_large -DVV_ATTN_PART=1 $AB
+else
+  rm -f build/vv_attn_lab_small.o build/vv_attn_lab_large.o
+fi
 for p in "${pids[@]}"; do wait $p; done
-rm -f build/vv_attn.o
+rm -f build/vv_attn.o build/vv_attn_lab.o
 hipcc --offload-arch=gfx950 -shared -fPIC -o libvvhip.so build/*.o
 echo "built $(pwd)/libvvhip.so"
 # host-side frame I/O codec (FFV1, plain C, no GPU): libvvio.so

@@ -1,3 +1,6 @@
+// LAB BUILD ONLY (VV_AB=1 build.sh; not part of the product library): the complete round-1..3 attention file with every A/B variant and timing probe
+// (VV_ATTN_VARIANT, tools/attn_ab.sh, tools/pmc_attn.sh; results: profiles/r*_attn*).  The product kernels live in vv_attn.hip, which calls
+// vv_attention_lab() when VV_ATTN_VARIANT is set in a lab build.
 // K3/K4/K5: flash attention on MFMA for gfx950 (spatial self-attention, 77-token cross-attention, temporal
 // attention over the frame axis, VAE mid-block attention).  See include/vvhip.h (vv_attention).
 //
@@ -39,26 +42,44 @@ __device__ __forceinline__ void glds16_asm(const void* gptr, void* lds_wave_base
 // softmax of tile k, ONE barrier per tile, no staging registers); DMA = false: register staged through dynamic LDS.
 // KIND only names the instantiation (0 spatial self-attention, 1 cross-attention to the text tokens; temporal attention has its own
 // tile shape): profilers then report the launches of each use separately (profiles/*_kernel_stats.csv).
-template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0>
+//
+// LAZY = true (needs DMA and a spare K-dim pad slot, i.e. D % 32 != 0): the softmax reference maximum is subtracted ON THE MATRIX PIPE and
+// is only refreshed when it is about to matter.  Q is held pre-multiplied by scale * log2(e); the first two zero-padded k slots of
+// every Q row carry -m split into hi + lo h16 parts and the same slots of every K row are 1.0 (written once, the LDS-DMA never touches
+// them), so the QK^T MFMAs deliver x = c q.k - m directly and P = exp2(x) needs neither the per-tile row maximum (13 v_max per 16
+// queries) nor the scale-and-shift (8 v_pk_fma).  m is allowed to lag the true running maximum by < 1 (P < 2: harmless in h16, the
+// denominator rides the ONES column of V in fp32): a tile whose packed P has any value >= 2.0 -- one OR tree over the packed registers,
+// bit 14 is the top exponent bit of both h16 formats -- takes the slow path (wave-uniform branch: QK^T again, classic maximum, rescale
+// of O^T, new pad slots).  Tile 0 always takes it.  Results equal the classic form up to the rounding of c*q to h16.
+// Range: the reference maximum itself has to fit the h16 format (|c q.k| < 65504 for fp16 operands; bf16 has the fp32 range) -- far beyond what
+// LayerNorm-ed attention inputs produce (|c q.k| of a few tens); the classic kernel (every other head dim) keeps the maximum in fp32.
+template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0, bool LAZY = false, int HACK = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params p, const int nqt) {
     constexpr int DK = (D + 31) / 32 * 32, DKC = DK / 8, KS = DK / 32;
     constexpr int DV = (D + 15) / 16 * 16, DVC = DV / 8, NDT = DV / 16;
     constexpr int KT = KVT / 16, US = KVT / 32;
-    constexpr int PK = DK * 2 + 32, PV = DV * 2 + ((DV * 2) % 64 == 0 ? 32 : 0);      // conflict-free ds_read_b128 / ds_read_b64_tr_b16 (bank model: tools/lds_bank_model.py)
+    // conflict-free ds_read_b128 / ds_read_b64_tr_b16 (bank model: tools/lds_bank_model.py).  SHORTK (LAZY, d = 40): a K row in LDS is only
+    // its 5 data chunks + the constant chunk (96 B, also conflict free); the k slots 48..63 the second MFMA slab still reads alias the
+    // first 32 B of the NEXT row -- finite numbers that meet the zeros of Q's padding -- so a K tile takes 6 LDS-DMA wave instructions
+    // instead of 10 (the fill time follows the instruction count, masked lanes are not free: tools/attn_fill_rate.hip)
+    constexpr bool SHORTK = LAZY && D == 40 && HACK != 8;
+    constexpr int PK = SHORTK ? 96 : DK * 2 + 32, PV = DV * 2 + ((DV * 2) % 64 == 0 ? 32 : 0);
     constexpr int NT = NW * 64;
     constexpr int KCH = (KVT * DKC + NT - 1) / NT, VCH = (KVT * DVC + NT - 1) / NT;
     constexpr int BQ = NW * QT * 16;
     // spare zero-padded V column (d = 40 -> 48): put 1.0 there, then row D of O^T accumulates sum_k P = the softmax
     // denominator on the MATRIX pipe instead of 16 packed adds per tile on the (issue-bound) VALU
     constexpr bool ONES = DV > D;
+    static_assert(!LAZY || (DMA && ONES && DK - D >= 2 && D % 8 == 0), "LAZY needs the DMA path, the ONES column and two spare k slots");
+    constexpr int PS = D / 32, PLG = (D % 32) / 8;       // LAZY: the pad slots D, D+1 live in qf[.][PS].x of the lanes with lg == PLG
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sK = smem;
     unsigned char* sV = smem + KVT * PK;
     constexpr int NSK = KVT * PK / 16, NSV = KVT * PV / 16;            // 16-byte LDS slots per K / V tile (multiples of 64)
     constexpr int KP = (NSK + NT - 1) / NT, VP = (NSV + NT - 1) / NT;  // DMA passes
     static_assert(!DMA || (NSK % 64 == 0 && NSV % 64 == 0), "K/V tile must be whole 1 KB wave blocks");
-    __shared__ __attribute__((aligned(1024))) unsigned char dK0[DMA ? KVT * PK : 16];
-    __shared__ __attribute__((aligned(1024))) unsigned char dK1[DMA ? KVT * PK : 16];
+    __shared__ __attribute__((aligned(1024))) unsigned char dK0[DMA ? KVT * PK + (SHORTK ? 64 : 0) : 16];      // SHORTK: the last row's alias reads stay inside
+    __shared__ __attribute__((aligned(1024))) unsigned char dK1[DMA ? KVT * PK + (SHORTK ? 64 : 0) : 16];
     __shared__ __attribute__((aligned(1024))) unsigned char dV0[DMA ? KVT * PV : 16];
     __shared__ __attribute__((aligned(1024))) unsigned char dV1[DMA ? KVT * PV : 16];
 
@@ -91,6 +112,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
         for (int s = 0; s < KS; ++s) {
             const int q = q0 + j * 16 + li, d0 = s * 32 + lg * 8;
             qf[j][s] = (q < p.Nq && d0 < D) ? *(const uint4*)(Q + (int64_t)q * p.q_rs + d0) : make_uint4(0, 0, 0, 0);
+            if (LAZY && !p.q_prescaled) {
+                float qv[8];
+                unpack8<T>(qf[j][s], qv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qv[e] *= p.scale * 1.4426950408889634f;
+                qf[j][s] = pack8<T>(qv);
+            }
         }
 
     f32x4 oacc[NDT][QT];
@@ -100,7 +128,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
         for (int j = 0; j < QT; ++j) oacc[d][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float mrun[QT], lrun[QT];
 #pragma unroll
-    for (int j = 0; j < QT; ++j) { mrun[j] = -1e30f; lrun[j] = 0.f; }
+    for (int j = 0; j < QT; ++j) { mrun[j] = LAZY ? 0.f : -1e30f; lrun[j] = 0.f; }
     const float c = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
 
     uint4 rk[KCH], rv[VCH];
@@ -155,7 +183,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
                 for (int kt = 0; kt < KT; ++kt) {
                     const uint4 kf = *(const uint4*)(sK + (kt * 16 + li) * PK + (s * 4 + lg) * 16);
 #pragma unroll
-                    for (int j = 0; j < QT; ++j) sacc[kt][j] = T::mfma(kf, qf[j][s], sacc[kt][j]);
+                    for (int j = 0; j < QT; ++j) { if (HACK == 4) sacc[kt][j][0] += __builtin_bit_cast(float, kf.x ^ qf[j][s].x) * 1e-30f; else sacc[kt][j] = T::mfma(kf, qf[j][s], sacc[kt][j]); }
                 }
             }
             if (MASK) {
@@ -181,11 +209,68 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
                     const uint2 hi = ds_read_tr16(a0 + 16 * PV);
                     const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
 #pragma unroll
-                    for (int j = 0; j < QT; ++j) oacc[d][j] = T::mfma(vf, pb[u][j], oacc[d][j]);
+                    for (int j = 0; j < QT; ++j) { if (HACK == 3) oacc[d][j][0] += __builtin_bit_cast(float, vf.x ^ pb[u][j].x); else oacc[d][j] = T::mfma(vf, pb[u][j], oacc[d][j]); }
                 }
             }
         };
         qk();
+        if constexpr (LAZY) {
+            // ---- fast path: x = c q.k - m came off the matrix pipe; P = exp2(x), packed
+            unsigned any = 0;
+#pragma unroll
+            for (int j = 0; j < QT; ++j) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[kt][j][r] = HACK == 2 ? sacc[kt][j][r] * 0.01f : __builtin_amdgcn_exp2f(sacc[kt][j][r]);
+#pragma unroll
+                for (int u = 0; u < US; ++u) {
+                    pb[u][j] = make_uint4(pack2<T>(sacc[2 * u][j][0], sacc[2 * u][j][1]), pack2<T>(sacc[2 * u][j][2], sacc[2 * u][j][3]),
+                                          pack2<T>(sacc[2 * u + 1][j][0], sacc[2 * u + 1][j][1]), pack2<T>(sacc[2 * u + 1][j][2], sacc[2 * u + 1][j][3]));
+                    any |= pb[u][j].x | pb[u][j].y | pb[u][j].z | pb[u][j].w;
+                }
+            }
+            const bool slow = it == 0 || __builtin_amdgcn_ballot_w64((any & 0x40004000u) != 0) != 0;      // wave-uniform
+            if (slow) {
+                qk();          // the scores again (relative to the old m; tile 0: m = 0)
+#pragma unroll
+                for (int j = 0; j < QT; ++j) {
+                    float mx = sacc[0][j][0];
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kt][j][r]);
+                    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), (16 << 10) | 0x1f)));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    if (it != 0) mx = fmaxf(mx, 0.f);                      // the reference only ever rises
+                    // new reference = the h16 hi + lo pair nearest to m + mx; the shift applied now is the difference of the two
+                    // REPRESENTED references, so this tile, the rescaled O^T and every later tile agree exactly
+                    const float target = mrun[j] + mx;
+                    const unsigned short hi = T::from_f32(-target);
+                    const unsigned short lo = T::from_f32(-target - T::to_f32(hi));
+                    const float mnew = -(T::to_f32(hi) + T::to_f32(lo));
+                    const float shift = mnew - mrun[j];
+                    mrun[j] = mnew;
+                    if (lg == PLG) qf[j][PS].x = (unsigned)hi | ((unsigned)lo << 16);
+                    if (it != 0) {
+                        const float alpha = __builtin_amdgcn_exp2f(-shift);
+#pragma unroll
+                        for (int d = 0; d < NDT; ++d) oacc[d][j] *= alpha;
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sacc[kt][j][r] = __builtin_amdgcn_exp2f(sacc[kt][j][r] - shift);
+#pragma unroll
+                    for (int u = 0; u < US; ++u)
+                        pb[u][j] = make_uint4(pack2<T>(sacc[2 * u][j][0], sacc[2 * u][j][1]), pack2<T>(sacc[2 * u][j][2], sacc[2 * u][j][3]),
+                                              pack2<T>(sacc[2 * u + 1][j][0], sacc[2 * u + 1][j][1]), pack2<T>(sacc[2 * u + 1][j][2], sacc[2 * u + 1][j][3]));
+                }
+                pv();
+            } else {
+                pv();      // (the PV MFMAs are duplicated into both arms so that O^T stays in place: no phi copies of 24 registers per tile)
+            }
+        } else {
         // ---- online softmax (per query column = per lane, replicated over the 4 lane groups)
 #pragma unroll
         for (int j = 0; j < QT; ++j) {
@@ -227,7 +312,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
                 pb[u][j] = make_uint4(pack2<T>(sacc[2 * u][j][0], sacc[2 * u][j][1]), pack2<T>(sacc[2 * u][j][2], sacc[2 * u][j][3]),
                                       pack2<T>(sacc[2 * u + 1][j][0], sacc[2 * u + 1][j][1]), pack2<T>(sacc[2 * u + 1][j][2], sacc[2 * u + 1][j][3]));
         }
-        pv();
+        }
+        if constexpr (!LAZY) pv();
     };
     const bool ragged = (p.Nkv % KVT) != 0;
     if constexpr (DMA) {
@@ -242,7 +328,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
             kdata[i] = ch * 8 < D && sidx < NSK;
             koff[i] = (unsigned)(row * (int)p.k_rs + ch * 8) * 2u;
             if (sidx < NSK) {
-                const uint4 fill = make_uint4(0, 0, 0, 0);
+                const unsigned one2 = (unsigned)T::from_f32(1.0f) * 0x10001u;      // LAZY: K[key][D] = K[key][D+1] = 1 (multiplies the -m slots of Q)
+                const uint4 fill = make_uint4((LAZY && ch * 8 == D) ? one2 : 0u, 0, 0, 0);
                 *(uint4*)(dK0 + sidx * 16) = fill; *(uint4*)(dK1 + sidx * 16) = fill;
             }
         }
@@ -256,6 +343,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
                 *(uint4*)(dV0 + sidx * 16) = fill; *(uint4*)(dV1 + sidx * 16) = fill;
             }
         }
+        if (SHORTK && t < 4) { *(uint4*)(dK0 + KVT * PK + t * 16) = make_uint4(0, 0, 0, 0); *(uint4*)(dK1 + KVT * PK + t * 16) = make_uint4(0, 0, 0, 0); }
         __syncthreads();    // the fill is complete before the first DMA lands (rows past Nkv of a ragged tile stay finite)
         const unsigned kstep = (unsigned)(KVT * (int)p.k_rs * 2), vstep = (unsigned)(KVT * (int)p.v_rs * 2);
         int issued = 0;     // tiles issued so far (= index of the tile the offsets address)
@@ -282,8 +370,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
         };
         auto step = [&](const int it, unsigned char* cK, unsigned char* cV, unsigned char* nK, unsigned char* nV) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of tile `it` has landed
-            __syncthreads();                                      // ... everybody's has, and everybody is done with tile it-1
-            if (it + 1 < ntiles) {
+            if (HACK != 1) __syncthreads();                       // ... everybody's has, and everybody is done with tile it-1
+            if (it + 1 < ntiles && HACK != 5) {
                 if (ragged && it + 2 == ntiles) dma_issue(nK, nV, std::true_type{});
                 else dma_issue(nK, nV, std::false_type{});
             }
@@ -329,7 +417,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
         const float inv = 1.0f / l;
         const int q = q0 + j * 16 + li;
         if (q < p.Nq) {
-            if (p.lse && lg == 0) p.lse[((int64_t)b * p.heads + h) * p.Nq + q] = mrun[j] * c + __log2f(l);      // log-sum-exp of this call's keys (log2 domain) for vv_attention_merge
+            if constexpr (!LAZY) {      // log-sum-exp of this call's keys (log2 domain) for vv_attention_merge
+                if (p.lse && lg == 0) p.lse[((int64_t)b * p.heads + h) * p.Nq + q] = mrun[j] * c + __log2f(l);
+            }
 #pragma unroll
             for (int d = 0; d < NDT; ++d) {
                 const int dd = d * 16 + lg * 4;
@@ -340,6 +430,293 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
             }
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Software-pipelined form for small head dims (d <= 64): per KV tile the wave issues, in ONE barrier interval,
+//     S_next = K(it+1) Q^T   (16 MFMAs)   |   O^T += V(it-1)^T P(it-1)^T   (12 MFMAs)   |   softmax of S(it) on the VALU
+// -- none of the 28 MFMAs depends on the softmax running beside them, so the matrix pipe could work under the (issue-bound) exponent
+// math of the SAME wave instead of waiting for it (cdna_hip_programming.md T15).
+// LAB VARIANT (VV_AB builds, VV_ATTN_VARIANT=20..22), NOT the product path: measured 403 TFLOP/s against 585 for the default kernel
+// on the d = 40 / N = 14400 shape (profiles/r2_attn_pipe_ab.txt) -- hipcc keeps the MFMAs of a step clustered ahead of the softmax
+// (sched_group_barrier pipelines are not honoured across the LDS-read dependencies) and the second S tile + deferred P push the
+// kernel to 256 VGPRs with spills, i.e. 2 waves per SIMD without the intra-wave overlap that was to pay for the lost wave.  K tiles are DMA'd two tiles ahead and V tiles
+// one ahead into 3-slot rings; the LDS-DMA is issued from inline asm (hipcc then orders no ds_read behind it) and every wait is
+// the hand-placed vmcnt(0) + s_barrier at the end of a step.  2 waves per SIMD (the second S tile and the deferred P cost 48 VGPRs).
+
+template <typename T, int D, int OCC, int KIND, int HINT = 0>
+__global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(const vv_attn_params p, const int nqt) {
+    constexpr int QT = 2, KVT = 64, NW = 4, NT = 256;
+    constexpr int DK = (D + 31) / 32 * 32, KS = DK / 32;
+    constexpr int DV = (D + 15) / 16 * 16, NDT = DV / 16;
+    constexpr int KT = KVT / 16, US = KVT / 32;
+    constexpr int PK = DK * 2 + 32, PV = DV * 2 + ((DV * 2) % 64 == 0 ? 32 : 0);
+    constexpr int BQ = NW * QT * 16;
+    constexpr bool ONES = DV > D;
+    constexpr int NSK = KVT * PK / 16, NSV = KVT * PV / 16;
+    constexpr int KP = (NSK + NT - 1) / NT, VP = (NSV + NT - 1) / NT;
+    constexpr int KBYTES = KVT * PK, VBYTES = KVT * PV;
+    constexpr int VALU_PER_MFMA = HINT;
+    static_assert(NSK % 64 == 0 && NSV % 64 == 0, "K/V tile must be whole 1 KB wave blocks");
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[3 * KBYTES + 3 * VBYTES];
+    unsigned char* const rK = ring;
+    unsigned char* const rV = ring + 3 * KBYTES;
+
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    int qt, h, b;
+    {
+        const int nbh = p.B * p.heads;
+        const int full = (nbh / 8) * 8;
+        const int bid = blockIdx.x;
+        int bh;
+        if (bid < full * nqt) { const int xcd = bid & 7, idx = bid >> 3; bh = (idx / nqt) * 8 + xcd; qt = idx % nqt; }
+        else { const int r = bid - full * nqt; bh = full + r / nqt; qt = r % nqt; }
+        h = bh % p.heads; b = bh / p.heads;
+    }
+    const unsigned short* Q = (const unsigned short*)p.q + (int64_t)b * p.q_bs + (int64_t)h * (p.q_hs ? p.q_hs : D);
+    const unsigned short* Kp = (const unsigned short*)p.k + (int64_t)b * p.k_bs + (int64_t)h * (p.k_hs ? p.k_hs : D);
+    const unsigned short* Vp = (const unsigned short*)p.v + (int64_t)b * p.v_bs + (int64_t)h * (p.v_hs ? p.v_hs : D);
+    unsigned short* O = (unsigned short*)p.o + (int64_t)b * p.o_bs + (int64_t)h * D;
+
+    const int q0 = qt * BQ + wave * QT * 16;
+    uint4 qf[QT][KS];
+#pragma unroll
+    for (int j = 0; j < QT; ++j)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int q = q0 + j * 16 + li, d0 = s * 32 + lg * 8;
+            qf[j][s] = (q < p.Nq && d0 < D) ? *(const uint4*)(Q + (int64_t)q * p.q_rs + d0) : make_uint4(0, 0, 0, 0);
+        }
+    f32x4 oacc[NDT][QT];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int j = 0; j < QT; ++j) oacc[d][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int j = 0; j < QT; ++j) { mrun[j] = -1e30f; lrun[j] = 0.f; }
+    const float c = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
+    const int ntiles = (p.Nkv + KVT - 1) / KVT;
+    const bool ragged = (p.Nkv % KVT) != 0;
+
+    // ---- DMA slots (as in attn_kernel): pad / ONES slots are written once into all three ring slots, their lanes masked off
+    unsigned koff[KP], voff[VP];
+    bool kdata[KP], vdata[VP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        const int sidx = i * NT + t, row = sidx / (PK / 16), ch = sidx - row * (PK / 16);
+        kdata[i] = ch * 8 < D && sidx < NSK;
+        koff[i] = (unsigned)(row * (int)p.k_rs + ch * 8) * 2u;
+        if (sidx < NSK) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) *(uint4*)(rK + r * KBYTES + sidx * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+        const int sidx = i * NT + t, row = sidx / (PV / 16), ch = sidx - row * (PV / 16);
+        vdata[i] = ch * 8 < D && sidx < NSV;
+        voff[i] = (unsigned)(row * (int)p.v_rs + ch * 8) * 2u;
+        if (sidx < NSV) {
+            const uint4 fill = make_uint4((ONES && ch * 8 == D) ? (unsigned)T::from_f32(1.0f) : 0u, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) *(uint4*)(rV + r * VBYTES + sidx * 16) = fill;
+        }
+    }
+    __syncthreads();
+    const unsigned kstep = (unsigned)(KVT * (int)p.k_rs * 2), vstep = (unsigned)(KVT * (int)p.v_rs * 2);
+    int k_issued = 0, v_issued = 0;
+    auto dma_k = [&]() {        // next K tile -> ring slot k_issued % 3
+        const bool check = ragged && k_issued + 1 == ntiles;
+        const int kv0 = k_issued * KVT;
+        unsigned char* bK = rK + (k_issued % 3) * KBYTES;
+#pragma unroll
+        for (int i = 0; i < KP; ++i) {
+            if (NSK % NT == 0 || i * NT + wave * 64 < NSK) {
+                if (kdata[i] && (!check || kv0 + (i * NT + t) / (PK / 16) < p.Nkv)) glds16_asm((const unsigned char*)Kp + koff[i], bK + (i * NT + wave * 64) * 16);
+                koff[i] += kstep;
+            }
+        }
+        ++k_issued;
+    };
+    auto dma_v = [&]() {
+        const bool check = ragged && v_issued + 1 == ntiles;
+        const int kv0 = v_issued * KVT;
+        unsigned char* bV = rV + (v_issued % 3) * VBYTES;
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            if (NSV % NT == 0 || i * NT + wave * 64 < NSV) {
+                if (vdata[i] && (!check || kv0 + (i * NT + t) / (PV / 16) < p.Nkv)) glds16_asm((const unsigned char*)Vp + voff[i], bV + (i * NT + wave * 64) * 16);
+                voff[i] += vstep;
+            }
+        }
+        ++v_issued;
+    };
+    auto sync_step = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    auto qk = [&](const int it, f32x4 (&sacc)[KT][QT], auto mask_tag) {      // S^T = K(it) Q^T
+        constexpr bool MASK = decltype(mask_tag)::value;
+        const unsigned char* sK = rK + (it % 3) * KBYTES;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int j = 0; j < QT; ++j) sacc[kt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const uint4 kf = *(const uint4*)(sK + (kt * 16 + li) * PK + (s * 4 + lg) * 16);
+#pragma unroll
+                for (int j = 0; j < QT; ++j) sacc[kt][j] = T::mfma(kf, qf[j][s], sacc[kt][j]);
+            }
+        if constexpr (MASK) {      // ragged last tile: keys past Nkv get -inf scores (selects, no branch)
+            const int lim = p.Nkv - it * KVT - lg * 4;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < QT; ++j) sacc[kt][j][r] = (kt * 16 + r < lim) ? sacc[kt][j][r] : -1e30f;
+        }
+    };
+    auto pv = [&](const int it, const uint4 (&pb)[US][QT]) {   // O^T += V(it)^T P^T
+        const unsigned char* sV = rV + (it % 3) * VBYTES;
+#pragma unroll
+        for (int u = 0; u < US; ++u)
+#pragma unroll
+            for (int d = 0; d < NDT; ++d) {
+                const unsigned char* a0 = sV + (u * 32 + 4 * lg + (li >> 2)) * PV + (d * 16 + 4 * (li & 3)) * 2;
+                const uint2 lo = ds_read_tr16(a0);
+                const uint2 hi = ds_read_tr16(a0 + 16 * PV);
+                const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                for (int j = 0; j < QT; ++j) oacc[d][j] = T::mfma(vf, pb[u][j], oacc[d][j]);
+            }
+    };
+    auto softmax = [&](f32x4 (&sacc)[KT][QT], uint4 (&pb)[US][QT]) {
+#pragma unroll
+        for (int j = 0; j < QT; ++j) {
+            float mx = sacc[0][j][0];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kt][j][r]);
+            mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), (16 << 10) | 0x1f)));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[j], mx);
+            const float mc = mnew * c;
+            const vv_f32x2 c2 = {c, c}, nmc2 = {-mc, -mc};
+            vv_f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    const vv_f32x2 a2 = __builtin_elementwise_fma((vv_f32x2){sacc[kt][j][r], sacc[kt][j][r + 1]}, c2, nmc2);
+                    const float e0 = __builtin_amdgcn_exp2f(a2.x), e1 = __builtin_amdgcn_exp2f(a2.y);
+                    sacc[kt][j][r] = e0; sacc[kt][j][r + 1] = e1;
+                    if (!ONES) ps2 += (vv_f32x2){e0, e1};
+                }
+            const float ps = ps2.x + ps2.y;
+            // always rescale (alpha = 1 when the maximum did not move): a branch here would cut the basic block and with it the
+            // interleaving of this VALU work with the MFMAs of qk / pv
+            const float alpha = __builtin_amdgcn_exp2f((mrun[j] - mnew) * c);
+            if (!ONES) lrun[j] = lrun[j] * alpha + ps;
+#pragma unroll
+            for (int d = 0; d < NDT; ++d) oacc[d][j] *= alpha;
+            mrun[j] = mnew;
+#pragma unroll
+            for (int u = 0; u < US; ++u)
+                pb[u][j] = make_uint4(pack2<T>(sacc[2 * u][j][0], sacc[2 * u][j][1]), pack2<T>(sacc[2 * u][j][2], sacc[2 * u][j][3]),
+                                      pack2<T>(sacc[2 * u + 1][j][0], sacc[2 * u + 1][j][1]), pack2<T>(sacc[2 * u + 1][j][2], sacc[2 * u + 1][j][3]));
+        }
+    };
+
+    // ---- pipeline.  Step `it`: issue K(it+2), V(it+1); S_b = K(it+1) Q^T; O^T += V(it-1)^T P(it-1); P(it) = softmax(S_a); swap a/b.
+    f32x4 sA[KT][QT], sB[KT][QT];
+    uint4 pA[US][QT], pB[US][QT];
+    dma_k(); dma_v();
+    if (ntiles > 1) dma_k();
+    sync_step();
+    if (ragged && ntiles == 1) qk(0, sA, std::true_type{}); else qk(0, sA, std::false_type{});
+    // one step, straight-line: DO_QK / DO_PV / MASK are compile-time so that qk, pv and the softmax share ONE basic block
+    auto step = [&](const int it, f32x4 (&sc)[KT][QT], f32x4 (&sn)[KT][QT], uint4 (&pc)[US][QT], uint4 (&pp)[US][QT], auto qk_tag, auto pv_tag,
+                    auto mask_tag) {
+        if (it + 2 < ntiles) dma_k();
+        if (it + 1 < ntiles) dma_v();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(qk_tag)::value) qk(it + 1, sn, mask_tag);
+        if constexpr (decltype(pv_tag)::value) pv(it - 1, pp);
+        softmax(sc, pc);
+        // interleave: every MFMA (with the LDS read that feeds it) is followed by a few of the softmax's VALU instructions, so the
+        // matrix pipe runs under the exponent math of this same wave
+        if constexpr (HINT > 0 && (decltype(qk_tag)::value || decltype(pv_tag)::value)) {
+            constexpr int NM = (decltype(qk_tag)::value ? KS * KT * QT : 0) + (decltype(pv_tag)::value ? US * NDT * QT : 0);
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);     // VALU (softmax)
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        sync_step();
+    };
+    using TT = std::true_type; using FF = std::false_type;
+    // the step that computes the scores of the LAST tile carries the ragged-key mask
+    auto step_any = [&](const int it, f32x4 (&sc)[KT][QT], f32x4 (&sn)[KT][QT], uint4 (&pc)[US][QT], uint4 (&pp)[US][QT]) {
+        const bool has_qk = it + 1 < ntiles, has_pv = it > 0, mask = ragged && it + 2 == ntiles;
+        if (has_qk && has_pv && !mask) step(it, sc, sn, pc, pp, TT{}, TT{}, FF{});         // steady state
+        else if (has_qk && has_pv) step(it, sc, sn, pc, pp, TT{}, TT{}, TT{});
+        else if (has_qk && !mask) step(it, sc, sn, pc, pp, TT{}, FF{}, FF{});
+        else if (has_qk) step(it, sc, sn, pc, pp, TT{}, FF{}, TT{});
+        else if (has_pv) step(it, sc, sn, pc, pp, FF{}, TT{}, FF{});
+        else step(it, sc, sn, pc, pp, FF{}, FF{}, FF{});
+    };
+    for (int it = 0; it < ntiles; it += 2) {
+        step_any(it, sA, sB, pA, pB);
+        if (it + 1 < ntiles) step_any(it + 1, sB, sA, pB, pA);
+    }
+    if ((ntiles - 1) & 1) pv(ntiles - 1, pB); else pv(ntiles - 1, pA);
+
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+        float l;
+        if (ONES) {
+            l = __shfl(oacc[D / 16][j][(D % 16) % 4], ((D % 16) / 4) * 16 + li);
+        } else {
+            l = lrun[j];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
+        const float inv = 1.0f / l;
+        const int q = q0 + j * 16 + li;
+        if (q < p.Nq) {
+#pragma unroll
+            for (int d = 0; d < NDT; ++d) {
+                const int dd = d * 16 + lg * 4;
+                if (dd < D) {
+                    const uint2 o2 = make_uint2(pack2<T>(oacc[d][j][0] * inv, oacc[d][j][1] * inv), pack2<T>(oacc[d][j][2] * inv, oacc[d][j][3] * inv));
+                    *(uint2*)(O + (int64_t)q * p.o_rs + dd) = o2;
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int D, int OCC, int KIND, int HINT = 0>
+int attn_pipe_launch(const vv_attn_params& p, hipStream_t st) {
+    constexpr int BQ = 128;
+    const int nqt = (p.Nq + BQ - 1) / BQ;
+    const int64_t nblk = (int64_t)p.B * p.heads * nqt;
+    if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_attention: grid too large");
+    hipLaunchKernelGGL((attn_pipe_kernel<T, D, OCC, KIND, HINT>), dim3((unsigned)nblk), dim3(256), 0, st, p, nqt);
+    VV_CHECK_LAUNCH("vv_attention(pipelined)");
+    return VV_OK;
 }
 
 
@@ -360,6 +737,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
 // LDS images (both 96-byte rows, filled by LDS-DMA, every wave instruction a whole KB):
 //   K: row = key, 16-byte chunk c stored at position c ^ ((row >> 3) & 1)  -> ds_read_b128 of 16 rows x one chunk is conflict free;
 //   V: key 8 g + 4 b + q stored at row 8 g + 2 q + b                      -> the 4 rows of a transposed read are 2 apart: conflict free.
+// Lazy reference maximum, slow path, ragged last tile: as in attn_kernel<LAZY>.
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 template <typename T> struct Mfma32;
 template <> struct Mfma32<BF16> {
@@ -372,27 +750,6 @@ template <> struct Mfma32<F16> {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
 };
-
-// self-attention (Nq == Nkv): the score of query q against ITS OWN key, from the lane's Q fragments (lane half h holds the 16 s + 8 h .. +7 slots of
-// the three k steps: 24 + 16 of the 40 products); -1e30 when there is no such key
-template <typename T>
-__device__ __forceinline__ float attn40_diag_score(const vv_attn_params& p, const unsigned char* Kp, const uint4 (&qx)[3], const int q, const int h) {
-    float sum = 0.f;
-    const bool on = p.Nq == p.Nkv && q < p.Nkv;
-#pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3) {
-        const int d0 = 16 * s3 + 8 * h;
-        if (on && d0 < 40) {
-            float qv[8], kv[8];
-            unpack8<T>(qx[s3], qv);
-            unpack8<T>(*(const uint4*)(Kp + ((int64_t)q * p.k_rs + d0) * 2), kv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sum += qv[e] * kv[e];
-        }
-    }
-    sum += __shfl_xor(sum, 32);
-    return on ? sum : -1e30f;
-}
 
 // OPTIMISTIC reference (this kernel) instead of the lazy running one: the softmax reference m of a query is fixed ONCE, before the key loop, from
 // the exact maximum of its scores against a 64-key sample spread over the whole sequence -- plus, for self-attention (Nq == Nkv), the query's OWN
@@ -407,7 +764,7 @@ __device__ __forceinline__ float attn40_diag_score(const vv_attn_params& p, cons
 // relative precision up to 2^16 (fp16) and the sums are fp32, so a later score may beat the sample maximum by up to 16 + MARGIN binary orders before
 // anything is lost.  Beyond that P overflows to inf, the denominator (row 40 of O^T) comes out non-finite, and the BLOCK repeats its keys once with the
 // exact maximum (a QK^T-only sweep first): correct for any input, slow only for the blocks that hit it.  bf16 cannot overflow at all.
-template <typename T, int NW, int OCC, bool RAGGED>
+template <typename T, int NW, int OCC, bool RAGGED, int HACK = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_params p, const int nqt) {
     // LDS: dense 80-byte rows (5 chunks of 8 h16) -- a K or V tile is exactly 5 KB = 5 LDS-DMA wave instructions with EVERY lane active (no
     // exec masking, no pad slots), 10 per 64-key tile.  The constant operand slots come from a region of 1.0 instead of from the rows:
@@ -517,7 +874,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
                 const uint4 kf = s < 2 ? *(const uint4*)(sK + kb * 32 * PR + ka0 + 32 * s) : *(const uint4*)(sK + kb * 32 * PR + ka2);
-                sacc[kb] = Mfma32<T>::run(kf, qf[s], sacc[kb]);
+                if (HACK == 4) sacc[kb][0] += __builtin_bit_cast(float, kf.x ^ qf[s].x) * 1e-30f; else sacc[kb] = Mfma32<T>::run(kf, qf[s], sacc[kb]);
             }
         }
     };
@@ -535,6 +892,24 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
 #pragma unroll
             for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kb][i]);
         return fmaxf(mx, __shfl_xor(mx, 32));
+    };
+    // self-attention: the score of query q against ITS OWN key (lane halves hold 24 + 16 of the 40 products; -1e30 when there is no such key)
+    auto diag_score = [&](const uint4 (&qx)[3], const int q) -> float {
+        float sum = 0.f;
+        const bool on = p.Nq == p.Nkv && q < p.Nkv;
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const int d0 = 16 * s3 + 8 * h;
+            if (on && d0 < D) {
+                float qv[8], kv[8];
+                unpack8<T>(qx[s3], qv);
+                unpack8<T>(*(const uint4*)(Kp + ((int64_t)q * p.k_rs + d0) * 2), kv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += qv[e] * kv[e];
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        return on ? sum : -1e30f;
     };
     auto set_reference = [&](const float target) {                // pad slots 40, 41 of Q <- -target as the nearest h16 hi + lo pair
         const unsigned short hi = T::from_f32(-target);
@@ -556,7 +931,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             qk(dK1, sA);
-            set_reference(fmaxf(row_max(sA), attn40_diag_score<T>(p, Kp, qf, q0 + r, h)) + MARGIN);
+            set_reference(fmaxf(row_max(sA), diag_score(qf, q0 + r)) + MARGIN);
         } else {
             qf[2].x = h == 1 ? 0u : qf[2].x;                      // plain scores again
             float mx = -1e30f;
@@ -591,7 +966,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sc[kb][i] = __builtin_amdgcn_exp2f(sc[kb][i]);
+                for (int i = 0; i < 16; ++i) sc[kb][i] = HACK == 2 ? sc[kb][i] * 0.01f : __builtin_amdgcn_exp2f(sc[kb][i]);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
                     pb[kb][s2] = make_uint4(pack2<T>(sc[kb][8 * s2 + 0], sc[kb][8 * s2 + 1]), pack2<T>(sc[kb][8 * s2 + 2], sc[kb][8 * s2 + 3]),
@@ -605,7 +980,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
                     const int g0 = 16 * (2 * kb + s2) * PR;
                     const uint2 lo = ds_read_tr16(cV + g0 + va0), hi = ds_read_tr16(cV + g0 + 2 * PR + va0);
                     const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    oacc = Mfma32<T>::run(vf, pb[kb][s2], oacc);
+                    if (HACK == 3) oacc[0] += __builtin_bit_cast(float, vf.x ^ pb[kb][s2].x); else oacc = Mfma32<T>::run(vf, pb[kb][s2], oacc);
                 }
                 // rows 32..47 on the 16x16x32 form (M = 16 instead of a second, three-quarters empty 32-row block): v_permlane16_swap turns the
                 // (s2 = 0, s2 = 1) dword pairs of P -- rows {q 0..15 | q 16..31} x {h = 0 | h = 1} -- into the B operands of the two query tiles:
@@ -621,15 +996,36 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
                 }
                 const uint2 lo = ds_read_tr16(cV + kb * 32 * PR + va1), hi = ds_read_tr16(cV + kb * 32 * PR + 2 * PR + va1);
                 const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                o2[0] = T::mfma(vf, pa, o2[0]); o2[1] = T::mfma(vf, pq, o2[1]);
+                if (HACK == 3) { o2[0][0] += __builtin_bit_cast(float, vf.x ^ pa.x); o2[1][0] += __builtin_bit_cast(float, vf.x ^ pq.x); }
+                else { o2[0] = T::mfma(vf, pa, o2[0]); o2[1] = T::mfma(vf, pq, o2[1]); }
+            }
+            if (HACK == 7) {
+                // requested issue order (the block has 14 MFMAs, 32 v_exp, 16 v_cvt_pk, 6 + 16 LDS reads): K fragments and the first V fragments up
+                // front, every further V read five MFMAs ahead of its use, and the exponentials / conversions of this tile spread evenly over
+                // the MFMA shadows (2-3 v_exp + 1-2 v_cvt_pk per MFMA: ~36 issue cycles against the MFMA's 32)
+#define VV_SGB_STEP(NE, NC, ND) \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
+                if (NE) __builtin_amdgcn_sched_group_barrier(0x400, NE, 0); \
+                if (NC) __builtin_amdgcn_sched_group_barrier(0x002, NC, 0); \
+                if (ND) __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);      // (exponentials first: they do not wait for the LDS reads just issued)
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                VV_SGB_STEP(3, 2, 1) VV_SGB_STEP(2, 1, 1) VV_SGB_STEP(2, 1, 1) VV_SGB_STEP(3, 2, 1) VV_SGB_STEP(2, 1, 1) VV_SGB_STEP(2, 1, 1)
+                VV_SGB_STEP(3, 1, 1) VV_SGB_STEP(2, 1, 1) VV_SGB_STEP(2, 1, 1) VV_SGB_STEP(3, 2, 1) VV_SGB_STEP(2, 1, 1) VV_SGB_STEP(2, 1, 1)
+                VV_SGB_STEP(0, 0, 0) VV_SGB_STEP(0, 0, 0)
+#undef VV_SGB_STEP
             }
         };
         // step `it`: K(it+1) and V(it) have landed (issued one step ago); issue K(it+2) over K(it) and V(it+1) over V(it-1)
         auto step = [&](const int it, unsigned char* kA, unsigned char* kB, unsigned char* vA, unsigned char* vB, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (it + 2 < ntiles) dma(0, it + 2, kA, 1u);
-            if (it + 1 < ntiles) dma(1, it + 1, vB, 1u);
+            if (HACK != 1) __syncthreads();
+            if (HACK != 5) {
+                if (it + 2 < ntiles) dma(0, it + 2, kA, 1u);
+                if (it + 1 < ntiles) dma(1, it + 1, vB, 1u);
+            }
             body(kB, vA, sc, sn);                                 // (the last step computes scores of a tile that does not exist: stale K, never used)
             if (RAGGED && it + 2 == ntiles) mask_last(sn);
         };
@@ -665,12 +1061,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
     }
 }
 
-template <typename T, int NW, int OCC, bool RAGGED>
+template <typename T, int NW, int OCC, bool RAGGED, int HACK = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_params p, const int nqt) {
     // TWO 32-query blocks per wave (a, b): every K / V fragment read from LDS and every LDS-DMA piece serves 64 queries -- half the LDS and L2 -> LDS
     // bytes per FLOP of attn40_kernel (the chip is power limited on this kernel: fewer bytes moved = a higher clock).  Not pipelined across
     // tiles; the two blocks overlap each other instead: QK_a, QK_b | exp_a, PV_a | exp_b, PV_b in ONE basic block per tile.
-    // LDS images, constant regions and row orders: as attn40_kernel above.
+    // LDS: dense 80-byte rows (5 chunks of 8 h16) -- a K or V tile is exactly 5 KB = 5 LDS-DMA wave instructions with EVERY lane active (no
+    // exec masking, no pad slots), 10 per 64-key tile.  The constant operand slots come from a region of 1.0 instead of from the rows:
+    //   K slots 40..47 (Q carries -m hi, -m lo, 0 x 6 there)  and  V columns 40..43 (O^T rows 40.. = sum_k P, the softmax denominator).
+    // Row orders: K natural (80-byte pitch: 16 consecutive rows x one chunk hit 16 different 16-byte bank slots);
+    //             V key 16 g + 4 j + q at row 16 g + 4 q + j (the 4 rows of one transposed read are 4 apart: conflict free at 80 bytes).
     constexpr int D = 40, KVT = 64, PR = 80, NCH = 5;
     constexpr int NT = NW * 64, QB = 2, BQ = NW * 32 * QB;
     constexpr int TILE = KVT * PR;                            // 5120
@@ -795,6 +1195,24 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
             for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kb][i]);
         return fmaxf(mx, __shfl_xor(mx, 32));
     };
+    // self-attention: the score of query q against ITS OWN key (lane halves hold 24 + 16 of the 40 products; -1e30 when there is no such key)
+    auto diag_score = [&](const uint4 (&qx)[3], const int q) -> float {
+        float sum = 0.f;
+        const bool on = p.Nq == p.Nkv && q < p.Nkv;
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const int d0 = 16 * s3 + 8 * h;
+            if (on && d0 < D) {
+                float qv[8], kv[8];
+                unpack8<T>(qx[s3], qv);
+                unpack8<T>(*(const uint4*)(Kp + ((int64_t)q * p.k_rs + d0) * 2), kv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += qv[e] * kv[e];
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        return on ? sum : -1e30f;
+    };
     auto set_reference = [&](const int x, const float target) {   // pad slots 40, 41 of Q <- -target as the nearest h16 hi + lo pair
         const unsigned short hi = T::from_f32(-target);
         const unsigned short lo = T::from_f32(-target - T::to_f32(hi));
@@ -813,7 +1231,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
 #pragma unroll
-            for (int x = 0; x < QB; ++x) { qk(dK1, x, sc[x]); set_reference(x, fmaxf(row_max(sc[x]), attn40_diag_score<T>(p, Kp, qf[x], q0 + 32 * x + r, h)) + MARGIN); }
+            for (int x = 0; x < QB; ++x) { qk(dK1, x, sc[x]); set_reference(x, fmaxf(row_max(sc[x]), diag_score(qf[x], q0 + 32 * x + r)) + MARGIN); }
         } else {
             float mx[QB];
 #pragma unroll
@@ -853,7 +1271,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) sc[x][kb][i] = __builtin_amdgcn_exp2f(sc[x][kb][i]);
+                    for (int i = 0; i < 16; ++i) sc[x][kb][i] = HACK == 2 ? sc[x][kb][i] * 0.01f : __builtin_amdgcn_exp2f(sc[x][kb][i]);
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2)
                         pb[kb][s2] = make_uint4(pack2<T>(sc[x][kb][8 * s2 + 0], sc[x][kb][8 * s2 + 1]), pack2<T>(sc[x][kb][8 * s2 + 2], sc[x][kb][8 * s2 + 3]),
@@ -885,8 +1303,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
         // step `it`: tile `it` (K and V) has landed; issue tile it+1 into the other buffers
         auto step = [&](const int it, unsigned char* cK, unsigned char* cV, unsigned char* nK, unsigned char* nV) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (it + 1 < ntiles) { dma(0, it + 1, nK, 1u); dma(1, it + 1, nV, 1u); }
+            if (HACK != 1) __syncthreads();
+            if (it + 1 < ntiles && HACK != 5) { dma(0, it + 1, nK, 1u); dma(1, it + 1, nV, 1u); }
             body(cK, cV, it + 1 == ntiles);
         };
         for (int it = 0; it < ntiles; it += 2) {
@@ -926,31 +1344,31 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
     }
 }
 
-template <typename T, int NW, int OCC>
+template <typename T, int NW, int OCC, int HACK = 0>
 int attn40q2_launch(const vv_attn_params& p, hipStream_t st) {
     constexpr int BQ = NW * 64;
     const int nqt = (p.Nq + BQ - 1) / BQ;
     const int64_t nblk = (int64_t)p.B * p.heads * nqt;
     if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_attention: grid too large");
-    if (p.Nkv % 64) hipLaunchKernelGGL((attn40q2_kernel<T, NW, OCC, true>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p, nqt);
-    else hipLaunchKernelGGL((attn40q2_kernel<T, NW, OCC, false>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p, nqt);
+    if (p.Nkv % 64) hipLaunchKernelGGL((attn40q2_kernel<T, NW, OCC, true, HACK>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p, nqt);
+    else hipLaunchKernelGGL((attn40q2_kernel<T, NW, OCC, false, HACK>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p, nqt);
     VV_CHECK_LAUNCH("vv_attention(d40, 64 queries per wave)");
     return VV_OK;
 }
 
-template <typename T, int NW, int OCC>
+template <typename T, int NW, int OCC, int HACK = 0>
 int attn40_launch(const vv_attn_params& p, hipStream_t st) {
     constexpr int BQ = NW * 32;
     const int nqt = (p.Nq + BQ - 1) / BQ;
     const int64_t nblk = (int64_t)p.B * p.heads * nqt;
     if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_attention: grid too large");
-    if (p.Nkv % 64) hipLaunchKernelGGL((attn40_kernel<T, NW, OCC, true>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p, nqt);
-    else hipLaunchKernelGGL((attn40_kernel<T, NW, OCC, false>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p, nqt);
+    if (p.Nkv % 64) hipLaunchKernelGGL((attn40_kernel<T, NW, OCC, true, HACK>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p, nqt);
+    else hipLaunchKernelGGL((attn40_kernel<T, NW, OCC, false, HACK>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p, nqt);
     VV_CHECK_LAUNCH("vv_attention(d40, 32x32x16)");
     return VV_OK;
 }
 
-template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0>
+template <typename T, int D, int QT, int KVT, int NW, bool PREFETCH, int OCC = 1, bool DMA = false, int KIND = 0, bool LAZY = false, int HACK = 0>
 int attn_launch(const vv_attn_params& p, hipStream_t st) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
     constexpr int PK = DK * 2 + 32, PV = DV * 2 + ((DV * 2) % 64 == 0 ? 32 : 0);   // conflict-free ds_read_b128 / ds_read_b64_tr_b16 (bank model: tools/lds_bank_model.py)
@@ -959,7 +1377,7 @@ int attn_launch(const vv_attn_params& p, hipStream_t st) {
     const int nqt = (p.Nq + BQ - 1) / BQ;
     const int64_t nblk = (int64_t)p.B * p.heads * nqt;
     if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_attention: grid too large");
-    auto kern = attn_kernel<T, D, QT, KVT, NW, PREFETCH, OCC, DMA, KIND>;
+    auto kern = attn_kernel<T, D, QT, KVT, NW, PREFETCH, OCC, DMA, KIND, LAZY, HACK>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -979,15 +1397,85 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
         // short sequences (temporal attention over <=32 frames, tiny test shapes): one wave per block, 32-key tiles
         if (p.Nq <= 32 && p.Nkv <= 32) return attn_launch<T, D, 2, 32, 1, true>(p, st);
         if constexpr (D <= 80) {
+#ifdef VV_AB      // lab build only: environment-selected A/B variants (profiles/r1_attn_pmc.txt)
+            static int var = -1;
+            if (var < 0) { const char* e = getenv("VV_ATTN_VARIANT"); var = e ? atoi(e) : 0; }
+            if (var == 1) return attn_launch<T, D, 2, 64, 4, false, 1>(p, st);     // no register prefetch
+            if (var == 2) return attn_launch<T, D, 2, 64, 4, true, 4>(p, st);      // capped at 128 VGPRs (4 waves/SIMD)
+            if (var == 3) return attn_launch<T, D, 2, 64, 4, false, 4>(p, st);     // both
+            if (var == 4) return attn_launch<T, D, 2, 32, 4, true, 4>(p, st);      // 32-key tiles, capped
+            if (var == 5) return attn_launch<T, D, 1, 64, 4, true, 1>(p, st);      // 16 queries per wave, 64 per block
+            if (var == 6) return attn_launch<T, D, 1, 64, 8, true, 1>(p, st);      // 16 queries per wave, 8 waves = 128 per block
+            if (var == 7) return attn_launch<T, D, 2, 64, 8, true, 1>(p, st);      // 32 queries per wave, 8 waves = 256 per block
+            if (var == 8) return attn_launch<T, D, 2, 64, 4, true>(p, st);         // register-staged K/V (the pre-DMA default)
+            if (var == 9) return attn_launch<T, D, 2, 64, 4, false, 3, true>(p, st);   // DMA, capped at 168 VGPRs (3 waves/SIMD)
+            if (var == 10) return attn_launch<T, D, 2, 64, 4, false, 1, true>(p, st);   // DMA, uncapped registers (2 waves/SIMD)
+            if (var == 13) return attn_launch<T, D, 2, 32, 4, false, 4, true>(p, st);   // DMA, 32-key tiles, capped at 128 VGPRs (4 waves/SIMD)
+            if (var == 14) return attn_launch<T, D, 2, 64, 4, true, 3>(p, st);          // register staged, capped at 168 VGPRs (3 waves/SIMD)
+            if constexpr (D <= 64) {
+                if (var == 20) return attn_pipe_launch<T, D, 2, 0, 0>(p, st);               // software pipelined, 2 waves/SIMD, compiler's order
+                if (var == 21) return attn_pipe_launch<T, D, 2, 0, 3>(p, st);               // ... sched_group_barrier: 3 VALU per MFMA
+                if (var == 22) return attn_pipe_launch<T, D, 2, 0, 5>(p, st);               // ... 5 VALU per MFMA
+            }
+#endif
             // default for d <= 64: K/V by LDS-DMA, double buffered, 3 waves/SIMD (d = 80 would spill: stays register staged)
             const bool cross = p.Nkv < 128 && p.Nq != p.Nkv;
-            if constexpr (D == 40) {
+            if constexpr (D == 40) {      // lazy reference maximum on the matrix pipe (spare k slots 40, 41)
+#ifdef VV_AB
+                if (var == 30) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0>(p, st);      // classic online softmax
+                if (var == 31) return attn_launch<T, D, 4, 64, 4, false, 2, true, 0, true>(p, st);      // lazy, 64 queries per wave, 2 waves/SIMD
+                if (var == 32) return attn_launch<T, D, 4, 64, 2, false, 4, true, 0, true>(p, st);      // lazy, 64 queries per wave, 2-wave blocks
+                if (var == 41) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true, 1>(p, st);      // timing probes (WRONG results): no barrier
+                if (var == 42) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true, 2>(p, st);      // ... no exp
+                if (var == 43) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true, 3>(p, st);      // ... no PV MFMAs
+                if (var == 44) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true, 4>(p, st);      // ... no QK MFMAs
+                if (var == 45) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true, 5>(p, st);      // ... no DMA
+                if (var == 48) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true, 8>(p, st);      // lazy with full 160-byte K rows
+                if (var == 35) return attn_launch<T, D, 2, 32, 8, false, 2, true, 0, true>(p, st);      // lazy, 8 waves (256 queries per block), 32-key tiles, 4 waves/SIMD
+                if (var == 36) return attn_launch<T, D, 2, 64, 8, false, 1, true, 0, true>(p, st);      // lazy, 8 waves, 64-key tiles, 2 waves/SIMD
+                if (var == 37) return attn_launch<T, D, 2, 64, 6, false, 2, true, 0, true>(p, st);      // lazy, 6 waves (192 queries per block), 3 waves/SIMD
+                if (var == 38) return attn_launch<T, D, 2, 64, 12, false, 1, true, 0, true>(p, st);     // lazy, 12 waves (384 queries per block), 3 waves/SIMD
+                if (var == 34) return attn_launch<T, D, 2, 32, 4, false, 4, true, 0, true>(p, st);      // lazy, 32-key tiles, 128-VGPR cap (4 waves/SIMD)
+                if (var == 33) return attn_launch<T, D, 2, 64, 2, false, 6, true, 0, true>(p, st);      // lazy, 2-wave blocks (6 blocks per CU)
+#endif
+#ifdef VV_AB
+                if (var == 50) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true>(p, st);      // round-2 default: lazy, 16x16x32 MFMAs
+                if (var == 51) return attn40_launch<T, 4, 3>(p, st);                                    // 32x32x16, capped at 168 VGPRs (3 waves/SIMD)
+                if (var == 52) return attn40_launch<T, 4, 2>(p, st);                                    // ... 2 waves/SIMD
+                if (var == 53) return attn40_launch<T, 8, 2>(p, st);                                    // ... 8-wave blocks
+                if (var == 54) return attn40_launch<T, 2, 4>(p, st);                                    // ... 2-wave blocks
+                if (var == 56) return attn40q2_launch<T, 4, 2>(p, st);                                  // 64 queries per wave, 2 waves/SIMD
+                if (var == 57) return attn40q2_launch<T, 2, 2>(p, st);                                  // ... 2-wave blocks
+                if (var == 58) return attn40q2_launch<T, 4, 1>(p, st);                                  // ... 1 wave/SIMD (512 registers)
+                if (var == 59) return attn40q2_launch<T, 8, 2>(p, st);                                  // ... 8-wave blocks: 512 queries share a K/V tile
+                if (var == 55) return attn40_launch<T, 4, 2, 6>(p, st);                                 // ... the compiler's own issue order (no sched_group_barrier pipeline)
+                if (var == 61) return attn40_launch<T, 4, 2, 1>(p, st);      // timing probes (WRONG results): no barrier
+                if (var == 62) return attn40_launch<T, 4, 2, 2>(p, st);      // ... no exp
+                if (var == 63) return attn40_launch<T, 4, 2, 3>(p, st);      // ... no PV MFMAs
+                if (var == 64) return attn40_launch<T, 4, 2, 4>(p, st);      // ... no QK MFMAs
+                if (var == 65) return attn40_launch<T, 4, 2, 5>(p, st);      // ... no DMA
+#endif
                 // 32x32x16 / 16x16x32 hybrid, optimistic reference: 64 queries per wave (2 waves/SIMD) on long sequences, 32 (3 waves/SIMD) below
                 if (!cross && p.Nkv >= 64) return p.Nq >= 1024 ? attn40q2_launch<T, 4, 2>(p, st) : attn40_launch<T, 4, 3>(p, st);
+                if (!cross) return attn_launch<T, D, 2, 64, 4, false, 3, true, 0, true>(p, st);
             }
             if (D <= 64) return cross ? attn_launch<T, D, 2, 64, 4, false, 3, true, 1>(p, st) : attn_launch<T, D, 2, 64, 4, false, 3, true, 0>(p, st);
             return cross ? attn_launch<T, D, 2, 64, 4, true, 1, false, 1>(p, st) : attn_launch<T, D, 2, 64, 4, true, 1, false, 0>(p, st);
         }
+#ifdef VV_AB      // lab build: block shapes for the long single-head case (SAM 2 memory attention, d = 256: profiles/r3_sam2_attn256_ab.txt)
+        if constexpr (D == 256) {
+            static int var = -1;
+            if (var < 0) { const char* e = getenv("VV_ATTN_VARIANT"); var = e ? atoi(e) : 0; }
+            if (var == 71) return attn_launch<T, D, 1, 64, 4, true>(p, st);       // 16 queries per wave: 64 per block
+            if (var == 72) return attn_launch<T, D, 2, 64, 2, true>(p, st);       // 2-wave blocks: 64 per block
+            if (var == 73) return attn_launch<T, D, 1, 64, 2, true>(p, st);       // 32 per block
+            if (var == 74) return attn_launch<T, D, 2, 32, 4, true>(p, st);       // 32-key tiles
+            if (var == 75) return attn_launch<T, D, 1, 32, 4, false>(p, st);      // the d = 512 form
+            if (var == 76) return attn_launch<T, D, 2, 64, 4, false>(p, st);      // no register prefetch
+            if (var == 77) return attn_launch<T, D, 1, 64, 8, true>(p, st);       // 8 waves x 16 queries
+            if (var == 78) return attn_launch<T, D, 2, 32, 1, true>(p, st);       // one wave per block
+        }
+#endif
         // one long head (SAM 2 memory attention: d = 256, 4096 queries x up to 28736 keys) is 32 blocks whatever the block shape below 8 waves:
         // eight waves of 16 queries keep the block's K/V tile loads covered (1.80 -> 1.05 ms; blocks of fewer than four waves are 7x slower:
         // the register-staged loader wants 256 threads), profiles/r3_sam2_attn256_ab.txt
@@ -1019,47 +1507,9 @@ int attn_by_d(const vv_attn_params& p, hipStream_t st) {
 }  // namespace
 
 #if VV_ATTN_PART == 0
-namespace {
-template <typename T>
-__global__ __launch_bounds__(256) void attn_merge_kernel(const unsigned short* __restrict__ parts, const float* __restrict__ lse, int S, int heads, int Nq, int D,
-                                                         int ld, unsigned short* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;        // one thread per (query, head, pair of channels)
-    const int half = D >> 1;
-    if (i >= (int64_t)Nq * heads * half) return;
-    const int c2 = (int)(i % half);
-    const int h = (int)((i / half) % heads);
-    const int q = (int)(i / ((int64_t)half * heads));
-    float mx = -3.0e38f;
-    for (int s = 0; s < S; ++s) mx = fmaxf(mx, lse[((int64_t)s * heads + h) * Nq + q]);
-    float a0 = 0.f, a1 = 0.f, den = 0.f;
-    for (int s = 0; s < S; ++s) {
-        const float w = __builtin_amdgcn_exp2f(lse[((int64_t)s * heads + h) * Nq + q] - mx);
-        const unsigned u = *(const unsigned*)(parts + ((int64_t)s * Nq + q) * ld + h * D + 2 * c2);
-        a0 = fmaf(w, T::to_f32(u & 0xffff), a0); a1 = fmaf(w, T::to_f32(u >> 16), a1); den += w;
-    }
-    const float inv = 1.0f / den;
-    *(unsigned*)(out + (int64_t)q * ld + h * D + 2 * c2) = pack2<T>(a0 * inv, a1 * inv);
-}
-}  // namespace
+extern "C" int vv_attention_lab_large_d(const vv_attn_params* pp, int dtype, void* stream);
 
-extern "C" int vv_attention_merge(const void* o_parts, const float* lse, int S, int heads, int Nq, int D, int ld, void* out, int dtype, void* stream) {
-    if (!o_parts || !lse || !out || S <= 0 || heads <= 0 || Nq <= 0 || D <= 0 || (D & 1) || (ld & 1) || ld < heads * D) VV_FAIL(VV_E_ARG, "vv_attention_merge: bad arguments");
-    const int64_t n = (int64_t)Nq * heads * (D / 2);
-    const dim3 grid((unsigned)((n + 255) / 256));
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == VV_BF16) hipLaunchKernelGGL(attn_merge_kernel<BF16>, grid, dim3(256), 0, st, (const unsigned short*)o_parts, lse, S, heads, Nq, D, ld, (unsigned short*)out);
-    else if (dtype == VV_F16) hipLaunchKernelGGL(attn_merge_kernel<F16>, grid, dim3(256), 0, st, (const unsigned short*)o_parts, lse, S, heads, Nq, D, ld, (unsigned short*)out);
-    else VV_FAIL(VV_E_ARG, "vv_attention_merge: bad dtype");
-    VV_CHECK_LAUNCH("vv_attention_merge");
-    return VV_OK;
-}
-
-extern "C" int vv_attention_large_d(const vv_attn_params* pp, int dtype, void* stream);
-#ifdef VV_AB      // lab build: VV_ATTN_VARIANT selects an experimental variant / timing probe of vv_attn_lab.hip
-extern "C" int vv_attention_lab(const vv_attn_params* pp, int dtype, void* stream);
-#endif
-
-extern "C" int vv_attention(const vv_attn_params* pp, int dtype, void* stream) {
+extern "C" int vv_attention_lab(const vv_attn_params* pp, int dtype, void* stream) {
     if (!pp) VV_FAIL(VV_E_ARG, "vv_attention: null params");
     const vv_attn_params& p = *pp;
     if (!p.q || !p.k || !p.v || !p.o) VV_FAIL(VV_E_ARG, "vv_attention: null pointer");
@@ -1068,14 +1518,11 @@ extern "C" int vv_attention(const vv_attn_params* pp, int dtype, void* stream) {
     if ((p.q_rs | p.k_rs | p.v_rs | p.q_bs | p.k_bs | p.v_bs | p.q_hs | p.k_hs | p.v_hs) & 7) VV_FAIL(VV_E_ARG, "vv_attention: q/k/v strides must be multiples of 8 elements");
     if (dtype != VV_BF16 && dtype != VV_F16) VV_FAIL(VV_E_ARG, "vv_attention: bad dtype");
     if (p.lse && p.D == 40) VV_FAIL(VV_E_UNSUPPORTED, "vv_attention: lse output is not available at D = 40");
-#ifdef VV_AB
-    if (getenv("VV_ATTN_VARIANT")) return vv_attention_lab(pp, dtype, stream);
-#endif
-    if (p.D > 80) return vv_attention_large_d(pp, dtype, stream);
+    if (p.D > 80) return vv_attention_lab_large_d(pp, dtype, stream);
     return dtype == VV_BF16 ? attn_by_d<BF16>(p, (hipStream_t)stream) : attn_by_d<F16>(p, (hipStream_t)stream);
 }
 #else
-extern "C" int vv_attention_large_d(const vv_attn_params* pp, int dtype, void* stream) {
+extern "C" int vv_attention_lab_large_d(const vv_attn_params* pp, int dtype, void* stream) {
     const vv_attn_params& p = *pp;
     return dtype == VV_BF16 ? attn_by_d<BF16>(p, (hipStream_t)stream) : attn_by_d<F16>(p, (hipStream_t)stream);
 }

@@ -40,8 +40,10 @@ class _Prof:
         return False
 
 
-# $VV_LIB_PATH: another build of the library (A/B of two builds on one device: tools/, lab builds); default = the in-tree product build
-_LIB_PATH = os.environ.get("VV_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libvvhip.so")
+# the in-tree product build; lab tools that A/B another build of the library set hip._LIB_PATH before the first launch (tools/bench_*.py).  No
+# environment variable is read anywhere in this module: behaviour is selected by API only.
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libvvhip.so")
+PROFILE_SHAPES = False   # bench.py --profile-shapes: profile keys of the GEMM / attention launches carry their M, N, K (tools/shape_table.py)
 _lib = None
 
 
@@ -207,8 +209,7 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
         # mirror of launch_t() in vv_gemm.hip (label only): LDS-DMA loaders prefer the 128x128 tile (4 blocks per CU) when N allows
         dma = x0.dtype != torch.float32 and C0 % 64 == 0 and C1 % 64 == 0 and weight.shape[1] == K
         lin = dma and ksize == 1 and stride == 1 and C1 == 0 and Hv == Hin and Wv == Win and Hout == Hin and Wout == Win
-        pref128 = os.environ.get("VV_GEMM_PREF128") is not None
-        tile = "128x128" if (epilogue == EPI_GEGLU or (pref128 and Npad % 128 == 0 and dma and not lin and M >= 16384)) else (
+        tile = "128x128" if epilogue == EPI_GEGLU else (
             "128x160" if Npad % 160 == 0 else ("128x128" if Npad % 128 == 0 else "128x16"))
         # mirror of vv_gemm256_try() in vv_gemm256.hip (label only): the long-k / wide-N shapes run on the 256-row kernels
         if tile_hint != 1 and dma and Hv == Hin and Wv == Win and ksize * (ksize_w or ksize) <= 9 and (
@@ -225,7 +226,7 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
             bn = 256 if form == 3 else (320 if (Npad % 320 == 0 and epilogue != EPI_GEGLU) else 256)
             if form and ((M + 255) // 256) * (Npad // bn) >= 400:
                 tile = f"256x{bn}" + ("p8" if form == 3 else "")
-        if os.environ.get("VV_PROFILE_SHAPES"):
+        if PROFILE_SHAPES:
             tile = f"M{M},N{N},K{K}|" + tile
         key = f"conv_gemm[{tile},{'f32in' if x0.dtype == torch.float32 else 'h16in'},k{ksize}{'x%d' % ksize_w if ksize_w and ksize_w != ksize else ''}]"
         es = x0.element_size()
@@ -305,7 +306,7 @@ def attention(dtype, q, k, v, out, *, B, heads, Nq, Nkv, D, q_bs, k_bs, v_bs, o_
                    q_bs=q_bs, k_bs=k_bs, v_bs=v_bs, o_bs=o_bs, q_rs=q_rs, k_rs=k_rs, v_rs=v_rs, o_rs=o_rs, B=B, heads=heads, Nq=Nq,
                    Nkv=Nkv, D=D, scale=float(D) ** -0.5 if scale is None else float(scale), q_hs=q_hs, k_hs=k_hs, v_hs=v_hs, q_prescaled=1 if q_prescaled else 0, lse=lse.data_ptr() if lse is not None else 0)
     kind = "temporal" if (Nq <= 32 and Nkv <= 32) else ("cross" if Nkv < 128 and Nq != Nkv else "spatial")
-    if os.environ.get("VV_PROFILE_SHAPES"):
+    if PROFILE_SHAPES:
         kind = f"B{B},N{Nq}|" + kind
     with _Prof(f"attention[{kind},d{D}]", 4.0 * B * heads * Nq * Nkv * D, 2 * B * heads * D * (2 * Nq + 2 * Nkv)):
         _check(lib().vv_attention(C.byref(p), dtype, _stream()), "vv_attention")
