@@ -523,8 +523,8 @@ def test_attention_d40_heavy_tail(gpu, orders):
     v[:, 225 * 7] = 5.0                                                           # ... with a value the bulk must pull away from
     qs, k, v = (t.to(td).float() for t in (q, k, v))                              # q is used pre-scaled: scores = q.k directly, in log2 units
     s = torch.einsum("bqhd,bkhd->bhqk", qs.double(), k.double())
-    gap = (s[..., 225 * 7] - s[..., :225].amax(-1)).min()
-    assert gap > orders - 4                                                       # the construction holds for every query
+    gap = (s[..., 225 * 7] - s[..., :225].median(-1).values).min()               # the outlier against the TYPICAL bulk key (the bulk itself spreads +- 3.5 orders)
+    assert gap > orders - 1.5                                                     # the construction holds for every query
     pr = torch.exp2(s - s.amax(-1, keepdim=True))
     bulk_share = 1.0 - (pr[..., 225 * 7] / pr.sum(-1)).mean().item()
     ref = torch.einsum("bhqk,bkhd->bqhd", pr / pr.sum(-1, keepdim=True), v.double()).float()

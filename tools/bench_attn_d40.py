@@ -4,6 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from videovanish_amd import hip
+if os.environ.get("VV_LIB_PATH"):
+    hip._LIB_PATH = os.environ["VV_LIB_PATH"]          # lab: A/B of two builds of the library on one device
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dname = sys.argv[2] if len(sys.argv) > 2 else "fp16"
@@ -18,12 +20,12 @@ qkv = qkv.to(td).to(dev)
 out = torch.empty(B * N, C, dtype=td, device=dev)
 fn = lambda: hip.attention(DT, qkv, qkv, qkv, out, B=B, heads=heads, Nq=N, Nkv=N, D=D, q_bs=N * 3 * C, k_bs=N * 3 * C, v_bs=N * 3 * C, o_bs=N * C,
                            q_rs=D, k_rs=D, v_rs=D, o_rs=C, k_off=N * C, v_off=2 * N * C, q_hs=N * D, k_hs=N * D, v_hs=N * D, q_prescaled=True)
-for _ in range(2):
+for _ in range(int(os.environ.get("VV_BENCH_WARM", "2"))):
     fn()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-n = 5
+n = int(os.environ.get("VV_BENCH_ITERS", "5"))
 for _ in range(n):
     fn()
 e1.record(); torch.cuda.synchronize()

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""CPU-only ranking of the rounding sites behind the end-to-end parity figure: the fp32 oracle against the oracle with the
+product's operand roundings emulated (oracle/emulate.py), FULL width, with one layer family at a time exempted on top of the product plan
+(fp16 operands, split-precision VAE decoder).  Prints per-pixel max-abs and rms in [0, 1]; rms ranks the families, max-abs is what the test asserts.
+    python tools/parity_rank.py [T H W steps]      (default 4 64 64 10: ~20 s per plan on 8 cores)"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import emulate as E                      # noqa: E402
+from oracle import pipeline_ref as R                 # noqa: E402
+from videovanish_amd.config import UNetConfig, VAEConfig   # noqa: E402
+from tools.parity_emulate import clip                # noqa: E402
+
+T, H, W, steps = (int(a) for a in (sys.argv[1:5] + ["4", "64", "64", "10"][len(sys.argv) - 1:]))
+ucfg, vcfg = UNetConfig(), VAEConfig()
+frames, m2d, prior = clip(T, H, W)
+torch.set_num_threads(os.cpu_count() or 8)
+dec = lambda n: n.startswith("vae.decoder") or n.startswith("vae.post_quant")
+cheap = lambda n: dec(n) or "time_emb" in n or ((n.startswith("unet.") or n.startswith("brushnet.")) and (n.endswith("conv_in") or n.endswith("conv_out")))
+fam = {
+    "product plan (decoder exact)": lambda n: dec(n),
+    "+ VAE encoder": lambda n: dec(n) or n.startswith("vae."),
+    "+ conv_in / conv_out of UNet, BrushNet": lambda n: dec(n) or ((n.startswith("unet.") or n.startswith("brushnet.")) and (n.endswith("conv_in") or n.endswith("conv_out"))),
+    "+ unet.conv_out only": lambda n: dec(n) or n == "unet.conv_out",
+    "+ unet.conv_in only": lambda n: dec(n) or n == "unet.conv_in",
+    "+ time embedding (linear_1/2, time_emb_proj)": lambda n: dec(n) or "time_emb" in n,
+    "+ BrushNet zero convolutions": lambda n: dec(n) or n.startswith("brushnet.brushnet_"),
+    "+ ResBlock convolutions + shortcuts": lambda n: dec(n) or (".resnets." in n and "time_emb" not in n),
+    "+ down / up samplers": lambda n: dec(n) or "samplers" in n,
+    "+ spatial transformers (all linears)": lambda n: dec(n) or ".attentions." in n,
+    "+ motion modules (all linears)": lambda n: dec(n) or ".motion_modules." in n,
+    "+ whole BrushNet": lambda n: dec(n) or n.startswith("brushnet."),
+    "+ whole UNet": lambda n: dec(n) or n.startswith("unet."),
+    "cheap set (conv_in/out + time emb)": cheap,
+    "cheap + UNet level 3 + mid (down 3, mid, up 0)": lambda n: cheap(n) or n.startswith("unet.down_blocks.3") or n.startswith("unet.mid_block") or n.startswith("unet.up_blocks.0"),
+    "cheap + UNet level 2 (down 2, up 1)": lambda n: cheap(n) or n.startswith("unet.down_blocks.2") or n.startswith("unet.up_blocks.1"),
+    "cheap + UNet level 1 (down 1, up 2)": lambda n: cheap(n) or n.startswith("unet.down_blocks.1") or n.startswith("unet.up_blocks.2"),
+    "cheap + UNet level 0 (down 0, up 3)": lambda n: cheap(n) or n.startswith("unet.down_blocks.0") or n.startswith("unet.up_blocks.3"),
+    "cheap + UNet up path": lambda n: cheap(n) or n.startswith("unet.up_blocks"),
+    "cheap + UNet up_blocks.3 (last level-0 block)": lambda n: cheap(n) or n.startswith("unet.up_blocks.3"),
+    "cheap + UNet up_blocks.3 resnets only": lambda n: cheap(n) or (n.startswith("unet.up_blocks.3") and ".resnets." in n),
+}
+only = os.environ.get("VV_RANK_ONLY")
+if only:
+    fam = {k: v for k, v in fam.items() if any(o in k for o in only.split("|")) or k.startswith("product plan")}
+kw = dict(steps=steps, chunk=T, overlap=0, seed=7, ucfg=ucfg, vcfg=vcfg, return_float=True)
+t0 = time.time()
+ref = R.diffueraser_forward(frames, m2d, prior, **kw)
+print(f"# full width, T={T} {W}x{H}, {steps} DDIM steps; oracle {time.time() - t0:.0f} s per run", flush=True)
+rows = []
+for name, ex in fam.items():
+    with E.emulate(dtype=torch.float16, exact=ex):
+        got = R.diffueraser_forward(frames, m2d, prior, **kw)
+    e = np.abs(got - ref)
+    rows.append((name, e.max(), np.sqrt((e ** 2).mean())))
+    print(f"{name:50s} max_abs={e.max():.3e} rms={rows[-1][2]:.3e}", flush=True)
+for cls, label in ((("w", "a"), "product plan, attention operands + P exact"), (("a", "qkv", "p"), "product plan, ALL weights exact"), (("w", "qkv", "p"), "product plan, ALL GEMM activations exact")):
+    with E.emulate(dtype=torch.float16, classes=cls, exact=dec):
+        got = R.diffueraser_forward(frames, m2d, prior, **kw)
+    e = np.abs(got - ref)
+    print(f"{label:50s} max_abs={e.max():.3e} rms={np.sqrt((e ** 2).mean()):.3e}", flush=True)

@@ -52,6 +52,8 @@ class RunConfig:
     # profiles/r2_parity_gpu.txt): fp16 MFMA operands (the reference itself computes in fp16 on GPU) + split-precision VAE decoder.
     # dtype="bf16", precise_decoder=False is ~5 % faster at 1e-2.
     dtype: str = "fp16"           # MFMA operand type: "bf16" | "fp16"
+    # time-embedding linears + the UNet's conv_in / conv_out in split precision too (round 4: ~0.1 % of a step, -7 % rms error: tools/parity_rank.py)
+    precise_io: bool = True
     precise_decoder: bool = True  # VAE decoder GEMMs as 3 split-precision passes (hi/lo operands): +3 % time at 50 steps, halves the pixel error
     # temporal scheme: "chunks" = independent `chunk`-frame clips + overlap cross-fade (build-defined, shards over GPUs);
     # "reference" = the third-party pipeline's own scheme (22-frame windows shifted on odd steps, value/count averaging, key-frame

@@ -75,6 +75,9 @@ class Conv:
         if geglu:
             w2, bias_t = packing.geglu_interleave(weight.reshape(weight.shape[0], -1), bias_t)
             wp, self.K = packing.pack_matrix(w2, ctx.h16, geglu=True), w2.shape[1]
+        elif precise and weight.device.type == "meta":                      # shape-only construction (modelhub.manifest)
+            self.cp = weight.shape[1] if cin_pad is None else cin_pad
+            wp, self.K = weight, 3 * self.cp * k * k
         elif precise:
             cp = weight.shape[1] if cin_pad is None else cin_pad            # pad the input channels first: the three groups are cp channels each
             wpad = torch.zeros((weight.shape[0], cp) + tuple(weight.shape[2:]), dtype=torch.float32)
@@ -128,7 +131,8 @@ class Linear:
             if geglu:
                 raise RuntimeError("precise GEGLU layers are not supported")
             self.kin = weight.shape[1]
-            weight = split3_weight(weight, ctx.h16)
+            if weight.device.type != "meta":
+                weight = split3_weight(weight, ctx.h16)
         self.K = weight.shape[1]
         self.w = ctx.dev(packing.pack_matrix(weight, ctx.h16, geglu=geglu))
         self.b = ctx.dev(bias_t.float()) if bias_t is not None else None
@@ -173,11 +177,12 @@ class LayerNorm:
 class ResBlock:
     """ResnetBlock2D: GN+SiLU -> conv3 (+temb) -> GN+SiLU -> conv3 -> + shortcut(x)."""
 
-    def __init__(self, ctx, name, cin, cout, groups, eps, temb_dim=None, precise=False):
+    def __init__(self, ctx, name, cin, cout, groups, eps, temb_dim=None, precise=False, precise_temb=False):
         self.ctx, self.cin, self.cout = ctx, cin, cout
         self.norm1 = GroupNorm(ctx, name + ".norm1", cin, groups, eps, precise=precise)
         self.conv1 = Conv(ctx, name + ".conv1", cin, cout, precise=precise)
-        self.temb = Linear(ctx, name + ".time_emb_proj", temb_dim, cout) if temb_dim else None
+        # precise_temb: the time-embedding projection in split precision -- a one-row GEMM per ResBlock (hoisted out of the denoise loop: free)
+        self.temb = Linear(ctx, name + ".time_emb_proj", temb_dim, cout, precise=precise_temb) if temb_dim else None
         self.norm2 = GroupNorm(ctx, name + ".norm2", cout, groups, eps, precise=precise)
         self.conv2 = Conv(ctx, name + ".conv2", cout, cout, precise=precise)
         self.short = Conv(ctx, name + ".conv_shortcut", cin, cout, k=1, precise=precise) if cin != cout else None

@@ -215,7 +215,7 @@ class DiffuEraserHIP:
         self.run = run or RunConfig()
         self.ctx = Ctx(device, self.run.dtype, self.run.weight_seed, weights=weights)
         text = self.ctx.src.normal("text_states", (1, self.run.unet.text_len, self.run.unet.cross_dim))
-        self.denoiser = Denoiser(self.ctx, self.run.unet, text)
+        self.denoiser = Denoiser(self.ctx, self.run.unet, text, precise_io=self.run.precise_io)
         self.vae = VAE(self.ctx, self.run.vae, precise_decoder=self.run.precise_decoder)
         self.ac = alphas_cumprod()
         self.taps = imageops.gaussian_taps_21()

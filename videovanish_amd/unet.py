@@ -29,14 +29,19 @@ def sinusoidal_pos_emb(n, dim):
 class _Backbone:
     """Shared down/mid/up structure of the UNet and of BrushNet."""
 
-    def __init__(self, ctx, pre, cfg, text_h16, motion, in_pad):
+    def __init__(self, ctx, pre, cfg, text_h16, motion, in_pad, precise_io=True):
+        """precise_io (round 4, tools/parity_rank.py): the layers whose operand rounding buys the most error for the least work run in split
+        precision (nn.split3_weight: hi / lo operands, 3 x the layer's FLOPs) -- the time-embedding linears and every ResBlock's time_emb_proj
+        (one-row GEMMs, hoisted out of the denoise loop), and the UNet's conv_in / conv_out (4 <-> 320 channels: 0.1 % of a step's FLOPs, but
+        their rounding sits directly on the network's input latents and on the predicted noise)."""
         self.ctx, self.cfg, self.pre, self.motion = ctx, cfg, pre, motion
+        self.precise_io = bool(precise_io)
         bo, L, lpb = cfg.block_out, len(cfg.block_out), cfg.layers_per_block
         td = cfg.temb_dim
-        self.t1 = Linear(ctx, pre + ".time_embedding.linear_1", bo[0], td)
-        self.t2 = Linear(ctx, pre + ".time_embedding.linear_2", td, td)
+        self.t1 = Linear(ctx, pre + ".time_embedding.linear_1", bo[0], td, precise=self.precise_io)
+        self.t2 = Linear(ctx, pre + ".time_embedding.linear_2", td, td, precise=self.precise_io)
         cin_real = cfg.in_ch if motion else cfg.brush_in_ch
-        self.conv_in = Conv(ctx, pre + ".conv_in", cin_real, bo[0], cin_pad=in_pad)
+        self.conv_in = Conv(ctx, pre + ".conv_in", cin_real, bo[0], cin_pad=in_pad, precise=self.precise_io and motion)
         pes = {}
 
         def pe(C):
@@ -45,7 +50,7 @@ class _Backbone:
             return pes[C]
 
         def layer(name_res, name_attn, name_mot, cin, cout, attn):
-            r = ResBlock(ctx, name_res, cin, cout, cfg.groups, 1e-5, td)
+            r = ResBlock(ctx, name_res, cin, cout, cfg.groups, 1e-5, td, precise_temb=self.precise_io)
             a = SpatialTransformer(ctx, name_attn, cout, cfg, text_h16) if attn else None
             m = MotionModule(ctx, name_mot, cout, cfg, pe(cout)) if motion else None
             return r, a, m
@@ -66,10 +71,10 @@ class _Backbone:
                 skip_ch.append(cout)
         self.skip_ch = list(skip_ch)
         C = bo[-1]
-        self.mid_r0 = ResBlock(ctx, f"{pre}.mid_block.resnets.0", C, C, cfg.groups, 1e-5, td)
+        self.mid_r0 = ResBlock(ctx, f"{pre}.mid_block.resnets.0", C, C, cfg.groups, 1e-5, td, precise_temb=self.precise_io)
         self.mid_a = SpatialTransformer(ctx, f"{pre}.mid_block.attentions.0", C, cfg, text_h16)
         self.mid_m = MotionModule(ctx, f"{pre}.mid_block.motion_modules.0", C, cfg, pe(C)) if motion else None
-        self.mid_r1 = ResBlock(ctx, f"{pre}.mid_block.resnets.1", C, C, cfg.groups, 1e-5, td)
+        self.mid_r1 = ResBlock(ctx, f"{pre}.mid_block.resnets.1", C, C, cfg.groups, 1e-5, td, precise_temb=self.precise_io)
         self.up, self.ups, self.up_ch = [], [], []
         rev, rev_attn = list(reversed(bo)), list(reversed(cfg.attn_levels))
         x_ch = C
@@ -179,8 +184,8 @@ class _Backbone:
 
 
 class BrushNet(_Backbone):
-    def __init__(self, ctx, cfg, text_h16):
-        super().__init__(ctx, "brushnet", cfg, text_h16, motion=False, in_pad=16)
+    def __init__(self, ctx, cfg, text_h16, precise_io=True):
+        super().__init__(ctx, "brushnet", cfg, text_h16, motion=False, in_pad=16, precise_io=precise_io)
         zg = cfg.zero_conv_gain
         self.zd = [Conv(ctx, f"brushnet.brushnet_down_blocks.{i}", c, c, k=1, gain=zg) for i, c in enumerate(self.skip_ch)]
         self.zm = Conv(ctx, "brushnet.brushnet_mid_block", cfg.block_out[-1], cfg.block_out[-1], k=1, gain=zg)
@@ -210,10 +215,10 @@ class BrushNet(_Backbone):
 
 
 class UNetMotion(_Backbone):
-    def __init__(self, ctx, cfg, text_h16):
-        super().__init__(ctx, "unet", cfg, text_h16, motion=True, in_pad=8)
-        self.norm_out = GroupNorm(ctx, "unet.conv_norm_out", cfg.block_out[0], cfg.groups, 1e-5)
-        self.conv_out = Conv(ctx, "unet.conv_out", cfg.block_out[0], cfg.out_ch)
+    def __init__(self, ctx, cfg, text_h16, precise_io=True):
+        super().__init__(ctx, "unet", cfg, text_h16, motion=True, in_pad=8, precise_io=precise_io)
+        self.norm_out = GroupNorm(ctx, "unet.conv_norm_out", cfg.block_out[0], cfg.groups, 1e-5, precise=self.precise_io)      # emits the split operand itself
+        self.conv_out = Conv(ctx, "unet.conv_out", cfg.block_out[0], cfg.out_ch, precise=self.precise_io)
 
     def down_mid(self, lat8, t, F, h, w):
         st = self.temb(t)
@@ -231,11 +236,11 @@ class UNetMotion(_Backbone):
 class Denoiser:
     """eps = UNet(latents, t | BrushNet(cat[latents, cond, mask], t)) for one clip."""
 
-    def __init__(self, ctx, cfg, text_states):
+    def __init__(self, ctx, cfg, text_states, precise_io=True):
         self.ctx, self.cfg = ctx, cfg
         text_h16 = ctx.dev(text_states[0], ctx.h16)
-        self.unet = UNetMotion(ctx, cfg, text_h16)
-        self.brush = BrushNet(ctx, cfg, text_h16)
+        self.unet = UNetMotion(ctx, cfg, text_h16, precise_io=precise_io)
+        self.brush = BrushNet(ctx, cfg, text_h16, precise_io=precise_io)
 
     # Two-stream schedule (default since round 4; measured in profiles/r3_two_stream_ab.txt: +2.4 %, bit-identical): the BrushNet backbone does
     # not depend on the UNet's down / mid path (only its zero convolutions add the UNet skips), so the two share the GPU.  Kernels of two streams
@@ -263,7 +268,8 @@ class Denoiser:
     def __call__(self, lat, cond, mask2d, t, F, h, w, H, W):
         """lat, cond: fp32 [F,h,w,4] device; mask2d: u8 [F,H,W]."""
         ctx = self.ctx
-        lat8 = hip.pad_channels(ctx.dt, lat, 8).view(F * h * w, 8)
+        # (precise_io: conv_in takes the fp32 latents and splits them itself -- no rounding of the network input to h16)
+        lat8 = (hip.pad_channels_f32(lat, 8) if self.unet.precise_io else hip.pad_channels(ctx.dt, lat, 8)).view(F * h * w, 8)
         x16 = hip.brushnet_input(ctx.dt, lat, cond, mask2d, H, W).view(F * h * w, 16)
         pre = None
         if Denoiser.OVERLAP and hip.PROFILE is None and not getattr(Denoiser.lane, "concurrent", False):
