@@ -6,6 +6,8 @@ import torch
 from videovanish_amd import hip
 if os.environ.get("VV_LIB_PATH"):
     hip._LIB_PATH = os.environ["VV_LIB_PATH"]          # lab: A/B of two builds of the library on one device
+if os.environ.get("VV_LIB_PATH"):
+    hip._LIB_PATH = os.environ["VV_LIB_PATH"]          # lab: A/B of two builds of the library on one device
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dname = sys.argv[2] if len(sys.argv) > 2 else "fp16"

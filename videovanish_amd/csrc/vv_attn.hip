@@ -680,17 +680,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
     constexpr float MARGIN = -4.0f;     // P = 2^4 at the sample maximum: see the comment above attn40_kernel (round 4)
     // FOUR arrays, not one: hipcc drains vmcnt(0) in front of a ds_read that may alias an LDS-DMA in flight, and tells buffers apart only as
     // distinct __shared__ objects (the DMA of step `it` targets the buffers the step does not read)
-    // (round 4) EIGHT of them: a step covers TWO 64-key tiles -- one s_waitcnt + barrier per 128 keys, the next two tiles' DMA in flight over the
-    // whole step -- so the four waves of a block re-synchronise half as often (profiles/r4_attn40q2_pmc.txt: 17 % of the wave cycles were spent parked
-    // at the per-tile barrier of the two-buffer form).  68 KB of LDS per block, two blocks per CU.
     __shared__ __attribute__((aligned(1024))) unsigned char dK0[TILE + KONES];
     __shared__ __attribute__((aligned(1024))) unsigned char dK1[TILE + KONES];
-    __shared__ __attribute__((aligned(1024))) unsigned char dK2[TILE + KONES];
-    __shared__ __attribute__((aligned(1024))) unsigned char dK3[TILE + KONES];
     __shared__ __attribute__((aligned(1024))) unsigned char dV0[TILE + VONES];
     __shared__ __attribute__((aligned(1024))) unsigned char dV1[TILE + VONES];
-    __shared__ __attribute__((aligned(1024))) unsigned char dV2[TILE + VONES];
-    __shared__ __attribute__((aligned(1024))) unsigned char dV3[TILE + VONES];
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -730,14 +723,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
     {
         const unsigned one2 = (unsigned)T::from_f32(1.0f) * 0x10001u;
         const uint4 ones = make_uint4(one2, one2, one2, one2), zero = make_uint4(0, 0, 0, 0);
-        for (int i = t; i < (TILE + KONES) / 16; i += NT) {
-            const uint4 v = i < TILE / 16 ? zero : ones;
-            *(uint4*)(dK0 + i * 16) = v; *(uint4*)(dK1 + i * 16) = v; *(uint4*)(dK2 + i * 16) = v; *(uint4*)(dK3 + i * 16) = v;
-        }
-        for (int i = t; i < (TILE + VONES) / 16; i += NT) {
-            const uint4 v = i < TILE / 16 ? zero : ones;
-            *(uint4*)(dV0 + i * 16) = v; *(uint4*)(dV1 + i * 16) = v; *(uint4*)(dV2 + i * 16) = v; *(uint4*)(dV3 + i * 16) = v;
-        }
+        for (int i = t; i < (TILE + KONES) / 16; i += NT) { *(uint4*)(dK0 + i * 16) = i < TILE / 16 ? zero : ones; *(uint4*)(dK1 + i * 16) = i < TILE / 16 ? zero : ones; }
+        for (int i = t; i < (TILE + VONES) / 16; i += NT) { *(uint4*)(dV0 + i * 16) = i < TILE / 16 ? zero : ones; *(uint4*)(dV1 + i * 16) = i < TILE / 16 ? zero : ones; }
     }
     __syncthreads();
 
@@ -850,7 +837,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
         __syncthreads();                                          // everybody is done with the sample (the last sweep tile)
         dma(0, 0, dK0, 1u);
         dma(1, 0, dV0, 1u);
-        if (ntiles > 1) { dma(0, 1, dK1, 1u); dma(1, 1, dV1, 1u); }
 #pragma unroll
         for (int x = 0; x < QB; ++x) {
 #pragma unroll
@@ -896,19 +882,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
                 }
             }
         };
-        // step `it`: tiles it, it + 1 (K and V) have landed in the c buffers; issue tiles it + 2, it + 3 into the n buffers (read two steps ago)
-        auto step = [&](const int it, unsigned char* cK0, unsigned char* cV0, unsigned char* cK1, unsigned char* cV1,
-                        unsigned char* nK0, unsigned char* nV0, unsigned char* nK1, unsigned char* nV1) {
+        // step `it`: tile `it` (K and V) has landed; issue tile it+1 into the other buffers
+        auto step = [&](const int it, unsigned char* cK, unsigned char* cV, unsigned char* nK, unsigned char* nV) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (it + 2 < ntiles) { dma(0, it + 2, nK0, 1u); dma(1, it + 2, nV0, 1u); }
-            if (it + 3 < ntiles) { dma(0, it + 3, nK1, 1u); dma(1, it + 3, nV1, 1u); }
-            body(cK0, cV0, it + 1 == ntiles);
-            if (it + 1 < ntiles) body(cK1, cV1, it + 2 == ntiles);
+            if (it + 1 < ntiles) { dma(0, it + 1, nK, 1u); dma(1, it + 1, nV, 1u); }
+            body(cK, cV, it + 1 == ntiles);
         };
-        for (int it = 0; it < ntiles; it += 4) {
-            step(it, dK0, dV0, dK1, dV1, dK2, dV2, dK3, dV3);
-            if (it + 2 < ntiles) step(it + 2, dK2, dV2, dK3, dV3, dK0, dV0, dK1, dV1);
+        for (int it = 0; it < ntiles; it += 2) {
+            step(it, dK0, dV0, dK1, dV1);
+            if (it + 1 < ntiles) step(it + 1, dK1, dV1, dK0, dV0);
         }
         // ---- denominators (O^T row 40 = register 0 of the row-32.. tiles on the lanes 32..47); non-finite or zero: repeat with the exact maximum
         bool bad = false;

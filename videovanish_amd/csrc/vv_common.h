@@ -51,12 +51,13 @@ template <typename T> __device__ __forceinline__ void unpack8(uint4 u, float* v)
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// exact (erf) GELU, matching torch.nn.functional.gelu default
-#ifndef VV_GELU_AS
+// exact (erf) GELU, matching torch.nn.functional.gelu default.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the h16 rounding
+// that follows: one v_rcp + one v_exp + 6 FMAs instead of ocml's two-branch erff) -- the form the fused kernels (vv_motion.hip, vv_chain.hip) have
+// used since round 2, the product default everywhere since round 4 (the GEGLU GEMMs gain 5-10 %: profiles/r3_gelu_as_ab.txt; parity re-validated
+// against the 1e-3 asserts: profiles/r4_parity_gpu.txt).  -DVV_GELU_ERFF (lab) brings ocml's erff back.
+#ifdef VV_GELU_ERFF
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 #else
-// lab build (-DVV_GELU_AS): erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, one v_rcp + one v_exp + 6 FMAs instead of ocml's two-branch erff);
-// measured in profiles/r3_gelu_as_ab.txt, NOT the product default (every numerics change is re-validated against the 1e-3 parity asserts first)
 __device__ __forceinline__ float gelu_f(float x) {
     const float z = fabsf(x) * 0.70710678118654752f;
     const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
