@@ -460,6 +460,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
             qf[s] = pack8<T>(qv);
         }
     }
+    const float dg = attn40_diag_score<T>(p, Kp, qf, q0 + r, h);      // self-attention: score against the query's own key (part of the reference sample)
     // ---- constant regions (written once): 1.0 everywhere; the tile buffers start as zeros (rows of a ragged tile that are never loaded stay finite)
     {
         const unsigned one2 = (unsigned)T::from_f32(1.0f) * 0x10001u;
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             qk(dK1, sA);
-            set_reference(fmaxf(row_max(sA), attn40_diag_score<T>(p, Kp, qf, q0 + r, h)) + MARGIN);
+            set_reference(fmaxf(row_max(sA), dg) + MARGIN);
         } else {
             qf[2].x = h == 1 ? 0u : qf[2].x;                      // plain scores again
             float mx = -1e30f;
@@ -719,6 +720,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
             qf[x][s] = pack8<T>(qv);
         }
     }
+    float dg[QB];                                              // self-attention: score against the query's own key (part of the reference sample)
+#pragma unroll
+    for (int x = 0; x < QB; ++x) dg[x] = attn40_diag_score<T>(p, Kp, qf[x], q0 + 32 * x + r, h);
     // ---- constant regions (written once): 1.0 everywhere; the tile buffers start as zeros (rows of a ragged tile that are never loaded stay finite)
     {
         const unsigned one2 = (unsigned)T::from_f32(1.0f) * 0x10001u;
@@ -813,7 +817,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
 #pragma unroll
-            for (int x = 0; x < QB; ++x) { qk(dK1, x, sc[x]); set_reference(x, fmaxf(row_max(sc[x]), attn40_diag_score<T>(p, Kp, qf[x], q0 + 32 * x + r, h)) + MARGIN); }
+            for (int x = 0; x < QB; ++x) { qk(dK1, x, sc[x]); set_reference(x, fmaxf(row_max(sc[x]), dg[x]) + MARGIN); }
         } else {
             float mx[QB];
 #pragma unroll
