@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VV_ABI_VERSION 9
+#define VV_ABI_VERSION 8
 
 enum { VV_BF16 = 0, VV_F16 = 1, VV_F32 = 2, VV_U8 = 3,
        VV_SPLIT3 = 16 /* vv_groupnorm out_dtype only: the K-concatenated split-precision operand [rows][3C] of vv_split3, in the operand dtype */ };
@@ -88,17 +88,8 @@ typedef struct {
                              the shape is eligible (h16 sources with channel counts % 64 == 0, <= 9 taps, no fused resize,
                              Npad % 320 or % 256 == 0; 8-phase: Npad % 256 == 0) */
     float act_slope;      /* VV_ACT_LRELU: negative-side slope (ProPainter: 0.1 in the alignment offset stacks, 0.2 in the encoders) */
-    float* stats_out;     /* ABI 9, optional: GroupNorm partial statistics of the OUTPUT, emitted by the epilogue so that the consumer's statistics
-                             pass (a full re-read of the tensor this launch just wrote) disappears.  [F][stats_slots][N][2] floats, ZEROED by the
-                             caller: (sum, sum of squares) of out[.][n] over the rows one wave owns, per frame; a wave writes only its own slots
-                             (no atomics: the values do not depend on arrival order), vv_groupnorm sums the slots in index order in double.
-                             Needs: fp32 output, ldo == N, N % 4 == 0, no GEGLU / head split, (Hout * Wout) % 16 == 0, and
-                             stats_slots >= vv_conv_gemm_stats_slots(Hin, Win, Hout, Wout); refused with VV_E_ARG otherwise */
-    int32_t stats_slots;
 } vv_conv_params;
 int vv_conv_gemm(const vv_conv_params* host_p, int dtype, void* stream);
-/* slots per frame that every tiling of vv_conv_gemm stays inside when it emits stats_out (host-side arithmetic, no launch) */
-int vv_conv_gemm_stats_slots(int Hin, int Win, int Hout, int Wout);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K2  GroupNorm (+SiLU) and LayerNorm (+positional embedding), fp32 statistics, h16 output.
@@ -116,9 +107,6 @@ typedef struct {
     int32_t silu;                       /* activation after the affine: VV_ACT_NONE / VV_ACT_SILU / VV_ACT_RELU */
     float* stats_ws;                    /* workspace: F * (nsplit + 1) * groups * 2 floats, nsplit = vv_groupnorm_nsplit() */
     void* out; int32_t out_dtype;       /* [F*HW][C] h16 (or fp32) */
-    const float* stats0; const float* stats1;   /* ABI 9, optional: the producers' partial statistics of in0 / in1 (vv_conv_params.stats_out: [F][slots][C0 | C1][2]).
-                                                   When every source has them the statistics pass over the tensor is skipped */
-    int32_t slots0, slots1;
 } vv_groupnorm_params;
 int vv_groupnorm_nsplit(int HW, int C);
 int vv_groupnorm(const vv_groupnorm_params* host_p, int dtype, void* stream);

@@ -2,8 +2,13 @@
 (reference call sites sam2_masker.py:88 `build_sam2_video_predictor`, :93 `init_state`, :122/:135
 `add_new_points_or_box`, :147 `propagate_in_video`).
 
-Only tests/ and tools/ benchmarks' baseline legs may import this file.  PARITY UNPINNED: the `sam2` package is third-party, absent from
-/root/reference and un-pinned (github.com/calledit/sam2_numpy_frames); the reference holds no tests or vectors for it.  What follows restates
+Only tests/ and tools/ benchmarks' baseline legs may import this file.  The `sam2` package is third-party, absent from /root/reference and un-pinned
+(github.com/calledit/sam2_numpy_frames); the reference holds no tests or vectors for it.  PINNED SINCE ROUND 4 against an independent published
+implementation of the same network, `transformers.models.sam2_video` (Hugging Face): tests/golden/make_sam2_hf_fixtures.py loads the SAME name-seeded
+weights into `Sam2VideoModel` through an explicit name map and stores its inputs / outputs stage by stage; tests/test_sam2_cpu.py::
+test_oracle_matches_transformers_sam2_vectors re-runs this file on them: <= 5e-7 of the output range on the image encoder, the prompted frame (click /
+box + negative click / click + mask prompt), the memory encoder and a tracked frame (memory selection, temporal encodings, object pointers, RoPE
+memory attention).  Not covered by that pin (no counterpart runs offline): the numpy-frames fork's own frame loading, `fill_holes`.  What follows restates
 the published SAM 2.1 modules (hieradet.py, image_encoder.py, position_encoding.py, memory_attention.py, memory_encoder.py,
 sam/prompt_encoder.py, sam/mask_decoder.py, sam/transformer.py, sam2_base.py, utils/misc.py::fill_holes_in_mask_scores) [UNVERIFIED-3P];
 the parameter manifest these functions consume has the published 224.4 M parameters (tests/test_sam2_cpu.py).

@@ -541,60 +541,3 @@ def test_attention_d40_heavy_tail(gpu, orders):
     e64, e32 = (got - ref).abs().max().item(), (got32 - ref[:, :640]).abs().max().item()
     print(f"attention d40 heavy tail [{orders} orders, bulk share {bulk_share:.3f}]: max-abs {e64:.2e} (64 q / wave), {e32:.2e} (32 q / wave), tol {tol:.2e}")
     assert torch.isfinite(got).all() and e64 <= tol and e32 <= tol
-
-
-@pytest.mark.parametrize("case", [
-    dict(F=3, H=30, W=40, cin=64, cout=160, k=3, stride=1, res=True),        # halo tiling (8 x 16 patches, ragged bottom / right), 1200 pixels per frame
-    dict(F=3, H=30, W=40, cin=128, cout=320, k=1, stride=1, res=False),      # linear 128-row tiles (LIN loader): 1200 % 64 = 48 -> wave segments straddle frames
-    dict(F=2, H=24, W=48, cin=128, cout=128, k=3, stride=2, res=False),      # stride 2 (FAST9 loader), 128 x 128 tile
-    dict(F=5, H=16, W=24, cin=64, cout=160, k=1, stride=1, res=True, f32in=True),   # fp32 A tile (FAST32), frames of 384 rows: six wave segments each
-    dict(F=8, H=90, W=160, cin=640, cout=320, k=3, stride=1, res=True),             # the 256 x 320 tile kernel (K = 5760, 450 x 1 tiles: 128-row wave segments)
-    dict(F=2, H=32, W=48, cin=128, cout=160, k=3, stride=1, res=False, cat=True),   # halo tiling with a channel-concat INPUT (two NHWC sources)
-])
-def test_conv_gemm_epilogue_statistics(gpu, case):
-    """vv_conv_params.stats_out (ABI 9): the GEMM's epilogue emits, per (frame, slot, channel), the sum and the sum of squares of the values it stores;
-    summed over the slots they are the GroupNorm statistics of the output tensor -- checked against torch on the stored fp32 output itself, for every
-    tiling (halo patches, linear 128- and 256-row tiles, wave segments that straddle a frame), bit-identical from run to run; a GroupNorm fed with them
-    equals the GroupNorm that reads the tensor twice to a few fp32 ulps of the statistics (per frame, clip-pooled and over a channel concat)."""
-    from videovanish_amd import hip, packing
-    td, dt = torch.float16, hip.F16
-    g = torch.Generator().manual_seed(5)
-    Fr, H, W, cin, cout, k, stride = (case[x] for x in ("F", "H", "W", "cin", "cout", "k", "stride"))
-    x = torch.randn(Fr, H, W, cin, generator=g)
-    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
-    b = torch.randn(cout, generator=g)
-    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
-    res = (torch.randn(Fr * Ho * Wo, cout, generator=g) * 3 + 0.7).to(gpu) if case.get("res") else None
-    wp, K = packing.pack_conv(w, td)
-    xin = x.to(gpu) if case.get("f32in") else x.to(td).to(gpu)
-    kw = dict(F=Fr, Hin=H, Win=W, Hout=Ho, Wout=Wo, ksize=k, stride=stride, pad_t=k // 2, pad_l=k // 2, bias=b.to(gpu), res0=res, out_dtype=torch.float32)
-    if case.get("cat"):
-        x0, x1 = xin[..., :cin // 2].contiguous(), xin[..., cin // 2:].contiguous()
-        run = lambda stats: hip.conv_gemm(dt, x0, wp.to(gpu), cout, K, x1=x1, stats=stats, **kw)
-    else:
-        run = lambda stats: hip.conv_gemm(dt, xin, wp.to(gpu), cout, K, stats=stats, **kw)
-    out = run(True)
-    st = getattr(out, hip.GN_STATS, None)
-    assert st is not None and st[1:] == (hip.lib().vv_conv_gemm_stats_slots(H, W, Ho, Wo), Fr, Ho * Wo, cout)
-    plain = run(False)
-    assert getattr(plain, hip.GN_STATS, None) is None and torch.equal(out, plain)               # the stored values do not change
-    sums = st[0].double().sum(1).cpu()                                                          # [F, C, 2]
-    o = out.double().cpu().reshape(Fr, Ho * Wo, cout)
-    ref = torch.stack([o.sum(1), (o * o).sum(1)], -1)
-    scale = torch.stack([o.abs().sum(1), (o * o).sum(1)], -1)
-    assert ((sums - ref).abs() / scale).max().item() < 2e-6
-    out2 = run(True)
-    assert torch.equal(getattr(out2, hip.GN_STATS)[0], st[0])                                   # no atomics: bit-identical partial sums
-    # a GroupNorm that takes them instead of reading the tensor twice
-    gamma, beta = torch.randn(cout, generator=g).to(gpu), torch.randn(cout, generator=g).to(gpu)
-    for pool in (False, True):
-        a = hip.groupnorm(dt, out, gamma, beta, 32, 1e-5, F=Fr, HW=Ho * Wo, silu=True, pool_frames=pool, out_dtype=torch.float32)
-        b2 = hip.groupnorm(dt, plain, gamma, beta, 32, 1e-5, F=Fr, HW=Ho * Wo, silu=True, pool_frames=pool, out_dtype=torch.float32)
-        assert (a - b2).abs().max().item() <= 2e-5 * max(1.0, b2.abs().max().item())
-    # channel concat of two producers (an up-path ResBlock's norm1): both sources must carry statistics
-    g2 = torch.randn(2 * cout, generator=g).to(gpu)
-    a = hip.groupnorm(dt, out, g2, g2, 32, 1e-5, x1=out2, F=Fr, HW=Ho * Wo, silu=True, out_dtype=torch.float32)
-    b2 = hip.groupnorm(dt, plain, g2, g2, 32, 1e-5, x1=run(False), F=Fr, HW=Ho * Wo, silu=True, out_dtype=torch.float32)
-    assert (a - b2).abs().max().item() <= 2e-5 * max(1.0, b2.abs().max().item())
-    mixed = hip.groupnorm(dt, out, g2, g2, 32, 1e-5, x1=plain, F=Fr, HW=Ho * Wo, silu=True, out_dtype=torch.float32)      # one source without: the old path
-    assert torch.equal(mixed, b2)

@@ -19,6 +19,9 @@ from tools.parity_emulate import clip                # noqa: E402
 
 T, H, W, steps = (int(a) for a in (sys.argv[1:5] + ["4", "64", "64", "10"][len(sys.argv) - 1:]))
 ucfg, vcfg = UNetConfig(), VAEConfig()
+if os.environ.get("VV_RANK_ARCH") == "tiny":      # the smoke test's architecture
+    from videovanish_amd.config import TINY_UNET, TINY_VAE
+    ucfg, vcfg = TINY_UNET, TINY_VAE
 frames, m2d, prior = clip(T, H, W)
 torch.set_num_threads(os.cpu_count() or 8)
 dec = lambda n: n.startswith("vae.decoder") or n.startswith("vae.post_quant")
@@ -52,7 +55,7 @@ if only:
 kw = dict(steps=steps, chunk=T, overlap=0, seed=7, ucfg=ucfg, vcfg=vcfg, return_float=True)
 t0 = time.time()
 ref = R.diffueraser_forward(frames, m2d, prior, **kw)
-print(f"# full width, T={T} {W}x{H}, {steps} DDIM steps; oracle {time.time() - t0:.0f} s per run", flush=True)
+print(f"# {os.environ.get('VV_RANK_ARCH', 'full')} width, T={T} {W}x{H}, {steps} DDIM steps; oracle {time.time() - t0:.0f} s per run", flush=True)
 rows = []
 for name, ex in fam.items():
     with E.emulate(dtype=torch.float16, exact=ex):

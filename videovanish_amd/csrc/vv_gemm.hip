@@ -93,13 +93,12 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
     const int tile_n = bid % tilesN, tile_m = bid / tilesN;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     // HALO: tile_m -> (frame, patch row, patch column)
-    int hf = 0, hy0 = 0, hx0 = 0, hslot = 0;
+    int hf = 0, hy0 = 0, hx0 = 0;
     if (HALO) {
         const int PW = (p.Win + 15) >> 4, PH = (p.Hin + 7) >> 3;
         hf = tile_m / (PH * PW);
         const int r = tile_m - hf * (PH * PW);
         hy0 = (r / PW) * 8; hx0 = (r % PW) * 16;
-        hslot = r * WR + wr;                   // statistics slot of this wave's four patch rows (vv_conv_params.stats_out)
     }
     // tile row -> output row m (and whether it exists)
     auto row_m = [&](int row, bool& ok) -> int {
@@ -394,7 +393,7 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
         }
     }
 
-    gemm_epilogue<T, MT, NT>(p, acc, wr * MT * 16, n0 + wc * NT * 16, lr, lq, HWo, row_m, HALO ? hf : -1, hslot);
+    gemm_epilogue<T, MT, NT>(p, acc, wr * MT * 16, n0 + wc * NT * 16, lr, lq, HWo, row_m);
 }
 
 template <typename T, int WR, int WC, int MT, int NT, int MODE>
@@ -437,10 +436,7 @@ int launch_t(const vv_conv_params& p, int M, hipStream_t st) {
     if (pref128 && p.Npad % 128 == 0 && (MODE == MODE_FAST || MODE == MODE_HALO) && M >= 16384) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, M, st);
     if (p.Npad % 160 == 0) return launch_cfg<T, 2, 2, 4, 5, MODE>(p, M, st);   // (a 256x160 4-wave tile measured the same: profiles/r1_gemm_ab.txt)
     if (p.Npad % 128 == 0) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, M, st);
-    if (p.Npad % 16 == 0 && p.Npad <= 64) {
-        if (p.stats_out) VV_FAIL(VV_E_ARG, "vv_conv_gemm: stats_out is not available for N <= 64 (32-row wave segments)");
-        return launch_cfg<T, 4, 1, 2, 1, MODE>(p, M, st);
-    }
+    if (p.Npad % 16 == 0 && p.Npad <= 64) return launch_cfg<T, 4, 1, 2, 1, MODE>(p, M, st);
     VV_FAIL(VV_E_ARG, "vv_conv_gemm: unsupported Npad %d (need %%160, %%128 or 16..64 %%16)", p.Npad);
 }
 
@@ -477,12 +473,6 @@ int launch_mode(const vv_conv_params& p, int M, hipStream_t st) {
 
 }  // namespace
 
-// wave segments are 64 rows (128-row tiles) or 128 rows (256-row tiles) of the M axis, or -- halo tiling -- 2 per 8 x 16 pixel patch
-extern "C" int vv_conv_gemm_stats_slots(int Hin, int Win, int Hout, int Wout) {
-    const int lin = (Hout * Wout) / 64 + 2, halo = ((Hin + 7) / 8) * ((Win + 15) / 16) * 2;
-    return lin > halo ? lin : halo;
-}
-
 extern "C" int vv_conv_gemm(const vv_conv_params* pp, int dtype, void* stream) {
     if (!pp) VV_FAIL(VV_E_ARG, "vv_conv_gemm: null params");
     const vv_conv_params& p = *pp;
@@ -506,10 +496,6 @@ extern "C" int vv_conv_gemm(const vv_conv_params* pp, int dtype, void* stream) {
                               (int64_t)p.N * stok_ > 0x7fffffff))
         VV_FAIL(VV_E_ARG, "vv_conv_gemm: split_heads needs N = 3*heads*dim, dim %% 4 == 0, h16 output, no residual / GEGLU, M %% split_tokens == 0");
     if (p.F <= 0 || p.Hout <= 0 || p.Wout <= 0 || p.Hin <= 0 || p.Win <= 0 || p.Hv <= 0 || p.Wv <= 0) VV_FAIL(VV_E_ARG, "vv_conv_gemm: bad geometry");
-    if (p.stats_out && (p.out_dtype != VV_F32 || p.ldo != p.N || (p.N & 3) || p.epilogue == VV_EPI_GEGLU || p.split_heads > 0 || (p.Hout * p.Wout) % 16 ||
-                        p.stats_slots < vv_conv_gemm_stats_slots(p.Hin, p.Win, p.Hout, p.Wout)))
-        VV_FAIL(VV_E_ARG, "vv_conv_gemm: stats_out needs fp32 output with ldo == N, N %% 4 == 0, no GEGLU / head split, Hout * Wout %% 16 == 0 and "
-                          "stats_slots >= vv_conv_gemm_stats_slots() = %d", vv_conv_gemm_stats_slots(p.Hin, p.Win, p.Hout, p.Wout));
     const int64_t M64 = (int64_t)p.F * p.Hout * p.Wout;
     if (M64 > 0x7fffffff || (int64_t)p.F * p.Hin * p.Win > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_conv_gemm: more than 2^31 pixels");
     const int M = (int)M64;

@@ -4,58 +4,9 @@
 #pragma once
 #include "vv_common.h"
 
-// sum over the 16 lanes of a DPP row (= the 16 rows lr of one column group lq), fixed order: every lane ends with the total
-__device__ __forceinline__ float gemm_row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));      // row_ror:8
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));      // row_ror:4
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));      // row_ror:2
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));      // row_ror:1
-    return v;
-}
-
-// GroupNorm partial statistics of the values this wave just stored (vv_conv_params.stats_out; acc holds the FINAL outputs, zeros where nothing was
-// stored): per column (sum, sum of squares) over the wave's rows of one frame -> p.stats_out[frame][slot][n][2].  A 16-row strip never straddles a
-// frame (Hout * Wout % 16 == 0, checked by the launcher); a wave's strips may: the running sums are flushed when the frame changes.  Slots: linear
-// tilings -- wave segment index (first row / SEG, SEG = MT * 16 rows) minus the index of the segment that holds the frame's first row; halo tiling --
-// handed in.  Each (frame, slot, column) is written by exactly one lane of the grid: no atomics, the consumer sums the slots in index order.
-template <int MT, int NT, typename RowMap>
-__device__ __forceinline__ void gemm_stats(const vv_conv_params& p, const f32x4 (&acc)[MT][NT], RowMap row_m, const int row0, const int ncol0, const int lr,
-                                           const int lq, const int HWo, const int halo_frame, const int halo_slot) {
-    constexpr int SEG = MT * 16;
-    bool ok0;
-    const int mfirst = row_m(row0, ok0);                       // linear tilings: m0 + row0 whether or not the row exists
-    int fr[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) fr[i] = halo_frame >= 0 ? halo_frame : (mfirst + 16 * i) / HWo;      // wave-uniform
-    auto flush = [&](const int f, const int n, float (&s)[4], float (&q)[4]) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s[r] = gemm_row16_sum(s[r]); q[r] = gemm_row16_sum(q[r]); }
-        if (lr == 0 && f < p.F && n < p.N) {
-            const int slot = halo_frame >= 0 ? halo_slot : mfirst / SEG - (int)(((int64_t)f * HWo) / SEG);
-            float* dst = p.stats_out + (((int64_t)f * p.stats_slots + slot) * p.N + n) * 2;
-            *(float4*)dst = make_float4(s[0], q[0], s[1], q[1]);
-            *(float4*)(dst + 4) = make_float4(s[2], q[2], s[3], q[3]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s[r] = 0.f; q[r] = 0.f; }
-    };
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = ncol0 + j * 16 + 4 * lq;
-        float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            if (i > 0 && fr[i] != fr[i - 1]) flush(fr[i - 1], n, s, q);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s[r] += v; q[r] += v * v; }
-        }
-        flush(fr[MT - 1], n, s, q);
-    }
-}
-
 template <typename T, int MT, int NT, typename RowMap>
 __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&acc)[MT][NT], const int row0, const int ncol0, const int lr,
-                                              const int lq, const int HWo, RowMap row_m, const int halo_frame = -1, const int halo_slot = 0) {
+                                              const int lq, const int HWo, RowMap row_m) {
     // ---- epilogue: lane owns out[m][n .. n+3].  All bias / time-embedding / residual loads of one 16-row strip are issued
     // back to back into registers BEFORE their first use (one wait per strip instead of one per load).
     const bool geglu = p.epilogue == VV_EPI_GEGLU;
@@ -122,13 +73,7 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
                     ra4[j] = (mok && n < N) ? *(const float4*)((const float*)p.res0 + rbase + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
-            if (!mok) {
-                if (p.stats_out) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};      // rows that do not exist contribute nothing to the statistics
-                }
-                continue;
-            }
+            if (!mok) continue;
             const float* rowv = p.rowvec ? p.rowvec + (int64_t)(m / HWo) * N : nullptr;
             int64_t rowpart = 0;
             if (split) {
@@ -139,7 +84,7 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = ncol0 + j * 16 + 4 * lq;
-                if (n >= N) { if (p.stats_out) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+                if (n >= N) continue;
                 const float4 bj = p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                 float v[4] = {(acc[i][j][0] + bj.x) * p.out_scale, (acc[i][j][1] + bj.y) * p.out_scale,
                               (acc[i][j][2] + bj.z) * p.out_scale, (acc[i][j][3] + bj.w) * p.out_scale};
@@ -158,10 +103,8 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
                 const int64_t oc = split ? rowpart + colpart[j] : (int64_t)m * p.ldo + n;
                 if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + oc) = make_float4(v[0], v[1], v[2], v[3]);
                 else *(uint2*)((unsigned short*)p.out + oc) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
-                if (p.stats_out) acc[i][j] = f32x4{v[0], v[1], v[2], v[3]};                  // the stored value (fp32 output: exactly what the consumer reads)
             }
         }
-        if (p.stats_out) gemm_stats<MT, NT>(p, acc, row_m, row0, ncol0, lr, lq, HWo, halo_frame, halo_slot);
         return;
     }
     // scalar tail path (N or ldo not a multiple of 4: e.g. the 3-channel VAE conv_out)

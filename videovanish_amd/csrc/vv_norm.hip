@@ -133,42 +133,6 @@ __global__ __launch_bounds__(256) void gn_finalize_pooled_kernel(const vv_groupn
     for (int f = t; f < p.F; f += 256) { fin[((int64_t)f * p.groups + grp) * 2] = (float)mean; fin[((int64_t)f * p.groups + grp) * 2 + 1] = rstd; }
 }
 
-// statistics from the producers' epilogues (vv_conv_params.stats_out: [F][slots][C0 | C1][2] per source): ONE BLOCK PER (frame | clip, group) sums the
-// group's channels over every slot (and frame, when pooled) -- thread t takes items t, t + 256, ... in double, then a fixed-order LDS tree: the same
-// order for every launch.  Unused slots are zero (the producer's caller cleared the buffer).  Writes (mean, rstd) where gn_apply_kernel reads them.
-__global__ __launch_bounds__(256) void gn_finalize_chan_kernel(const vv_groupnorm_params p, const GNGeom g) {
-    __shared__ double ss[256], sq[256];
-    const int C = p.C0 + p.C1, cpg = C / p.groups, grp = blockIdx.x, t = threadIdx.x;
-    const int f0 = p.pool_frames ? 0 : blockIdx.y, f1 = p.pool_frames ? p.F : blockIdx.y + 1;
-    double s = 0.0, q = 0.0;
-    for (int cc = 0; cc < cpg; ++cc) {
-        const int c = grp * cpg + cc;
-        const bool first = c < p.C0;
-        const float* src = first ? p.stats0 : p.stats1;
-        const int Cs = first ? p.C0 : p.C1, cs = first ? c : c - p.C0, slots = first ? p.slots0 : p.slots1;
-        const int64_t items = (int64_t)(f1 - f0) * slots;
-        for (int64_t i = t; i < items; i += 256) {
-            const int f = f0 + (int)(i / slots), sl = (int)(i % slots);
-            const float2 v = *(const float2*)(src + (((int64_t)f * slots + sl) * Cs + cs) * 2);
-            s += v.x; q += v.y;
-        }
-    }
-    ss[t] = s; sq[t] = q;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (t < o) { ss[t] += ss[t + o]; sq[t] += sq[t + o]; }
-        __syncthreads();
-    }
-    const double n = (double)(f1 - f0) * p.HW * cpg;
-    const double mean = ss[0] / n;
-    double var = sq[0] / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-    float* fin = p.stats_ws + (int64_t)p.F * g.nsplit * p.groups * 2;
-    if (p.pool_frames) { for (int f = t; f < p.F; f += 256) { fin[((int64_t)f * p.groups + grp) * 2] = (float)mean; fin[((int64_t)f * p.groups + grp) * 2 + 1] = rstd; } }
-    else if (t == 0) { fin[((int64_t)blockIdx.y * p.groups + grp) * 2] = (float)mean; fin[((int64_t)blockIdx.y * p.groups + grp) * 2 + 1] = rstd; }
-}
-
 template <typename T>
 __global__ void gn_apply_kernel(const vv_groupnorm_params p, const GNGeom g) {
     const int t = threadIdx.x, split = blockIdx.x, f = blockIdx.y;
@@ -269,14 +233,9 @@ int gn_launch(const vv_groupnorm_params& p, hipStream_t st, bool apply = true) {
     const int C = p.C0 + p.C1;
     const GNGeom g = gn_geom(p.HW, C);
     const int threads = (g.threads + 63) / 64 * 64;
-    if (p.stats0 && (p.C1 == 0 || p.stats1)) {
-        // every source came with its producer's partial sums (vv_conv_params.stats_out): no pass over the tensor for the statistics
-        hipLaunchKernelGGL(gn_finalize_chan_kernel, dim3(p.groups, p.pool_frames ? 1 : p.F), dim3(256), 0, st, p, g);
-    } else {
-        hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), (size_t)2 * g.krows * C * sizeof(float), st, p, g);
-        if (p.pool_frames) hipLaunchKernelGGL(gn_finalize_pooled_kernel, dim3(p.groups), dim3(256), 0, st, p, g);
-        else hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.F), dim3(256), 0, st, p, g);
-    }
+    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), (size_t)2 * g.krows * C * sizeof(float), st, p, g);
+    if (p.pool_frames) hipLaunchKernelGGL(gn_finalize_pooled_kernel, dim3(p.groups), dim3(256), 0, st, p, g);
+    else hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.F), dim3(256), 0, st, p, g);
     if (apply) hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
     VV_CHECK_LAUNCH("vv_groupnorm");
     return VV_OK;
@@ -298,7 +257,6 @@ extern "C" int vv_groupnorm(const vv_groupnorm_params* pp, int dtype, void* stre
     if (p.in_dtype != VV_F32 && p.in_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_groupnorm: in_dtype mismatch");
     if (p.out_dtype != VV_F32 && p.out_dtype != dtype && p.out_dtype != VV_SPLIT3) VV_FAIL(VV_E_ARG, "vv_groupnorm: out_dtype mismatch");
     if (p.F <= 0 || p.HW <= 0) VV_FAIL(VV_E_ARG, "vv_groupnorm: empty input");
-    if ((p.stats0 && p.slots0 <= 0) || (p.stats1 && p.slots1 <= 0) || (p.stats1 && !p.stats0)) VV_FAIL(VV_E_ARG, "vv_groupnorm: stats0 / stats1 need their slot counts (and stats1 needs stats0)");
     return dtype == VV_BF16 ? gn_launch<BF16>(p, (hipStream_t)stream) : gn_launch<F16>(p, (hipStream_t)stream);
 }
 
@@ -313,7 +271,6 @@ extern "C" int vv_groupnorm_stats(const vv_groupnorm_params* pp, int dtype, void
     if (p.groups <= 0 || p.groups > 256 || C % p.groups || C / 8 > 1024) VV_FAIL(VV_E_ARG, "vv_groupnorm_stats: groups=%d C=%d", p.groups, C);
     if (p.in_dtype != VV_F32 && p.in_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_groupnorm_stats: in_dtype mismatch");
     if (p.F <= 0 || p.HW <= 0) VV_FAIL(VV_E_ARG, "vv_groupnorm_stats: empty input");
-    if ((p.stats0 && p.slots0 <= 0) || (p.stats1 && p.slots1 <= 0) || (p.stats1 && !p.stats0)) VV_FAIL(VV_E_ARG, "vv_groupnorm_stats: stats0 / stats1 need their slot counts (and stats1 needs stats0)");
     return dtype == VV_BF16 ? gn_launch<BF16>(p, (hipStream_t)stream, false) : gn_launch<F16>(p, (hipStream_t)stream, false);
 }
 

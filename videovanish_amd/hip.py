@@ -12,30 +12,9 @@ BF16, F16, F32, U8 = 0, 1, 2, 3
 SPLIT3 = 16      # vv_groupnorm out_dtype: the K-concatenated split-precision operand (see split3)
 EPI_NONE, EPI_GEGLU = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 9
+ABI_VERSION = 8
 _DT = {"bf16": BF16, "fp16": F16}
 _TORCH_H16 = {BF16: torch.bfloat16, F16: torch.float16}
-
-GN_STATS = "_vv_gn_stats"    # attribute a conv_gemm(stats=True) output carries: (partial sums [F, slots, C, 2], slots, F, HW, C)
-STATS_FROM_EPILOGUE = True   # class-level switch for A/B runs and tests (False: every GroupNorm runs its own statistics pass, the round-3 behaviour)
-
-
-def _gn_stats_of(x, F, HW):
-    st = getattr(x, GN_STATS, None) if x is not None else None
-    if st is None or not STATS_FROM_EPILOGUE:
-        return None
-    ws, slots, Fs, HWs, Cs = st
-    return st if (Fs == F and HWs == HW and Cs == x.shape[-1] and x.dtype == torch.float32) else None
-
-
-def _gn_stats_fields(x0, x1, F, HW):
-    """(stats0 ptr, stats1 ptr, slots0, slots1) for vv_groupnorm_params when EVERY source carries its producer's partial sums, else zeros"""
-    s0 = _gn_stats_of(x0, F, HW)
-    s1 = _gn_stats_of(x1, F, HW) if x1 is not None else None
-    if s0 is None or (x1 is not None and s1 is None):
-        return dict(stats0=0, stats1=0, slots0=0, slots1=0)
-    return dict(stats0=s0[0].data_ptr(), stats1=s1[0].data_ptr() if s1 is not None else 0, slots0=s0[1], slots1=s1[1] if s1 is not None else 0)
-
 
 PROFILE_TAG = ""   # prefix added to profile keys (nn.MotionModule sets "motion:" so bench.py can price the temporal block)
 PROFILE = None   # bench.py sets this to a list: every MFMA-kernel launch is then bracketed by HIP events on the launch stream
@@ -77,7 +56,7 @@ class ConvParams(C.Structure):
                 ("res0", C.c_void_p), ("res1", C.c_void_p), ("res_dtype", C.c_int32), ("out", C.c_void_p),
                 ("out_dtype", C.c_int32), ("ldo", C.c_int32), ("epilogue", C.c_int32), ("out_scale", C.c_float), ("ksize_w", C.c_int32),
                 ("act", C.c_int32), ("split_heads", C.c_int32), ("split_dim", C.c_int32), ("split_tokens", C.c_int32),
-                ("tile_hint", C.c_int32), ("act_slope", C.c_float), ("stats_out", C.c_void_p), ("stats_slots", C.c_int32)]
+                ("tile_hint", C.c_int32), ("act_slope", C.c_float)]
 
 
 class DeformParams(C.Structure):
@@ -91,7 +70,7 @@ class GroupNormParams(C.Structure):
     _fields_ = [("in0", C.c_void_p), ("in1", C.c_void_p), ("in_dtype", C.c_int32), ("C0", C.c_int32), ("C1", C.c_int32),
                 ("F", C.c_int32), ("HW", C.c_int32), ("groups", C.c_int32), ("pool_frames", C.c_int32), ("eps", C.c_float),
                 ("gamma", C.c_void_p), ("beta", C.c_void_p), ("silu", C.c_int32), ("stats_ws", C.c_void_p),
-                ("out", C.c_void_p), ("out_dtype", C.c_int32), ("stats0", C.c_void_p), ("stats1", C.c_void_p), ("slots0", C.c_int32), ("slots1", C.c_int32)]
+                ("out", C.c_void_p), ("out_dtype", C.c_int32)]
 
 
 class MotionParams(C.Structure):
@@ -119,7 +98,7 @@ class AttnParams(C.Structure):
                 ("scale", C.c_float), ("q_hs", C.c_int64), ("k_hs", C.c_int64), ("v_hs", C.c_int64), ("q_prescaled", C.c_int32), ("lse", C.c_void_p)]
 
 
-EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name", "vv_conv_gemm", "vv_conv_gemm_stats_slots", "vv_groupnorm_nsplit",
+EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name", "vv_conv_gemm", "vv_groupnorm_nsplit",
            "vv_groupnorm", "vv_layernorm", "vv_attention", "vv_axpby_f32", "vv_silu_f32", "vv_sched_step", "vv_add_inplace",
            "vv_mask_collapse_dilate", "vv_resize_bilinear_u8", "vv_resize_nearest_u8", "vv_feather_composite", "vv_chamfer_dt",
            "vv_preprocess", "vv_brushnet_input", "vv_pad_channels", "vv_decode_blend", "vv_blur_compose",
@@ -198,10 +177,8 @@ def _need_cuda(*ts):
 def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, Wv=None, Hout=None, Wout=None, ksize=1,
               stride=1, pad_t=0, pad_l=0, bias=None, rowvec=None, res0=None, res1=None, out=None, out_dtype=None,
               epilogue=EPI_NONE, out_scale=1.0, C0=None, C1=0, ksize_w=0, act=ACT_NONE, out_col=0, split_heads=0, split_dim=0, split_tokens=0, tile_hint=0,
-              act_slope=0.0, stats=False):
-    """Launch vv_conv_gemm.  x0/x1: NHWC activations ([F,Hin,Win,C] or any shape with C last); weight: [Npad,Kpad] h16.
-    stats=True: the epilogue also emits the GroupNorm partial statistics of the output (vv_conv_params.stats_out) when the launch is eligible; they
-    ride on the returned tensor (GN_STATS) and the next groupnorm() on that tensor skips its statistics pass."""
+              act_slope=0.0):
+    """Launch vv_conv_gemm.  x0/x1: NHWC activations ([F,Hin,Win,C] or any shape with C last); weight: [Npad,Kpad] h16."""
     _need_cuda(x0, x1, weight, bias, rowvec, res0, res1, out)      # out_col: write into columns [out_col, out_col+N) of `out`
     Hv = Hin if Hv is None else Hv
     Wv = Win if Wv is None else Wv
@@ -227,13 +204,6 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
                    ldo=out.shape[-1],
                    epilogue=epilogue, out_scale=out_scale, ksize_w=ksize_w, act=act, split_heads=split_heads, split_dim=split_dim,
                    split_tokens=split_tokens, tile_hint=tile_hint, act_slope=act_slope)
-    ws = None
-    if stats and STATS_FROM_EPILOGUE and epilogue == EPI_NONE and split_heads == 0 and out.dtype == torch.float32 and out.shape[-1] == N and out_col == 0 \
-            and N % 4 == 0 and N > 64 and (Hout * Wout) % 16 == 0:
-        slots = lib().vv_conv_gemm_stats_slots(Hin, Win, Hout, Wout)
-        ws = torch.zeros((F, slots, N, 2), dtype=torch.float32, device=x0.device)
-        p.stats_out, p.stats_slots = ws.data_ptr(), slots
-        setattr(out, GN_STATS, (ws, slots, F, Hout * Wout, N))
     if PROFILE is not None:
         Npad = weight.shape[0]
         # mirror of launch_t() in vv_gemm.hip (label only): LDS-DMA loaders prefer the 128x128 tile (4 blocks per CU) when N allows
@@ -284,10 +254,8 @@ def groupnorm(dtype, x0, gamma, beta, groups, eps, *, x1=None, F, HW, silu=False
         odt = dt_of(out)
     p = GroupNormParams(in0=x0.data_ptr(), in1=x1.data_ptr() if x1 is not None else 0, in_dtype=dt_of(x0), C0=C0, C1=C1, F=F, HW=HW,
                         groups=groups, pool_frames=int(pool_frames), eps=eps, gamma=gamma.data_ptr(), beta=beta.data_ptr(),
-                        silu=int(act) if act is not None else int(silu), stats_ws=ws.data_ptr(), out=out.data_ptr(), out_dtype=odt,
-                        **_gn_stats_fields(x0, x1, F, HW))
-    nread = 1 if p.stats0 else 2          # (statistics from the producer's epilogue: one pass over the tensor instead of two)
-    with _Prof("groupnorm", 0.0, F * HW * Ctot * (nread * x0.element_size() + (6 if odt == SPLIT3 else out.element_size()))):
+                        silu=int(act) if act is not None else int(silu), stats_ws=ws.data_ptr(), out=out.data_ptr(), out_dtype=odt)
+    with _Prof("groupnorm", 0.0, F * HW * Ctot * (2 * x0.element_size() + (6 if odt == SPLIT3 else out.element_size()))):
         _check(lib().vv_groupnorm(C.byref(p), dtype, _stream()), "vv_groupnorm")
     return out
 
@@ -299,8 +267,8 @@ def motion_module_c320(dtype, x, stream_w, params, gamma, beta, groups, eps, *, 
     nsplit = lib().vv_groupnorm_nsplit(HW, Cc)
     ws = torch.empty(F * (nsplit + 1) * groups * 2, dtype=torch.float32, device=x.device)
     gp = GroupNormParams(in0=x.data_ptr(), in1=0, in_dtype=dt_of(x), C0=Cc, C1=0, F=F, HW=HW, groups=groups, pool_frames=1, eps=eps,
-                         gamma=gamma.data_ptr(), beta=beta.data_ptr(), silu=0, stats_ws=ws.data_ptr(), out=0, out_dtype=F32, **_gn_stats_fields(x, None, F, HW))
-    with _Prof("groupnorm", 0.0, 0 if gp.stats0 else F * HW * Cc * x.element_size()):
+                         gamma=gamma.data_ptr(), beta=beta.data_ptr(), silu=0, stats_ws=ws.data_ptr(), out=0, out_dtype=F32)
+    with _Prof("groupnorm", 0.0, F * HW * Cc * x.element_size()):
         _check(lib().vv_groupnorm_stats(C.byref(gp), dtype, _stream()), "vv_groupnorm_stats")
     aff = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
     fin = ws.data_ptr() + F * nsplit * groups * 2 * 4
@@ -579,8 +547,8 @@ def spatial_chain_front_c320(dtype, x, gamma, beta, groups, eps, stream_w, param
     nsplit = lib().vv_groupnorm_nsplit(HW, Cc)
     ws = torch.empty(F * (nsplit + 1) * groups * 2, dtype=torch.float32, device=x.device)
     gp = GroupNormParams(in0=x.data_ptr(), in1=0, in_dtype=dt_of(x), C0=Cc, C1=0, F=F, HW=HW, groups=groups, pool_frames=0, eps=eps,
-                         gamma=gamma.data_ptr(), beta=beta.data_ptr(), silu=0, stats_ws=ws.data_ptr(), out=0, out_dtype=F32, **_gn_stats_fields(x, None, F, HW))
-    with _Prof("groupnorm", 0.0, 0 if gp.stats0 else F * HW * Cc * x.element_size()):
+                         gamma=gamma.data_ptr(), beta=beta.data_ptr(), silu=0, stats_ws=ws.data_ptr(), out=0, out_dtype=F32)
+    with _Prof("groupnorm", 0.0, F * HW * Cc * x.element_size()):
         _check(lib().vv_groupnorm_stats(C.byref(gp), dtype, _stream()), "vv_groupnorm_stats")
     aff = torch.empty((F, 2, Cc), dtype=torch.float32, device=x.device)
     fin = ws.data_ptr() + F * nsplit * groups * 2 * 4

@@ -93,8 +93,7 @@ class Conv:
         self.b = ctx.dev(bias_t.float()) if bias_t is not None else None
 
     def __call__(self, x0, F, H, W, x1=None, stride=1, Hv=None, Wv=None, Hout=None, Wout=None, pad=None, bias=True, rowvec=None,
-                 res0=None, res1=None, out_dtype=torch.float32, out=None, scale=1.0, bias_override=None, stats=False):
-        """stats: the output feeds a GroupNorm -- let the GEMM's epilogue emit that GroupNorm's partial statistics (hip.conv_gemm(stats=True))."""
+                 res0=None, res1=None, out_dtype=torch.float32, out=None, scale=1.0, bias_override=None):
         k = self.k
         pad = (k // 2) if pad is None else pad
         Hv = H if Hv is None else Hv
@@ -110,10 +109,10 @@ class Conv:
             x3 = x0 if (x0.dtype == self.ctx.h16 and x0.shape[1] == 3 * self.cp) else hip.split3(self.ctx.dt, x0)
             return hip.conv_gemm(self.ctx.dt, x3, self.w, self.cout, self.K, F=F, Hin=H, Win=W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout, ksize=k,
                                  stride=stride, pad_t=pad, pad_l=pad, bias=b, res0=res0, res1=res1, out=out, out_dtype=torch.float32,
-                                 out_scale=scale, stats=stats), Hout, Wout
+                                 out_scale=scale), Hout, Wout
         return hip.conv_gemm(self.ctx.dt, x0, self.w, self.cout, self.K, x1=x1, F=F, Hin=H, Win=W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout,
                              ksize=k, stride=stride, pad_t=pad, pad_l=pad, bias=b, rowvec=rowvec, res0=res0, res1=res1, out=out,
-                             out_dtype=out_dtype, epilogue=hip.EPI_GEGLU if self.geglu else hip.EPI_NONE, out_scale=scale, stats=stats), Hout, Wout
+                             out_dtype=out_dtype, epilogue=hip.EPI_GEGLU if self.geglu else hip.EPI_NONE, out_scale=scale), Hout, Wout
 
 
 class Linear:
@@ -205,14 +204,13 @@ class ResBlock:
                 b1 = silu_temb[id(self)]
             else:
                 b1 = self.temb_bias(silu_temb).view(-1)
-        h, _, _ = self.conv1(h, F, H, W, bias_override=b1, stats=True)       # norm2's statistics come out of this GEMM's epilogue
+        h, _, _ = self.conv1(h, F, H, W, bias_override=b1)
         h = self.norm2(h, F, HW, silu=True)
         if self.short is not None:
             xs, _, _ = self.short(x0, F, H, W, x1=x1)
         else:
             xs = x0
-        # (the block's fp32 output feeds a GroupNorm next -- of a transformer, a motion module or the next ResBlock, possibly as a skip: its statistics too)
-        out, _, _ = self.conv2(h, F, H, W, res0=xs, res1=res1, out_dtype=out_dtype, stats=out_dtype == torch.float32)
+        out, _, _ = self.conv2(h, F, H, W, res0=xs, res1=res1, out_dtype=out_dtype)
         return out
 
 
@@ -366,7 +364,7 @@ class SpatialTransformer:
         t = self.attn1.spatial(self.n1(t), t, F, HW)
         t = self.attn2(self.n2(t), t, F, HW)
         t = self.ff(self.n3(t), t)
-        out, _, _ = self.proj_out(t, F, H, W, res0=x, out_dtype=out_dtype, stats=out_dtype == torch.float32)      # feeds a motion module's / ResBlock's GroupNorm
+        out, _, _ = self.proj_out(t, F, H, W, res0=x, out_dtype=out_dtype)
         return out
 
 

@@ -126,7 +126,7 @@ class _Backbone:
 
     def run_down(self, x_in, F, h, w, st):
         """x_in: h16 [F*h*w, in_pad].  Returns (x, skips=[(tensor,H,W)...], (H,W))."""
-        x, _, _ = self.conv_in(x_in, F, h, w, stats=True)
+        x, _, _ = self.conv_in(x_in, F, h, w)
         H, W = h, w
         skips = [(x, H, W)]
         L = len(self.cfg.block_out)
@@ -139,7 +139,7 @@ class _Backbone:
                     x = m(x, F, H, W)
                 skips.append((x, H, W))
             if i < L - 1:
-                x, H, W = self.downs[i](x, F, H, W, stride=2, stats=True)
+                x, H, W = self.downs[i](x, F, H, W, stride=2)
                 skips.append((x, H, W))
         return x, skips, (H, W)
 
@@ -177,7 +177,7 @@ class _Backbone:
             if i < L - 1:
                 _, Hn, Wn = skips[-1]
                 au = add_up.pop(0) if add_up is not None else None
-                x, H, W = self.ups[i](x, F, H, W, Hv=Hn, Wv=Wn, res1=au, stats=True)
+                x, H, W = self.ups[i](x, F, H, W, Hv=Hn, Wv=Wn, res1=au)
                 if collect:
                     outs.append((x, H, W))
         return x, outs, (H, W)
@@ -207,7 +207,7 @@ class BrushNet(_Backbone):
         down_raw, mid, ups, (H, W) = pre if pre is not None else self.backbone(x16, t, F, h, w)
         new_skips = []
         for z, (s, sh, sw), (us, _, _) in zip(self.zd, down_raw, unet_skips):
-            o, _, _ = z(s, F, sh, sw, res0=us, scale=scale, stats=True)          # a UNet up-path skip: one source of a ResBlock's norm1
+            o, _, _ = z(s, F, sh, sw, res0=us, scale=scale)
             new_skips.append((o, sh, sw))
         new_mid, _, _ = self.zm(mid, F, H, W, res0=unet_mid, scale=scale)
         add_up = [z(s, F, sh, sw, scale=scale)[0] for z, (s, sh, sw) in zip(self.zu, ups)]

@@ -71,7 +71,7 @@ class VAE:
 
     def encode(self, img8, F, H, W):
         """img8: h16 [F*H*W, 8] (3 real channels, [-1,1]) -> scaled latent means fp32 [F, H/f, W/f, 4]."""
-        x, _, _ = self.e_in(img8, F, H, W, stats=True)
+        x, _, _ = self.e_in(img8, F, H, W)
         for i, rs in enumerate(self.e_blocks):
             last = i < len(self.e_blocks) - 1
             for j, r in enumerate(rs):
@@ -80,7 +80,7 @@ class VAE:
                 x = r(x, F, H, W, out_dtype=self.ctx.h16 if (last and j == len(rs) - 1) else torch.float32)
             if i < len(self.e_blocks) - 1:
                 # F.pad(x,(0,1,0,1)) + stride-2 conv, pad 0: bottom/right zeros come from the bounds check
-                x, H, W = self.e_down[i](x, F, H, W, stride=2, pad=0, Hout=H // 2, Wout=W // 2, stats=True)
+                x, H, W = self.e_down[i](x, F, H, W, stride=2, pad=0, Hout=H // 2, Wout=W // 2)
         x = self.e_mid(x, F, H, W)
         h = self.e_norm(x, F, H * W, silu=True)
         m, _, _ = self.e_out(h, F, H, W)
@@ -100,7 +100,7 @@ class VAE:
         else:
             pq = torch.zeros((F * h * w, 8), dtype=torch.float32, device=lat.device)
             self.post_quant(z8, F, h, w, out=pq)
-        x, _, _ = self.d_in(pq, F, h, w, stats=True)
+        x, _, _ = self.d_in(pq, F, h, w)
         H, W = h, w
         x = self.d_mid(x, F, H, W)
         for i, rs in enumerate(self.d_blocks):
@@ -108,7 +108,7 @@ class VAE:
             for j, r in enumerate(rs):
                 x = r(x, F, H, W, out_dtype=self.ctx.h16 if (last and j == len(rs) - 1) else torch.float32)   # feeds only the upsample conv
             if i < len(self.d_blocks) - 1:
-                x, H, W = self.d_up[i](x, F, H, W, Hv=2 * H, Wv=2 * W, stats=True)      # nearest x2 fused into the conv gather
+                x, H, W = self.d_up[i](x, F, H, W, Hv=2 * H, Wv=2 * W)      # nearest x2 fused into the conv gather
         hh = self.d_norm(x, F, H * W, silu=True)
         out, _, _ = self.d_out(hh, F, H, W)
         return out.view(F, H, W, 3)
