@@ -26,6 +26,8 @@ model.forward_device(fr[:chunk], pr[:chunk], mk[:chunk], chunk, 0, steps=min(ste
 torch.cuda.synchronize()
 ref = None
 for c in configs:
+    c, _, vb = c.partition("/")                 # "2s/8": VAE encode / decode in batches of 8 frames (DiffuEraserHIP.vae_batch; default 4)
+    model.vae_batch = int(vb) if vb else 4
     c0, _, stag = c.partition("@")              # "2s@0.4": lane k starts 0.4 k seconds late (RunConfig.lane_stagger_s)
     lanes, mode = int(c0[:-1]), c0[-1]
     unet.Denoiser.OVERLAP = mode == "o"      # (with lanes > 1 the product keeps one stream per chunk whatever this says: profiles/r4_schedule_ab_*.txt
@@ -36,4 +38,4 @@ for c in configs:
     torch.cuda.synchronize(); dt = time.time() - t0
     same = "" if ref is None else f" identical={bool(torch.equal(out, ref))}"
     ref = out if ref is None else ref
-    print(f"{c}: {dt / K:8.3f} s/chunk  {(chunk - overlap) * K / dt:.4f} frames/s  ({K} chunks){same}", flush=True)
+    print(f"{c}{'/' + vb if vb else ''}: {dt / K:8.3f} s/chunk  {(chunk - overlap) * K / dt:.4f} frames/s  ({K} chunks){same}", flush=True)

@@ -41,6 +41,10 @@ fam = {
     "+ whole BrushNet": lambda n: dec(n) or n.startswith("brushnet."),
     "+ whole UNet": lambda n: dec(n) or n.startswith("unet."),
     "cheap set (conv_in/out + time emb)": cheap,
+    "cheap, decoder exact only from up_blocks.2 on (mid / up 0 / up 1 plain fp16)": lambda n: (cheap(n) and not dec(n)) or (dec(n) and not any(k in n for k in ("mid_block", "up_blocks.0", "up_blocks.1", "conv_in", "post_quant"))),
+    "cheap, decoder exact only from up_blocks.1 on (mid / up 0 plain fp16)": lambda n: (cheap(n) and not dec(n)) or (dec(n) and not any(k in n for k in ("mid_block", "up_blocks.0", "conv_in", "post_quant"))),
+    "cheap, decoder: weights exact only (2-pass)": lambda n: ({"w"} if dec(n) else cheap(n)),
+    "cheap, decoder: activations exact only (2-pass)": lambda n: ({"a"} if dec(n) else cheap(n)),
     "cheap + UNet level 3 + mid (down 3, mid, up 0)": lambda n: cheap(n) or n.startswith("unet.down_blocks.3") or n.startswith("unet.mid_block") or n.startswith("unet.up_blocks.0"),
     "cheap + UNet level 2 (down 2, up 1)": lambda n: cheap(n) or n.startswith("unet.down_blocks.2") or n.startswith("unet.up_blocks.1"),
     "cheap + UNet level 1 (down 1, up 2)": lambda n: cheap(n) or n.startswith("unet.down_blocks.1") or n.startswith("unet.up_blocks.2"),
