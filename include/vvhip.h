@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VV_ABI_VERSION 8
+#define VV_ABI_VERSION 9
 
 enum { VV_BF16 = 0, VV_F16 = 1, VV_F32 = 2, VV_U8 = 3,
        VV_SPLIT3 = 16 /* vv_groupnorm out_dtype only: the K-concatenated split-precision operand [rows][3C] of vv_split3, in the operand dtype */ };
@@ -88,6 +88,12 @@ typedef struct {
                              the shape is eligible (h16 sources with channel counts % 64 == 0, <= 9 taps, no fused resize,
                              Npad % 320 or % 256 == 0; 8-phase: Npad % 256 == 0) */
     float act_slope;      /* VV_ACT_LRELU: negative-side slope (ProPainter: 0.1 in the alignment offset stacks, 0.2 in the encoders) */
+    /* ABI 9 -- output scatter (sc_oh > 0): row m = (f, y, x) of this launch's Hout x Wout grid is stored at (and its residuals are read from) row
+       (f * sc_oh + y * sc_sy + sc_oy) * sc_ow + x * sc_sx + sc_ox of an [F][sc_oh][sc_ow][ldo] tensor.  One 3x3 convolution over a nearest-2x
+       upsampled image is four 2x2 convolutions over the source image, one per output parity, with the taps that fall on the same source pixel
+       summed (4/9 of the work): each of the four launches scatters with sc_sy = sc_sx = 2, (sc_oy, sc_ox) = its parity.  Not with GEGLU /
+       split_heads. */
+    int32_t sc_oh, sc_ow, sc_sy, sc_sx, sc_oy, sc_ox;
 } vv_conv_params;
 int vv_conv_gemm(const vv_conv_params* host_p, int dtype, void* stream);
 

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_binding_lists_match_header(lib):
     from videovanish_amd import hip
     assert sorted(hip.EXPORTS) == _declared()
-    assert lib.vv_abi_version() == hip.ABI_VERSION == 8
+    assert lib.vv_abi_version() == hip.ABI_VERSION == 9
 
 
 def test_vvio_header_symbols_are_exported():

@@ -42,6 +42,41 @@ def test_spatial_attention_full_size(gpu):
     assert (got - ref).abs().max().item() <= 2 ** -7 * max(1.0, ref.abs().max().item())
 
 
+
+@pytest.mark.parametrize("dname,td,ulp", [("bf16", torch.bfloat16, 2 ** -8), ("fp16", torch.float16, 2 ** -11)])
+def test_spatial_attention_level1_full_size(gpu, dname, td, ulp):
+    """N = 3600 tokens (45 x 80: UNet level 1 at 720p; 3600 = 56 x 64 + 16: ragged last key tile, last query block of 16 queries), 8 heads x d = 80,
+    head-major q_prescaled layout as the pipeline stores it: attn80_kernel against an fp64 softmax over every query of two (frame, head) pairs,
+    deterministic, and the log-sum-exp output against torch.logsumexp."""
+    from videovanish_amd import hip
+    dt = hip.dtype_id(dname)
+    g = torch.Generator().manual_seed(62)
+    B, heads, D, Nl = 3, 8, 80, 45 * 80
+    C = heads * D
+    c = hip.attention_q_scale(D)
+    q = _r(torch.randn(B, Nl, heads, D, generator=g) * c * 1.5, td)
+    k = _r(torch.randn(B, Nl, heads, D, generator=g) * 1.5, td)
+    v = _r(torch.randn(B, Nl, heads, D, generator=g), td)
+    hm = torch.stack([q, k, v], 1).permute(0, 1, 3, 2, 4).contiguous().to(td).to(gpu)
+    out = torch.empty(B, Nl, C, dtype=td, device=gpu)
+    args = dict(B=B, heads=heads, Nq=Nl, Nkv=Nl, D=D, q_bs=3 * Nl * C, k_bs=3 * Nl * C, v_bs=3 * Nl * C, o_bs=Nl * C, q_rs=D, k_rs=D, v_rs=D, o_rs=C,
+                k_off=Nl * C, v_off=2 * Nl * C, q_hs=Nl * D, k_hs=Nl * D, v_hs=Nl * D, q_prescaled=True)
+    hip.attention(dt, hm, hm, hm, out, **args)
+    out2 = torch.empty_like(out)
+    lse = torch.empty(B, heads, Nl, dtype=torch.float32, device=gpu)
+    hip.attention(dt, hm, hm, hm, out2, lse=lse, **args)
+    assert torch.equal(out, out2)                                   # deterministic, and the lse output does not change the result
+    for b, h in ((0, 0), (2, 5)):
+        s = q[b, :, h].double() @ k[b, :, h].double().t()           # log2 units (q carries scale * log2 e)
+        pr = torch.exp2(s - s.amax(-1, keepdim=True))
+        ref = ((pr / pr.sum(-1, keepdim=True)) @ v[b, :, h].double()).float()
+        got = out[b, :, h * D:(h + 1) * D].float().cpu()
+        err = (got - ref).abs().max().item()
+        print(f"attention d80 N3600 [{dname}] (b={b}, h={h}): max-abs {err:.2e} (tolerance {4 * ulp * max(1.0, ref.abs().max().item()):.2e})")
+        assert err <= 4 * ulp * max(1.0, ref.abs().max().item())
+        want = (torch.logsumexp(s * math.log(2.0), -1) / math.log(2.0)).float()
+        assert (lse[b, h].cpu() - want).abs().max().item() <= 2e-3
+
 def test_temporal_attention_full_size(gpu):
     """32 frames x 14400 pixels x 8 heads x d=40: the strided (f,hw)->(hw,f) gather at full size; 300 pixels checked."""
     from videovanish_amd import hip

@@ -930,6 +930,333 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// d = 80 (UNet level 1: 3600 tokens per frame at 720p; SAM 2's 72 -> 80 padded heads) in the form of attn40q2_kernel (round 4): S^T = K Q^T and
+// O^T rows 0..63 on v_mfma_f32_32x32x16, rows 64..79 on 16x16x32 through v_permlane16_swap, 64 queries per wave, optimistic softmax reference,
+// branch-free tile body.  What d = 80 changes:
+//   * 80 = 5 k steps of 16 exactly: there is no pad slot for the reference to ride in.  It enters as the C OPERAND of the first MFMA of every score
+//     block instead: a per-query-block register tile negm (all 16 registers of a lane = -m of the lane's query, fp32: no hi / lo split), read by the
+//     out-of-place MFMA -- no instruction, no extra k step (a sixth k step would be +10 % matrix-pipe time).
+//   * all 16 rows of the 16x16x32 block are data, so the softmax denominator does not come off the matrix pipe: l += dot2(P pair, (1, 1)) on the
+//     packed, ROUNDED probabilities (v_dot2_f32_f16: 16 instructions per 32 queries x 64 keys) -- numerator and denominator see the same P.
+//   * LDS images, 160-byte rows (10 chunks of 8 h16), all 20 LDS-DMA pieces of a tile with every lane active:
+//       K: row = key, chunk c stored at position c ^ ((row >> 3) & 1)  -> the ds_read_b128 of 16 rows x one chunk is conflict free (tools/lds_bank_model.py);
+//       V: key 8 A + 4 b + q stored at row 8 A + 2 q + b               -> the 4 rows of a transposed read are 2 apart: conflict free at 160 bytes
+//          (the 16x16x32 block's reads are 2-way conflicted: 4 of 24 reads per tile).
+// Waves whose queries all lie past Nq (the last query tile of N = 3600 holds 16 queries) keep feeding the DMA ring but skip the tile body.
+template <typename T> __device__ __forceinline__ float psum2(unsigned u, float acc);
+template <> __device__ __forceinline__ float psum2<F16>(unsigned u, float acc) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(vv_f16x2, u), (vv_f16x2){(_Float16)1.0f, (_Float16)1.0f}, acc, false);
+}
+template <> __device__ __forceinline__ float psum2<BF16>(unsigned u, float acc) {
+    return acc + __builtin_bit_cast(float, u << 16) + __builtin_bit_cast(float, u & 0xffff0000u);
+}
+
+template <typename T, int NW, int OCC, bool RAGGED>
+__global__ __launch_bounds__(NW * 64, OCC) void attn80_kernel(const vv_attn_params p, const int nqt) {
+    constexpr int D = 80, KVT = 64, PR = 160, NCH = 10, QB = 2, NS = 5;
+    constexpr int NT = NW * 64, BQ = NW * 32 * QB;
+    constexpr int TILE = KVT * PR;                            // 10240
+    constexpr int NPK = TILE / 1024;                          // 10 DMA pieces (1 KB each) per K tile, 10 per V tile
+    constexpr int PPW = 2 * NPK / NW;                         // 5 pieces per wave and tile (piece j = wave + NW i: j < 10 = K, else V)
+    static_assert(NW == 4, "piece distribution assumes four waves");
+    constexpr float MARGIN = -4.0f;                           // P = 2^4 at the sample maximum (see attn40_kernel)
+    __shared__ __attribute__((aligned(1024))) unsigned char dK0[TILE];
+    __shared__ __attribute__((aligned(1024))) unsigned char dK1[TILE];
+    __shared__ __attribute__((aligned(1024))) unsigned char dV0[TILE];
+    __shared__ __attribute__((aligned(1024))) unsigned char dV1[TILE];
+
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int qt, hd, b;
+    {
+        const int nbh = p.B * p.heads;
+        const int full = (nbh / 8) * 8;
+        const int bid = blockIdx.x;
+        int bh;
+        if (bid < full * nqt) { const int xcd = bid & 7, idx = bid >> 3; bh = (idx / nqt) * 8 + xcd; qt = idx % nqt; }
+        else { const int rr = bid - full * nqt; bh = full + rr / nqt; qt = rr % nqt; }
+        hd = bh % p.heads; b = bh / p.heads;
+    }
+    const unsigned short* Q = (const unsigned short*)p.q + (int64_t)b * p.q_bs + (int64_t)hd * (p.q_hs ? p.q_hs : D);
+    const unsigned char* Kp = (const unsigned char*)((const unsigned short*)p.k + (int64_t)b * p.k_bs + (int64_t)hd * (p.k_hs ? p.k_hs : D));
+    const unsigned char* Vp = (const unsigned char*)((const unsigned short*)p.v + (int64_t)b * p.v_bs + (int64_t)hd * (p.v_hs ? p.v_hs : D));
+    unsigned short* O = (unsigned short*)p.o + (int64_t)b * p.o_bs + (int64_t)hd * D;
+
+    // ---- Q fragments: lane (r, h) holds Q[q0 + 32 x + r][16 s + 8 h .. +7], s = 0..4
+    const int q0 = qt * BQ + wave * 32 * QB;
+    const bool active = q0 < p.Nq;                             // wave-uniform
+    uint4 qf[QB][NS];
+    float dg[QB];                                              // self-attention: score against the query's own key (part of the reference sample)
+#pragma unroll
+    for (int x = 0; x < QB; ++x) {
+        const int q = q0 + 32 * x + r;
+        float sum = 0.f;
+        const bool on = p.Nq == p.Nkv && q < p.Nkv;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int d0 = 16 * s + 8 * h;
+            qf[x][s] = q < p.Nq ? *(const uint4*)(Q + (int64_t)q * p.q_rs + d0) : make_uint4(0, 0, 0, 0);
+            float qv[8];
+            unpack8<T>(qf[x][s], qv);
+            if (!p.q_prescaled) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qv[e] *= p.scale * 1.4426950408889634f;
+                qf[x][s] = pack8<T>(qv);
+                unpack8<T>(qf[x][s], qv);
+            }
+            if (on) {
+                float kv[8];
+                unpack8<T>(*(const uint4*)(Kp + ((int64_t)q * p.k_rs + d0) * 2), kv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += qv[e] * kv[e];
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        dg[x] = on ? sum : -1e30f;
+    }
+    // the tile buffers start as zeros (rows of a ragged tile that are never loaded stay finite)
+    for (int i = t; i < TILE / 16; i += NT) {
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+        *(uint4*)(dK0 + i * 16) = zero; *(uint4*)(dK1 + i * 16) = zero; *(uint4*)(dV0 + i * 16) = zero; *(uint4*)(dV1 + i * 16) = zero;
+    }
+    __syncthreads();
+
+    // ---- this wave's DMA pieces: piece j = wave + NW i; slot = (j % 10) * 64 + lane = row * 10 + position of the K (j < 10) or V tile
+    unsigned doff[PPW];          // byte offset of the slot's source inside a tile = key * row stride + chunk * 16 (chunk * 16 < row stride: the key is doff / row stride)
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int j = wave + NW * i, slot = (j % NPK) * 64 + lane, row = slot / NCH, pos = slot - row * NCH;
+        const bool isv = j >= NPK;
+        const int key = isv ? (row & ~7) + 4 * (row & 1) + ((row >> 1) & 3) : row;
+        const int ch = isv ? pos : pos ^ ((row >> 3) & 1);
+        doff[i] = (unsigned)(key * (int)(isv ? p.v_rs : p.k_rs) + ch * 8) * 2u;
+    }
+    const int ntiles = (p.Nkv + KVT - 1) / KVT;
+    const int nlast = p.Nkv - (ntiles - 1) * KVT;             // keys in the last tile (KVT unless RAGGED)
+    const unsigned kstep = (unsigned)(KVT * (int)p.k_rs * 2), vstep = (unsigned)(KVT * (int)p.v_rs * 2);
+    // K part (want & 1) / V part (want & 2) of tile `it` -> the buffers bK / bV; stride > 1: the 64-key SAMPLE (keys 0, stride, 2 stride, ..), K only
+    auto dma = [&](const int want, const int it, unsigned char* bK, unsigned char* bV, const unsigned stride) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int j = wave + NW * i;                          // wave-uniform
+            const bool isv = j >= NPK;
+            if (isv ? (want & 2) != 0 : (want & 1) != 0) {
+                const unsigned char* src = isv ? Vp + (size_t)it * vstep : Kp + (size_t)it * kstep;
+                unsigned char* dst = (isv ? bV : bK) + (j % NPK) * 1024;
+                unsigned off = doff[i];
+                const unsigned rs2 = (unsigned)(isv ? p.v_rs : p.k_rs) * 2u;
+                if (stride != 1) off += (off / rs2) * rs2 * (stride - 1);                            // (once per block)
+                if (RAGGED && it + 1 == ntiles && stride == 1) { if (off < (unsigned)nlast * rs2) glds16(src + off, dst); }
+                else glds16(src + off, dst);
+            }
+        }
+    };
+
+    // ---- lane-constant LDS read addresses (byte offsets into a tile buffer; key block / k step / d block are instruction immediates)
+    const int ka = r * PR + 16 * (h ^ ((r >> 3) & 1));            // K chunk 2 s + h of row r sits at position 2 s + (h ^ bit 3 of r): + 32 s
+    const int vq = (lane >> 2) & 3, vpp = lane & 3, vcb = (lane >> 4) & 1;
+    const int va0 = (2 * vq + h) * PR + (16 * vcb + 4 * vpp) * 2;              // rows 0..31 of O^T; + 64: rows 32..63; + 16 (2 kb + s2) rows; hi: + 8 rows
+    const int va1 = (16 * vcb + 2 * vq + h) * PR + 128 + 8 * vpp;             // rows 64..79 (16x16x32: k group (s2 = vcb, h)); + 32 kb rows; hi: + 8 rows
+
+    // S^T block kb (32 keys) of query block x = K Q^T + C
+    auto qk = [&](const unsigned char* sK, const int kb, const int x, const f32x16& c0) {
+        f32x16 acc = Mfma32<T>::run(*(const uint4*)(sK + kb * 32 * PR + ka), qf[x][0], c0);
+#pragma unroll
+        for (int s = 1; s < NS; ++s) acc = Mfma32<T>::run(*(const uint4*)(sK + kb * 32 * PR + ka + 32 * s), qf[x][s], acc);
+        return acc;
+    };
+    auto mask_last = [&](f32x16& sacc, const int kb) {            // keys past Nkv of the ragged last tile: -inf scores (P = 0)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= nlast) sacc[i] = -1e30f;
+    };
+    auto row_max = [&](const f32x16& sacc, float mx) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[i]);
+        return mx;
+    };
+    auto splat = [&](const float v) { f32x16 c; 
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = v;
+        return c; };
+
+    f32x16 negm[QB];          // -reference of the lane's query in every register: the C operand of the first score MFMA
+    f32x16 oacc[QB][2];       // O^T rows 0..31, 32..63 per query block (32x32x16 layout: lane = query, registers + h = d)
+    f32x4 o2[QB][2];          // O^T rows 64..79 for the queries 0..15 / 16..31 of each block (16x16x32 layout)
+    float l[QB];              // softmax denominators (this lane's half of the keys until the final exchange)
+    float ref[QB];
+    const f32x16 zero16 = splat(0.f);
+    // ---- reference: attempt 0 = maximum over the 64-key sample (and the own key) + MARGIN; attempt 1 (after an overflow) = the exact maximum
+    auto reference = [&](const int attempt) {
+        if (attempt == 0) {
+            dma(1, 0, dK1, dV1, (unsigned)(p.Nkv / KVT));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#pragma unroll
+            for (int x = 0; x < QB; ++x) {
+                float mx = dg[x];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) mx = row_max(qk(dK1, kb, x, zero16), mx);
+                ref[x] = fmaxf(mx, __shfl_xor(mx, 32)) + MARGIN;
+            }
+        } else {
+            float mx[QB];
+#pragma unroll
+            for (int x = 0; x < QB; ++x) mx[x] = -1e30f;
+            __syncthreads();
+            dma(1, 0, dK0, dV0, 1u);
+            for (int it = 0; it < ntiles; ++it) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (it + 1 < ntiles) { if (it & 1) dma(1, it + 1, dK0, dV0, 1u); else dma(1, it + 1, dK1, dV1, 1u); }
+#pragma unroll
+                for (int x = 0; x < QB; ++x)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        f32x16 sc = (it & 1) ? qk(dK1, kb, x, zero16) : qk(dK0, kb, x, zero16);
+                        if (RAGGED && it + 1 == ntiles) mask_last(sc, kb);
+                        mx[x] = row_max(sc, mx[x]);
+                    }
+            }
+#pragma unroll
+            for (int x = 0; x < QB; ++x) ref[x] = fmaxf(mx[x], __shfl_xor(mx[x], 32));
+        }
+#pragma unroll
+        for (int x = 0; x < QB; ++x) negm[x] = splat(-ref[x]);
+    };
+    // all key tiles with the reference in place; true = some denominator of the BLOCK is non-finite or zero
+    auto tiles = [&]() {
+        __syncthreads();                                          // everybody is done with the sample (the last sweep tile)
+        dma(3, 0, dK0, dV0, 1u);
+#pragma unroll
+        for (int x = 0; x < QB; ++x) {
+            oacc[x][0] = zero16; oacc[x][1] = zero16;
+            o2[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o2[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            l[x] = 0.f;
+        }
+        // one tile, per 32-key block: scores of both query blocks, then per query block P = exp2(S) packed, l += sum P, O^T += V^T P^T -- ONE basic block
+        auto body = [&](const unsigned char* cK, const unsigned char* cV, const bool last) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x16 sc[QB];
+#pragma unroll
+                for (int x = 0; x < QB; ++x) {
+                    sc[x] = qk(cK, kb, x, negm[x]);
+                    if (RAGGED && last) mask_last(sc[x], kb);
+                }
+                uint4 pb[QB][2];
+#pragma unroll
+                for (int x = 0; x < QB; ++x) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sc[x][i] = __builtin_amdgcn_exp2f(sc[x][i]);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        pb[x][s2] = make_uint4(pack2<T>(sc[x][8 * s2 + 0], sc[x][8 * s2 + 1]), pack2<T>(sc[x][8 * s2 + 2], sc[x][8 * s2 + 3]),
+                                               pack2<T>(sc[x][8 * s2 + 4], sc[x][8 * s2 + 5]), pack2<T>(sc[x][8 * s2 + 6], sc[x][8 * s2 + 7]));
+                        l[x] = psum2<T>(pb[x][s2].x, l[x]); l[x] = psum2<T>(pb[x][s2].y, l[x]);      // (a second chain costs the ragged instantiation two spills in the loop)
+                        l[x] = psum2<T>(pb[x][s2].z, l[x]); l[x] = psum2<T>(pb[x][s2].w, l[x]);
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    // rows 0..63 of O^T: keys 32 kb + 16 s2 + 8 j4 + 4 h + q, j4 = 0 (elements 0..3), 1 (elements 4..7): V rows 16 (2 kb + s2) + 8 j4 + 2 q + h
+                    const int g0 = 16 * (2 * kb + s2) * PR;
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const uint2 lo = ds_read_tr16(cV + g0 + va0 + 64 * db), hi = ds_read_tr16(cV + g0 + 8 * PR + va0 + 64 * db);
+                        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                        for (int x = 0; x < QB; ++x) oacc[x][db] = Mfma32<T>::run(vf, pb[x][s2], oacc[x][db]);
+                    }
+                }
+                // rows 64..79 on the 16x16x32 form: v_permlane16_swap turns the (s2 = 0, s2 = 1) dword pairs of P into the B operands of the two
+                // 16-query tiles (k group g = lane >> 4 = (s2 = g & 1, h = g >> 1): keys 32 kb + 16 s2 + 4 h + {0..3, 8..11}), as in attn40_kernel
+                const uint2 lo = ds_read_tr16(cV + kb * 32 * PR + va1), hi = ds_read_tr16(cV + kb * 32 * PR + 8 * PR + va1);
+                const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                for (int x = 0; x < QB; ++x) {
+                    auto s0 = __builtin_amdgcn_permlane16_swap(pb[x][0].x, pb[x][1].x, false, false);
+                    auto s1 = __builtin_amdgcn_permlane16_swap(pb[x][0].y, pb[x][1].y, false, false);
+                    auto s2_ = __builtin_amdgcn_permlane16_swap(pb[x][0].z, pb[x][1].z, false, false);
+                    auto s3 = __builtin_amdgcn_permlane16_swap(pb[x][0].w, pb[x][1].w, false, false);
+                    const uint4 pa = make_uint4(s0[0], s1[0], s2_[0], s3[0]);
+                    const uint4 pq = make_uint4(s0[1], s1[1], s2_[1], s3[1]);
+                    o2[x][0] = T::mfma(vf, pa, o2[x][0]); o2[x][1] = T::mfma(vf, pq, o2[x][1]);
+                }
+            }
+        };
+        // step `it`: tile `it` (K and V) has landed; issue tile it+1 into the other buffers.  `last` (the ragged tile: masked scores) is a compile-time
+        // property of the call site, so every instance of the tile body stays ONE basic block
+        auto step = [&](const int it, unsigned char* cK, unsigned char* cV, unsigned char* nK, unsigned char* nV, auto lastc) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (it + 1 < ntiles) dma(3, it + 1, nK, nV, 1u);
+            if (active) body(cK, cV, decltype(lastc)::value);
+        };
+        const int nplain = RAGGED ? ntiles - 1 : ntiles;
+        int it = 0;
+        for (; it + 1 < nplain; it += 2) {
+            step(it, dK0, dV0, dK1, dV1, std::false_type{});
+            step(it + 1, dK1, dV1, dK0, dV0, std::false_type{});
+        }
+        if (it < nplain) { step(it, dK0, dV0, dK1, dV1, std::false_type{}); ++it; }
+        if (RAGGED) {
+            if (it & 1) step(it, dK1, dV1, dK0, dV0, std::true_type{});
+            else step(it, dK0, dV0, dK1, dV1, std::true_type{});
+        }
+        // ---- denominators: both key halves; non-finite (some P overflowed) or zero: the block repeats its keys with the exact maximum
+        bool bad = false;
+#pragma unroll
+        for (int x = 0; x < QB; ++x) {
+            l[x] += __shfl_xor(l[x], 32);
+            bad = bad || !(l[x] > 0.f && l[x] < 3.0e38f);
+        }
+        return __syncthreads_or(active && bad ? 1 : 0) != 0;
+    };
+    reference(0);
+    if (tiles()) { reference(1); tiles(); }
+    if (!active) return;
+    // ---- finalize: O[q][d] = O^T[d][q] / l
+#pragma unroll
+    for (int x = 0; x < QB; ++x) {
+        {
+            const float inv = 1.0f / l[x];
+            const int q = q0 + 32 * x + r;
+            if (q < p.Nq) {
+                unsigned short* orow = O + (int64_t)q * p.o_rs;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *(uint2*)(orow + 32 * db + 8 * g + 4 * h) = make_uint2(pack2<T>(oacc[x][db][4 * g] * inv, oacc[x][db][4 * g + 1] * inv),
+                                                                              pack2<T>(oacc[x][db][4 * g + 2] * inv, oacc[x][db][4 * g + 3] * inv));
+                if (p.lse && h == 0) p.lse[((int64_t)b * p.heads + hd) * p.Nq + q] = ref[x] + __log2f(l[x]);
+            }
+        }
+        // rows 64..79: 16-query tile qt2, lane (c = lane & 15, g = lane >> 4): d = 64 + 4 g + reg of query 16 qt2 + c
+#pragma unroll
+        for (int qt2 = 0; qt2 < 2; ++qt2) {
+            const float inv = 1.0f / __shfl(l[x], 16 * qt2 + (lane & 15));
+            const int q = q0 + 32 * x + 16 * qt2 + (lane & 15);
+            if (q < p.Nq)
+                *(uint2*)(O + (int64_t)q * p.o_rs + 64 + 4 * (lane >> 4)) = make_uint2(pack2<T>(o2[x][qt2][0] * inv, o2[x][qt2][1] * inv), pack2<T>(o2[x][qt2][2] * inv, o2[x][qt2][3] * inv));
+        }
+    }
+}
+
+template <typename T, int NW, int OCC>
+int attn80_launch(const vv_attn_params& p, hipStream_t st) {
+    constexpr int BQ = NW * 64;
+    const int nqt = (p.Nq + BQ - 1) / BQ;
+    const int64_t nblk = (int64_t)p.B * p.heads * nqt;
+    if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_attention: grid too large");
+    if (p.Nkv % 64) hipLaunchKernelGGL((attn80_kernel<T, NW, OCC, true>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p, nqt);
+    else hipLaunchKernelGGL((attn80_kernel<T, NW, OCC, false>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p, nqt);
+    VV_CHECK_LAUNCH("vv_attention(d80, 64 queries per wave)");
+    return VV_OK;
+}
+
 template <typename T, int NW, int OCC>
 int attn40q2_launch(const vv_attn_params& p, hipStream_t st) {
     constexpr int BQ = NW * 64;
@@ -988,6 +1315,10 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
             if constexpr (D == 40) {
                 // 32x32x16 / 16x16x32 hybrid, optimistic reference: 64 queries per wave (2 waves/SIMD) on long sequences, 32 (3 waves/SIMD) below
                 if (!cross && p.Nkv >= 64) return p.Nq >= 1024 ? attn40q2_launch<T, 4, 2>(p, st) : attn40_launch<T, 4, 3>(p, st);
+            }
+            if constexpr (D == 80) {
+                // the same form at d = 80 (round 4): reference through the C operand, denominators on the VALU
+                if (!cross && p.Nkv >= 64 && p.Nq >= 512) return attn80_launch<T, 4, 2>(p, st);
             }
             if (D <= 64) return cross ? attn_launch<T, D, 2, 64, 4, false, 3, true, 1>(p, st) : attn_launch<T, D, 2, 64, 4, false, 3, true, 0>(p, st);
             return cross ? attn_launch<T, D, 2, 64, 4, true, 1, false, 1>(p, st) : attn_launch<T, D, 2, 64, 4, true, 1, false, 0>(p, st);

@@ -497,6 +497,14 @@ extern "C" int vv_conv_gemm(const vv_conv_params* pp, int dtype, void* stream) {
         VV_FAIL(VV_E_ARG, "vv_conv_gemm: split_heads needs N = 3*heads*dim, dim %% 4 == 0, h16 output, no residual / GEGLU, M %% split_tokens == 0");
     if (p.F <= 0 || p.Hout <= 0 || p.Wout <= 0 || p.Hin <= 0 || p.Win <= 0 || p.Hv <= 0 || p.Wv <= 0) VV_FAIL(VV_E_ARG, "vv_conv_gemm: bad geometry");
     const int64_t M64 = (int64_t)p.F * p.Hout * p.Wout;
+    if (p.sc_oh != 0) {
+        if (p.sc_oh < 0 || p.sc_ow <= 0 || p.sc_sy <= 0 || p.sc_sx <= 0 || p.sc_oy < 0 || p.sc_ox < 0 || (int64_t)(p.Hout - 1) * p.sc_sy + p.sc_oy >= p.sc_oh ||
+            (int64_t)(p.Wout - 1) * p.sc_sx + p.sc_ox >= p.sc_ow)
+            VV_FAIL(VV_E_ARG, "vv_conv_gemm: output scatter (%d x %d, step %d x %d, origin %d, %d) does not hold the %d x %d grid", p.sc_oh, p.sc_ow, p.sc_sy, p.sc_sx,
+                    p.sc_oy, p.sc_ox, p.Hout, p.Wout);
+        if (p.epilogue == VV_EPI_GEGLU || p.split_heads > 0) VV_FAIL(VV_E_ARG, "vv_conv_gemm: output scatter with GEGLU / split_heads");
+        if ((int64_t)p.F * p.sc_oh * p.sc_ow > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_conv_gemm: more than 2^31 pixels");
+    }
     if (M64 > 0x7fffffff || (int64_t)p.F * p.Hin * p.Win > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_conv_gemm: more than 2^31 pixels");
     const int M = (int)M64;
     hipStream_t st = (hipStream_t)stream;

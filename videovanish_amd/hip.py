@@ -12,7 +12,7 @@ BF16, F16, F32, U8 = 0, 1, 2, 3
 SPLIT3 = 16      # vv_groupnorm out_dtype: the K-concatenated split-precision operand (see split3)
 EPI_NONE, EPI_GEGLU = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 8
+ABI_VERSION = 9
 _DT = {"bf16": BF16, "fp16": F16}
 _TORCH_H16 = {BF16: torch.bfloat16, F16: torch.float16}
 
@@ -56,7 +56,8 @@ class ConvParams(C.Structure):
                 ("res0", C.c_void_p), ("res1", C.c_void_p), ("res_dtype", C.c_int32), ("out", C.c_void_p),
                 ("out_dtype", C.c_int32), ("ldo", C.c_int32), ("epilogue", C.c_int32), ("out_scale", C.c_float), ("ksize_w", C.c_int32),
                 ("act", C.c_int32), ("split_heads", C.c_int32), ("split_dim", C.c_int32), ("split_tokens", C.c_int32),
-                ("tile_hint", C.c_int32), ("act_slope", C.c_float)]
+                ("tile_hint", C.c_int32), ("act_slope", C.c_float),
+                ("sc_oh", C.c_int32), ("sc_ow", C.c_int32), ("sc_sy", C.c_int32), ("sc_sx", C.c_int32), ("sc_oy", C.c_int32), ("sc_ox", C.c_int32)]
 
 
 class DeformParams(C.Structure):
@@ -177,8 +178,10 @@ def _need_cuda(*ts):
 def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, Wv=None, Hout=None, Wout=None, ksize=1,
               stride=1, pad_t=0, pad_l=0, bias=None, rowvec=None, res0=None, res1=None, out=None, out_dtype=None,
               epilogue=EPI_NONE, out_scale=1.0, C0=None, C1=0, ksize_w=0, act=ACT_NONE, out_col=0, split_heads=0, split_dim=0, split_tokens=0, tile_hint=0,
-              act_slope=0.0):
-    """Launch vv_conv_gemm.  x0/x1: NHWC activations ([F,Hin,Win,C] or any shape with C last); weight: [Npad,Kpad] h16."""
+              act_slope=0.0, scatter=None):
+    """Launch vv_conv_gemm.  x0/x1: NHWC activations ([F,Hin,Win,C] or any shape with C last); weight: [Npad,Kpad] h16.
+    scatter = (OH, OW, sy, sx, oy, ox): row (f, y, x) of this launch goes to row (f*OH + y*sy + oy)*OW + x*sx + ox of `out` (required; residuals
+    are read at the same rows) -- the four parity launches of a convolution over a nearest-2x upsampled image (nn.UpConv2x)."""
     _need_cuda(x0, x1, weight, bias, rowvec, res0, res1, out)      # out_col: write into columns [out_col, out_col+N) of `out`
     Hv = Hin if Hv is None else Hv
     Wv = Win if Wv is None else Wv
@@ -192,6 +195,9 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
     if res0 is not None and res1 is not None and res0.dtype != res1.dtype:
         raise RuntimeError(f"vv_conv_gemm: res0 ({res0.dtype}) and res1 ({res1.dtype}) must share one dtype (one res_dtype field covers both)")
     res_dt = dt_of(res0) if res0 is not None else (dt_of(res1) if res1 is not None else F32)
+    sc = (0, 0, 0, 0, 0, 0) if scatter is None else tuple(int(v) for v in scatter)
+    if scatter is not None and (out is None or out.numel() < F * sc[0] * sc[1] * nout):
+        raise RuntimeError("vv_conv_gemm: a scattered store needs the caller's [F*OH*OW, N] output tensor")
     if out is None:
         od = h16(dtype) if out_dtype is None else out_dtype
         out = torch.empty((M, nout), dtype=od, device=x0.device)
@@ -203,7 +209,8 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
                    res_dtype=res_dt, out=out.data_ptr() + out_col * out.element_size(), out_dtype=dt_of(out),
                    ldo=out.shape[-1],
                    epilogue=epilogue, out_scale=out_scale, ksize_w=ksize_w, act=act, split_heads=split_heads, split_dim=split_dim,
-                   split_tokens=split_tokens, tile_hint=tile_hint, act_slope=act_slope)
+                   split_tokens=split_tokens, tile_hint=tile_hint, act_slope=act_slope,
+                   sc_oh=sc[0], sc_ow=sc[1], sc_sy=sc[2], sc_sx=sc[3], sc_oy=sc[4], sc_ox=sc[5])
     if PROFILE is not None:
         Npad = weight.shape[0]
         # mirror of launch_t() in vv_gemm.hip (label only): LDS-DMA loaders prefer the 128x128 tile (4 blocks per CU) when N allows

@@ -6,7 +6,7 @@ import threading
 import torch
 
 from . import hip
-from .nn import Conv, GroupNorm, Linear, MotionModule, ResBlock, SpatialTransformer
+from .nn import Conv, GroupNorm, Linear, MotionModule, ResBlock, SpatialTransformer, UpConv2x
 
 
 def timestep_embedding(t, dim):
@@ -88,7 +88,7 @@ class _Backbone:
                 self.up_ch.append(cout)
             self.up.append(layers)
             if i < L - 1:
-                self.ups.append(Conv(ctx, f"{pre}.up_blocks.{i}.upsamplers.0.conv", cout, cout))
+                self.ups.append(UpConv2x(ctx, f"{pre}.up_blocks.{i}.upsamplers.0.conv", cout, cout))
                 self.up_ch.append(cout)
 
     def temb(self, t, key=None):

@@ -3,7 +3,7 @@ site diffuerase.py:62-67 -> DiffuEraser.forward -> vae.encode / vae.decode)."""
 import torch
 
 from . import hip
-from .nn import Conv, GroupNorm, Linear, ResBlock, SelfAttention
+from .nn import Conv, GroupNorm, Linear, ResBlock, SelfAttention, UpConv2x
 
 
 class _MidAttn:
@@ -65,7 +65,7 @@ class VAE:
                 cin = cout
             self.d_blocks.append(rs)
             if i < len(rev) - 1:
-                self.d_up.append(Conv(ctx, f"{pre}.up_blocks.{i}.upsamplers.0.conv", cout, cout, precise=pd))
+                self.d_up.append(UpConv2x(ctx, f"{pre}.up_blocks.{i}.upsamplers.0.conv", cout, cout, precise=pd))
         self.d_norm = GroupNorm(ctx, pre + ".conv_norm_out", rev[-1], g, 1e-6, precise=pd)
         self.d_out = Conv(ctx, pre + ".conv_out", rev[-1], 3, precise=pd)
 
