@@ -92,7 +92,7 @@ typedef struct {
        (f * sc_oh + y * sc_sy + sc_oy) * sc_ow + x * sc_sx + sc_ox of an [F][sc_oh][sc_ow][ldo] tensor.  One 3x3 convolution over a nearest-2x
        upsampled image is four 2x2 convolutions over the source image, one per output parity, with the taps that fall on the same source pixel
        summed (4/9 of the work): each of the four launches scatters with sc_sy = sc_sx = 2, (sc_oy, sc_ox) = its parity.  Not with GEGLU /
-       split_heads. */
+       split_heads / rowvec; runs on the 128-row tiles whatever tile_hint says. */
     int32_t sc_oh, sc_ow, sc_sy, sc_sx, sc_oy, sc_ox;
 } vv_conv_params;
 int vv_conv_gemm(const vv_conv_params* host_p, int dtype, void* stream);

@@ -108,6 +108,11 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
             return (hf * p.Hin + y) * p.Win + x;
         }
         ok = m0 + row < M;
+        if (p.sc_oh > 0 && ok) {      // output scatter (ABI 9): row (f, y, x) of this launch -> row of the [F][sc_oh][sc_ow] grid; residuals and the store follow it
+            const int m = m0 + row, HWs = p.Hout * p.Wout;
+            const int f = m / HWs, r = m - f * HWs, y = r / p.Wout, x = r - y * p.Wout;
+            return (f * p.sc_oh + y * p.sc_sy + p.sc_oy) * p.sc_ow + x * p.sc_sx + p.sc_ox;
+        }
         return m0 + row;
     };
 
@@ -502,7 +507,7 @@ extern "C" int vv_conv_gemm(const vv_conv_params* pp, int dtype, void* stream) {
             (int64_t)(p.Wout - 1) * p.sc_sx + p.sc_ox >= p.sc_ow)
             VV_FAIL(VV_E_ARG, "vv_conv_gemm: output scatter (%d x %d, step %d x %d, origin %d, %d) does not hold the %d x %d grid", p.sc_oh, p.sc_ow, p.sc_sy, p.sc_sx,
                     p.sc_oy, p.sc_ox, p.Hout, p.Wout);
-        if (p.epilogue == VV_EPI_GEGLU || p.split_heads > 0) VV_FAIL(VV_E_ARG, "vv_conv_gemm: output scatter with GEGLU / split_heads");
+        if (p.epilogue == VV_EPI_GEGLU || p.split_heads > 0 || p.rowvec) VV_FAIL(VV_E_ARG, "vv_conv_gemm: output scatter with GEGLU / split_heads / rowvec");
         if ((int64_t)p.F * p.sc_oh * p.sc_ow > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_conv_gemm: more than 2^31 pixels");
     }
     if (M64 > 0x7fffffff || (int64_t)p.F * p.Hin * p.Win > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_conv_gemm: more than 2^31 pixels");

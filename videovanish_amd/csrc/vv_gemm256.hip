@@ -396,7 +396,7 @@ int launch256_t(const vv_conv_params& p, int M, bool lin, int form, hipStream_t 
 extern "C" int vv_gemm256_try(const vv_conv_params* pp, int dtype, int force, void* stream) {
     const vv_conv_params& p = *pp;
     const int kw = p.ksize_w > 0 ? p.ksize_w : p.ksize;
-    if (p.in_dtype == VV_F32 || p.Kpad != p.K || (p.C0 & 63) || (p.C1 & 63)) return -1000;
+    if (p.in_dtype == VV_F32 || p.Kpad != p.K || (p.C0 & 63) || (p.C1 & 63) || p.sc_oh > 0) return -1000;      // (the scattered store lives in the 128-row kernels)
     if (p.Hv != p.Hin || p.Wv != p.Win || p.ksize * kw > 9) return -1000;
     if (!(p.Npad % 320 == 0 && p.epilogue != VV_EPI_GEGLU) && p.Npad % 256 != 0) return -1000;
     if (force >= 2 && p.Npad % 256 != 0) return -1000;

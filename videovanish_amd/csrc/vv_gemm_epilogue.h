@@ -4,13 +4,6 @@
 #pragma once
 #include "vv_common.h"
 
-// output scatter (vv_conv_params.sc_*): launch row m = (f, y, x) -> row of the [F][sc_oh][sc_ow] grid
-__device__ __forceinline__ int64_t vv_scatter_row(const vv_conv_params& p, const int m, const int HWo) {
-    if (p.sc_oh <= 0) return m;
-    const int f = m / HWo, r = m - f * HWo, y = r / p.Wout, x = r - y * p.Wout;
-    return ((int64_t)f * p.sc_oh + y * p.sc_sy + p.sc_oy) * p.sc_ow + x * p.sc_sx + p.sc_ox;
-}
-
 template <typename T, int MT, int NT, typename RowMap>
 __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&acc)[MT][NT], const int row0, const int ncol0, const int lr,
                                               const int lq, const int HWo, RowMap row_m) {
@@ -70,8 +63,7 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
         for (int i = 0; i < MT; ++i) {
             bool mok;
             const int m = row_m(row0 + i * 16 + lr, mok);
-            const int64_t mo = vv_scatter_row(p, mok ? m : 0, HWo);          // == m without a scatter
-            const int64_t rbase = mo * N;
+            const int64_t rbase = (int64_t)(mok ? m : 0) * N;
             float4 ra4[NT];
             // issue every res0 load of this strip first (the common residual); rarer addends are read in place
             if (p.res0 && r0f32) {
@@ -108,7 +100,7 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
                 if (p.act == VV_ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                 else if (p.act == VV_ACT_LRELU) { v[0] = v[0] > 0.f ? v[0] : v[0] * p.act_slope; v[1] = v[1] > 0.f ? v[1] : v[1] * p.act_slope; v[2] = v[2] > 0.f ? v[2] : v[2] * p.act_slope; v[3] = v[3] > 0.f ? v[3] : v[3] * p.act_slope; }
                 // head-major QKV store: out[b][which][head][token][d] = row part + column part
-                const int64_t oc = split ? rowpart + colpart[j] : mo * p.ldo + n;
+                const int64_t oc = split ? rowpart + colpart[j] : (int64_t)m * p.ldo + n;
                 if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + oc) = make_float4(v[0], v[1], v[2], v[3]);
                 else *(uint2*)((unsigned short*)p.out + oc) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
             }
@@ -125,9 +117,8 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int n = ncol0 + j * 16 + 4 * lq;
-            const int64_t mo = vv_scatter_row(p, m, HWo);
-            const int64_t ri = mo * N + n;
-            const int64_t oc = mo * p.ldo + n;
+            const int64_t ri = (int64_t)m * N + n;
+            const int64_t oc = (int64_t)m * p.ldo + n;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (n + r >= N) continue;
