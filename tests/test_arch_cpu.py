@@ -7,6 +7,7 @@ sd-vae-ft-mse AutoencoderKL 83,653,863 -- and the AnimateDiff-style motion modul
 The constructors run on CPU here with a shape-only weight source (meta tensors, no arithmetic, no GPU call)."""
 import math
 
+import pytest
 import torch
 
 from videovanish_amd import nn as vnn
@@ -112,3 +113,31 @@ def test_key_names_follow_diffusers_layout(monkeypatch):
               "decoder.mid_block.attentions.0.group_norm.weight", "decoder.up_blocks.0.upsamplers.0.conv.weight",
               "decoder.up_blocks.3.resnets.2.conv2.bias", "quant_conv.weight", "post_quant_conv.bias", "decoder.conv_out.weight"):
         assert k in v, k
+
+
+@pytest.mark.parametrize("H,W,Hv", [(5, 6, 10), (5, 6, 9), (2, 3, 3), (23, 8, 45)])
+def test_upconv2x_phase_weights_equal_the_upsampled_convolution(H, W, Hv):
+    """packing.upconv2x_phase_weight (nn.UpConv2x): four 2x2 convolutions over the source image, one per output parity, with pad = 1 - parity and
+    the 3x3 taps that fall on one source pixel summed, ARE conv3x3(interpolate(x, nearest)) -- in fp64, even heights and Hv = 2 H - 1 (the last
+    row from the "last" tap table: the tap below it is zero padding, not the duplicated source row)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    Fr, C, N, Wv = 2, 3, 4, 2 * W
+    x = torch.randn(Fr, C, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(N, C, 3, 3, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, size=(Hv, Wv), mode="nearest"), w, padding=1)
+    out = torch.full_like(ref, float("nan"))
+    odd = Hv == 2 * H - 1
+    for py in (0, 1):
+        rows = H - 1 if odd else H
+        for px in (0, 1):
+            wp = packing.upconv2x_phase_weight(w, py, px).double()
+            xp = F.pad(x, (1 - px, px, 1 - py, py))                              # left, right, top, bottom: pad = 1 - parity, bottom / right by bounds
+            out[:, :, py:py + 2 * rows:2, px::2] = F.conv2d(xp.float().double(), wp)[:, :, :rows]
+    if odd:
+        for px in (0, 1):
+            wl = packing.upconv2x_phase_weight(w, "last", px).double()
+            xl = F.pad(x[:, :, H - 2:], (1 - px, px, 0, 0))
+            out[:, :, Hv - 1:Hv, px::2] = F.conv2d(xl, wl)
+    assert not torch.isnan(out).any()
+    assert (out - ref).abs().max().item() <= 1e-5          # (the phase weights are summed in fp32)

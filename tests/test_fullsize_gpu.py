@@ -75,7 +75,7 @@ def test_spatial_attention_level1_full_size(gpu, dname, td, ulp):
         print(f"attention d80 N3600 [{dname}] (b={b}, h={h}): max-abs {err:.2e} (tolerance {4 * ulp * max(1.0, ref.abs().max().item()):.2e})")
         assert err <= 4 * ulp * max(1.0, ref.abs().max().item())
         want = (torch.logsumexp(s * math.log(2.0), -1) / math.log(2.0)).float()
-        assert (lse[b, h].cpu() - want).abs().max().item() <= 2e-3
+        assert (lse[b, h].cpu() - want).abs().max().item() <= max(2e-3, 2 * ulp)      # log2 units: the sum carries the rounding of P (one dominant key: one ulp of P)
 
 def test_temporal_attention_full_size(gpu):
     """32 frames x 14400 pixels x 8 heads x d=40: the strided (f,hw)->(hw,f) gather at full size; 300 pixels checked."""

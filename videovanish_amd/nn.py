@@ -126,8 +126,6 @@ class UpConv2x:
     last output row then sees zero padding where the even case sees the duplicated source row, so it is computed by two small launches of its own
     (py = 0 weights without w[2]) over the last two source rows.  Anything else falls back to the fused-gather 3x3 form."""
 
-    _V = {0: ((1.0, 0.0, 0.0), (0.0, 1.0, 1.0)), 1: ((1.0, 1.0, 0.0), (0.0, 0.0, 1.0)), "last": ((1.0, 0.0, 0.0), (0.0, 1.0, 0.0))}
-
     def __init__(self, ctx, name, cin, cout, gain=1.0, precise=False):
         self.ctx, self.name, self.cin, self.cout, self.gain, self.precise = ctx, name, cin, cout, gain, precise
         weight, b = ctx.src.conv(name, cin, cout, 3, gain)
@@ -141,7 +139,7 @@ class UpConv2x:
         w32 = weight.float()
 
         def phase(vy, vx):
-            wp = torch.einsum("ty,oiyx,sx->oits", torch.tensor(self._V[vy]), w32, torch.tensor(self._V[vx]))      # [cout, cin, 2, 2]
+            wp = packing.upconv2x_phase_weight(w32, vy, vx)                                                        # [cout, cin, 2, 2]
             packed, K = packing.pack_conv(split3_weight(wp, ctx.h16) if precise else wp, ctx.h16)
             return ctx.dev(packed), K
         for py in (0, 1):

@@ -40,6 +40,18 @@ def pack_conv(w, h16, cin_pad=None):
     return pack_matrix(t.reshape(cout, kh * kw * cp), h16), kh * kw * cp
 
 
+# taps of a 3x3 kernel over a nearest-2x upsampled image that fall on the SAME source pixel, per output parity (nn.UpConv2x): rows of the 2 x 3
+# matrices = the two source taps, columns = the three kernel taps they collect.  "last": parity 0 when the tap below is zero padding (odd Hv).
+UPCONV2X_TAPS = {0: ((1.0, 0.0, 0.0), (0.0, 1.0, 1.0)), 1: ((1.0, 1.0, 0.0), (0.0, 0.0, 1.0)), "last": ((1.0, 0.0, 0.0), (0.0, 1.0, 0.0))}
+
+
+def upconv2x_phase_weight(w, vy, vx):
+    """Conv2d weight [Cout][Cin][3][3] -> the 2x2 weight [Cout][Cin][2][2] of output parity (vy, vx) of conv3x3(nearest_upsample_2x(x)) taken over
+    x itself: source rows (y - 1, y) for vy = 0 / (y, y + 1) for vy = 1 (pad_t = 1 - vy), columns alike; summed in fp32 before any rounding."""
+    w32 = w.float()
+    return torch.einsum("ty,oiyx,sx->oits", torch.tensor(UPCONV2X_TAPS[vy], dtype=torch.float32), w32, torch.tensor(UPCONV2X_TAPS[vx], dtype=torch.float32))
+
+
 def geglu_interleave(w, b):
     """GEGLU projection [2*inner][K] (rows: values then gates) -> rows interleaved in blocks of 16
     [v0..15 | g0..15 | v16..31 | g16..31 ...] so that value and gate of one output land in the same lane."""
