@@ -261,7 +261,7 @@ def test_upconv2x_parity_phases(gpu, dname, td, ulp, Fr, H, W, Hv, Wv, C, N, f32
     xr = x if precise else _r(x, td)
     res = torch.randn(Fr, N, Hv, Wv, generator=g)
     ref = F.conv2d(F.interpolate(xr, size=(Hv, Wv), mode="nearest"), w.float(), b.float(), padding=1) + res
-    xin = _nhwc(xr).to(gpu) if f32in else _nhwc(xr).to(td).to(gpu)
+    xin = (_nhwc(xr).to(gpu) if f32in else _nhwc(xr).to(td).to(gpu)).reshape(-1, C)          # [M, C], as the layers hand it over
     out, ho, wo = up(xin, Fr, H, W, Hv=Hv, Wv=Wv, res1=_nhwc(res).to(gpu))
     assert (ho, wo) == (Hv, Wv) and out.dtype == torch.float32
     got = out.cpu().reshape(Fr, Hv, Wv, N).permute(0, 3, 1, 2)

@@ -705,6 +705,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
 
     // ---- Q fragments: lane (r, h) holds Q[q0 + r][16 s + 8 h .. +7]; chunk 5 (s = 2, h = 1) is the pad chunk: slots 40, 41 = -m (hi, lo)
     const int q0 = qt * BQ + wave * 32 * QB;
+    const bool active = q0 < p.Nq;       // wave-uniform: a wave past Nq (N = 14400: three of the four waves of the last query block) feeds the DMA ring only
     uint4 qf[QB][3];
 #pragma unroll
     for (int x = 0; x < QB; ++x)
@@ -891,7 +892,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (it + 1 < ntiles) { dma(0, it + 1, nK, 1u); dma(1, it + 1, nV, 1u); }
-            body(cK, cV, it + 1 == ntiles);
+            if (active) body(cK, cV, it + 1 == ntiles);
         };
         for (int it = 0; it < ntiles; it += 2) {
             step(it, dK0, dV0, dK1, dV1);
@@ -905,8 +906,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
             lb[x] = __shfl(o2[x][1][0], 32 + (lane & 15));
             bad = bad || !(la[x] > 0.f && la[x] < 3.0e38f && lb[x] > 0.f && lb[x] < 3.0e38f);
         }
-        if (attempt == 1 || !__syncthreads_or(bad ? 1 : 0)) break;
+        if (attempt == 1 || !__syncthreads_or(active && bad ? 1 : 0)) break;
     }
+    if (!active) return;
     // ---- finalize: O[q][d] = O^T[d][q] / l
 #pragma unroll
     for (int x = 0; x < QB; ++x) {
