@@ -115,29 +115,34 @@ def test_key_names_follow_diffusers_layout(monkeypatch):
         assert k in v, k
 
 
-@pytest.mark.parametrize("H,W,Hv", [(5, 6, 10), (5, 6, 9), (2, 3, 3), (23, 8, 45)])
-def test_upconv2x_phase_weights_equal_the_upsampled_convolution(H, W, Hv):
-    """packing.upconv2x_phase_weight (nn.UpConv2x): four 2x2 convolutions over the source image, one per output parity, with pad = 1 - parity and
-    the 3x3 taps that fall on one source pixel summed, ARE conv3x3(interpolate(x, nearest)) -- in fp64, even heights and Hv = 2 H - 1 (the last
-    row from the "last" tap table: the tap below it is zero padding, not the duplicated source row)."""
+@pytest.mark.parametrize("H,W,Hv,Wv", [(5, 6, 10, 12), (5, 6, 9, 12), (2, 3, 3, 6), (23, 8, 45, 16), (5, 6, 10, 11), (5, 6, 9, 11), (2, 2, 3, 3)])
+def test_upconv2x_phase_weights_equal_the_upsampled_convolution(H, W, Hv, Wv):
+    """packing.upconv2x_phase_weight (nn.UpConv2x): 2x2 convolutions over the source image, one per output parity, with pad = 1 - parity and
+    the 3x3 taps that fall on one source pixel summed, ARE conv3x3(interpolate(x, nearest)) -- in fp64, even sizes and Hv = 2 H - 1 / Wv = 2 W - 1
+    (the last row / column / corner from the "last" tap table: the tap beyond the edge is zero padding, not the duplicated source pixel).  Mirrors the
+    launch plan of UpConv2x.__call__: bulk, last row, last column, corner."""
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(5)
-    Fr, C, N, Wv = 2, 3, 4, 2 * W
+    Fr, C, N = 2, 3, 4
     x = torch.randn(Fr, C, H, W, generator=g, dtype=torch.float64)
     w = torch.randn(N, C, 3, 3, generator=g, dtype=torch.float64)
     ref = F.conv2d(F.interpolate(x, size=(Hv, Wv), mode="nearest"), w, padding=1)
     out = torch.full_like(ref, float("nan"))
-    odd = Hv == 2 * H - 1
+    oh, ow = 2 * H - Hv, 2 * W - Wv
+
+    def conv(src, key, pt, pl, hout, wout):                                   # 2x2 taps, top / left padding (pt, pl), bottom / right by bounds
+        wp = packing.upconv2x_phase_weight(w, *key).double()
+        return F.conv2d(F.pad(src, (pl, 1, pt, 1)), wp)[:, :, :hout, :wout]
     for py in (0, 1):
-        rows = H - 1 if odd else H
         for px in (0, 1):
-            wp = packing.upconv2x_phase_weight(w, py, px).double()
-            xp = F.pad(x, (1 - px, px, 1 - py, py))                              # left, right, top, bottom: pad = 1 - parity, bottom / right by bounds
-            out[:, :, py:py + 2 * rows:2, px::2] = F.conv2d(xp.float().double(), wp)[:, :, :rows]
-    if odd:
+            out[:, :, py:py + 2 * (H - oh):2, px:px + 2 * (W - ow):2] = conv(x, (py, px), 1 - py, 1 - px, H - oh, W - ow)
+    if oh:
         for px in (0, 1):
-            wl = packing.upconv2x_phase_weight(w, "last", px).double()
-            xl = F.pad(x[:, :, H - 2:], (1 - px, px, 0, 0))
-            out[:, :, Hv - 1:Hv, px::2] = F.conv2d(xl, wl)
+            out[:, :, Hv - 1:Hv, px:px + 2 * (W - ow):2] = conv(x[:, :, H - 2:], ("last", px), 0, 1 - px, 1, W - ow)
+    if ow:
+        for py in (0, 1):
+            out[:, :, py:py + 2 * (H - oh):2, Wv - 1:Wv] = conv(x[:, :, :, W - 2:], (py, "last"), 1 - py, 0, H - oh, 1)
+    if oh and ow:
+        out[:, :, Hv - 1:Hv, Wv - 1:Wv] = conv(x[:, :, H - 2:, W - 2:], ("last", "last"), 0, 0, 1, 1)
     assert not torch.isnan(out).any()
     assert (out - ref).abs().max().item() <= 1e-5          # (the phase weights are summed in fp32)

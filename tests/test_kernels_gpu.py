@@ -245,12 +245,15 @@ def test_attention_spatial(gpu, dname, td, ulp, B, heads, Nq, Nkv, D):
 @pytest.mark.parametrize("Fr,H,W,Hv,Wv,C,N,f32in,precise", [(2, 9, 12, 18, 24, 64, 64, False, False), (2, 9, 12, 17, 24, 64, 96, False, False),
                                                            (1, 5, 8, 10, 16, 128, 64, True, False), (3, 2, 4, 3, 8, 64, 64, False, False),
                                                            (2, 23, 40, 45, 80, 64, 160, False, False), (1, 6, 7, 11, 13, 64, 64, False, False),
-                                                           (1, 7, 9, 14, 18, 64, 32, True, True), (1, 7, 9, 13, 18, 64, 32, True, True)])
+                                                           (2, 8, 14, 15, 27, 64, 64, False, False), (1, 5, 7, 10, 13, 64, 64, True, False),
+                                                           (1, 2, 2, 3, 3, 64, 64, False, False), (1, 6, 7, 12, 15, 64, 64, False, False),
+                                                           (1, 7, 9, 14, 18, 64, 32, True, True), (1, 7, 9, 13, 17, 64, 32, True, True)])
 def test_upconv2x_parity_phases(gpu, dname, td, ulp, Fr, H, W, Hv, Wv, C, N, f32in, precise):
     """nn.UpConv2x: the 3x3 convolution of an Upsample2D layer as four 2x2 convolutions over the SOURCE image (taps on the same source pixel summed,
-    scattered store, ABI 9) against torch's interpolate(nearest) + conv2d with exact weights -- even sizes, Hv = 2 H - 1 (the last row has its own
-    launches; 45 x 80 from 23 x 40 is UNet level 2 -> 1 at 720p), a width that is not 2 W (fallback to the fused-gather form), fp32 and h16
-    sources, bias + residual, split precision (the VAE decoder) -- and against the fused-gather form itself."""
+    scattered store, ABI 9) against torch's interpolate(nearest) + conv2d with exact weights -- even sizes, Hv = 2 H - 1 and / or Wv = 2 W - 1 (the
+    last row / column / corner have their own launches; 45 x 80 from 23 x 40 is UNet level 2 -> 1 at 720p, 15 x 27 from 8 x 14 is c2's level 3 -> 2),
+    a width outside the family (15 from 7: fallback to the fused-gather form), fp32 and h16 sources, bias + residual, split precision (the VAE
+    decoder) -- and against the fused-gather form itself."""
     from videovanish_amd import hip
     from videovanish_amd.nn import Ctx, UpConv2x
     ctx = Ctx(gpu, dname, weight_seed=7)
@@ -271,8 +274,33 @@ def test_upconv2x_parity_phases(gpu, dname, td, ulp, Fr, H, W, Hv, Wv, C, N, f32
     assert err <= tol, (err, tol)
     old, _, _ = up.fallback()(xin, Fr, H, W, Hv=Hv, Wv=Wv, res1=_nhwc(res).to(gpu))          # the fused-gather 3x3 form (9 taps, weights rounded one by one)
     assert (old - out).abs().max().item() <= tol
-    if Wv != 2 * W:
-        assert torch.equal(old, out)                                                          # ... which IS the path such sizes take
+    if Wv > 2 * W:
+        assert torch.equal(old, out)                                                          # ... which IS the path sizes outside the family take
+
+
+def test_conv_gemm_scatter_arguments(gpu):
+    """vv_conv_params.sc_* (ABI 9): a grid that does not hold the launch's rows, a missing output tensor, GEGLU / rowvec with a scatter are refused by name;
+    a 1x1 launch scattered with step 1 / origin 0 into its own grid equals the plain launch bit for bit (also through a 256-row-eligible shape, which
+    must stay on the 128-row kernels)."""
+    from videovanish_amd import hip, packing
+    td, dt = torch.float16, hip.F16
+    g = torch.Generator().manual_seed(41)
+    Fr, H, W, C, N = 2, 6, 8, 64, 320
+    x = torch.randn(Fr * H * W, C, generator=g).to(td).to(gpu)
+    w = packing.pack_matrix(torch.randn(N, C, generator=g) / 8.0, td).to(gpu)
+    plain = hip.conv_gemm(dt, x, w, N, C, F=Fr, Hin=H, Win=W, out_dtype=torch.float32)
+    out = torch.zeros(Fr * H * W, N, dtype=torch.float32, device=gpu)
+    hip.conv_gemm(dt, x, w, N, C, F=Fr, Hin=H, Win=W, out=out, scatter=(H, W, 1, 1, 0, 0))
+    assert torch.equal(out, plain)
+    big = torch.zeros(Fr * 2 * H * 2 * W, N, dtype=torch.float32, device=gpu)
+    hip.conv_gemm(dt, x, w, N, C, F=Fr, Hin=H, Win=W, out=big, scatter=(2 * H, 2 * W, 2, 2, 1, 0))
+    assert torch.equal(big.view(Fr, 2 * H, 2 * W, N)[:, 1::2, 0::2].reshape(-1, N), plain) and big.view(Fr, 2 * H, 2 * W, N)[:, 0::2].abs().max().item() == 0.0
+    with pytest.raises(RuntimeError, match="scatter"):
+        hip.conv_gemm(dt, x, w, N, C, F=Fr, Hin=H, Win=W, out=big, scatter=(2 * H - 1, 2 * W, 2, 2, 1, 0))       # row 2 (H - 1) + 1 does not exist
+    with pytest.raises(RuntimeError, match="scatter"):
+        hip.conv_gemm(dt, x, w, N, C, F=Fr, Hin=H, Win=W, scatter=(2 * H, 2 * W, 2, 2, 0, 0))                    # no output tensor
+    with pytest.raises(RuntimeError, match="scatter"):
+        hip.conv_gemm(dt, x, w, N, C, F=Fr, Hin=H, Win=W, out=big, rowvec=torch.zeros(Fr, N, device=gpu), scatter=(2 * H, 2 * W, 2, 2, 0, 0))
 
 
 @pytest.mark.parametrize("dname,td,ulp", DT)

@@ -119,12 +119,14 @@ class UpConv2x:
     """The 3x3 convolution (padding 1) of an Upsample2D layer, taken over the nearest-neighbour upsampled image WITHOUT building it and without the
     taps the upsampling duplicates: the 3 x 3 taps of output pixel (2y + py, 2x + px) fall on only 2 x 2 source pixels, so each of the four output
     parities is a 2x2 convolution over the SOURCE image whose weights are the 3x3 taps summed per source pixel (in fp32, before the one rounding to
-    h16) -- 4/9 of the multiply-adds of the fused-gather form Conv(..., Hv=, Wv=) runs.  Four launches of vv_conv_gemm (ksize 2, pad = 1 - parity)
-    scatter into the [F, Hv, Wv] output (vv_conv_params.sc_*); bias / residual ride in every launch.
+    h16: packing.upconv2x_phase_weight) -- 4/9 of the multiply-adds of the fused-gather form Conv(..., Hv=, Wv=) runs.  Four launches of
+    vv_conv_gemm (ksize 2, pad = 1 - parity) scatter into the [F, Hv, Wv] output (vv_conv_params.sc_*); bias / residual ride in every launch.
       rows:  py = 0: source rows (y - 1: w[0], y: w[1] + w[2]);   py = 1: (y: w[0] + w[1], y + 1: w[2]);   columns alike.
-    Sizes: Wv == 2 W and Hv == 2 H, or Hv == 2 H - 1 (torch's nearest map floor(r H / Hv) is floor(r / 2) there too: 45 rows from 23 at 720p): the
-    last output row then sees zero padding where the even case sees the duplicated source row, so it is computed by two small launches of its own
-    (py = 0 weights without w[2]) over the last two source rows.  Anything else falls back to the fused-gather 3x3 form."""
+    Sizes: Hv in (2 H, 2 H - 1) and Wv in (2 W, 2 W - 1) -- every size a stride-2 downsampling followed by "resize to the skip's size" produces
+    (torch's nearest map floor(r H / Hv) is floor(r / 2) for both; 45 rows from 23 at 720p).  In the odd case the last output row (column) sees zero
+    padding where the even case sees the duplicated source row, so it is computed by small launches of its own over the last two source rows
+    (columns) with the tap beyond the edge dropped ("last" weights); both odd: one more launch for the corner pixel.  Anything else falls back to
+    the fused-gather 3x3 form."""
 
     def __init__(self, ctx, name, cin, cout, gain=1.0, precise=False):
         self.ctx, self.name, self.cin, self.cout, self.gain, self.precise = ctx, name, cin, cout, gain, precise
@@ -132,21 +134,16 @@ class UpConv2x:
         self.b = ctx.dev(b.float()) if (b is not None and b.device.type != "meta") else None
         self.meta = weight.device.type == "meta"
         self.cp = cin
-        self.w, self.wl, self._fallback = {}, {}, None
+        self.w, self._fallback = {}, None
         if self.meta:                                    # shape-only construction (modelhub.manifest): the tensor was requested, nothing is packed
             self.K = 4 * cin * (3 if precise else 1)
             return
         w32 = weight.float()
-
-        def phase(vy, vx):
-            wp = packing.upconv2x_phase_weight(w32, vy, vx)                                                        # [cout, cin, 2, 2]
-            packed, K = packing.pack_conv(split3_weight(wp, ctx.h16) if precise else wp, ctx.h16)
-            return ctx.dev(packed), K
-        for py in (0, 1):
-            for px in (0, 1):
-                self.w[(py, px)], self.K = phase(py, px)
-        for px in (0, 1):
-            self.wl[px], _ = phase("last", px)
+        for vy in (0, 1, "last"):
+            for vx in (0, 1, "last"):
+                wp = packing.upconv2x_phase_weight(w32, vy, vx)                                                    # [cout, cin, 2, 2]
+                packed, self.K = packing.pack_conv(split3_weight(wp, ctx.h16) if precise else wp, ctx.h16)
+                self.w[(vy, vx)] = ctx.dev(packed)
 
     def fallback(self):
         if self._fallback is None:
@@ -156,25 +153,33 @@ class UpConv2x:
     def __call__(self, x, F, H, W, Hv=None, Wv=None, res1=None):
         Hv = 2 * H if Hv is None else Hv
         Wv = 2 * W if Wv is None else Wv
-        odd = Hv == 2 * H - 1
-        if Wv != 2 * W or not (Hv == 2 * H or (odd and H >= 2)) or self.cin % 8:
+        oh, ow = 2 * H - Hv, 2 * W - Wv                      # 1: the odd case of that dimension
+        if oh not in (0, 1) or ow not in (0, 1) or (oh and H < 2) or (ow and W < 2) or self.cin % 8:
             return self.fallback()(x, F, H, W, Hv=Hv, Wv=Wv, res1=res1)
         ctx = self.ctx
         x = x.reshape(-1, x.shape[-1])
         if self.precise:      # [M, 3 C]: hi | lo | hi' (see Conv)
             x = x if (x.dtype == ctx.h16 and x.shape[1] == 3 * self.cp) else hip.split3(ctx.dt, x)
         Cx = x.shape[-1]
+        x4 = x.view(F, H, W, Cx)
         out = torch.empty((F * Hv * Wv, self.cout), dtype=torch.float32, device=x.device)
+
+        def launch(src, hin, win, hout, wout, wkey, pt, pl, oy, ox):
+            hip.conv_gemm(ctx.dt, src, self.w[wkey], self.cout, self.K, F=F, Hin=hin, Win=win, Hout=hout, Wout=wout, ksize=2, pad_t=pt, pad_l=pl,
+                          bias=self.b, res1=res1, out=out, scatter=(Hv, Wv, 2, 2, oy, ox))
         for py in (0, 1):
-            rows = H - 1 if odd else H                  # odd: class 0 leaves its last row to the launches below, class 1 has H - 1 rows
+            for px in (0, 1):                                # the bulk: every row / column whose taps do not reach beyond an odd edge
+                launch(x, H, W, H - oh, W - ow, (py, px), 1 - py, 1 - px, py, px)
+        if oh:
+            xr = x4[:, H - 2:].contiguous()                  # the last two source rows of every frame -> output row Hv - 1 (parity 0)
             for px in (0, 1):
-                hip.conv_gemm(ctx.dt, x, self.w[(py, px)], self.cout, self.K, F=F, Hin=H, Win=W, Hout=rows, Wout=W, ksize=2, pad_t=1 - py, pad_l=1 - px,
-                              bias=self.b, res1=res1, out=out, scatter=(Hv, Wv, 2, 2, py, px))
-        if odd:
-            xl = x.view(F, H, W, Cx)[:, H - 2:].contiguous()         # the last two source rows of every frame
-            for px in (0, 1):
-                hip.conv_gemm(ctx.dt, xl, self.wl[px], self.cout, self.K, F=F, Hin=2, Win=W, Hout=1, Wout=W, ksize=2, pad_t=0, pad_l=1 - px,
-                              bias=self.b, res1=res1, out=out, scatter=(Hv, Wv, 2, 2, Hv - 1, px))
+                launch(xr, 2, W, 1, W - ow, ("last", px), 0, 1 - px, Hv - 1, px)
+        if ow:
+            xc = x4[:, :, W - 2:].contiguous()               # the last two source columns -> output column Wv - 1
+            for py in (0, 1):
+                launch(xc, H, 2, H - oh, 1, (py, "last"), 1 - py, 0, py, Wv - 1)
+        if oh and ow:
+            launch(x4[:, H - 2:, W - 2:].contiguous(), 2, 2, 1, 1, ("last", "last"), 0, 0, Hv - 1, Wv - 1)
         return out, Hv, Wv
 
 
