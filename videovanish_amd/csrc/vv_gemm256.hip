@@ -414,10 +414,16 @@ extern "C" int vv_gemm256_try(const vv_conv_params* pp, int dtype, int force, vo
         const bool n256 = p.Npad % 256 == 0;
         const int BN = (p.Npad % 320 == 0 && p.epilogue != VV_EPI_GEGLU) ? 320 : 256;
         bool win = false;
+        // Round 4: re-measured in back-to-back loops of 0.4 s per form (the board is power capped; the round-2 table came from 6-launch loops that
+        // ran while the clock was still ramping: profiles/r4_gemm256_steady.txt): the 3x3 convolutions of levels 0 / 1 (M > 65536) are faster on the
+        // 128-row tiles whatever their K (x1.06-1.18), level 2 stays here (x1.12-1.34); the level-2 FF output projection (K = 5120, N = 1280) takes
+        // the 2-phase 256x320 form (x1.14 over the 128-row tile, x1.09 over the 8-phase form; the level-1 one, K = 2560, gained x1.05 standalone and lost
+        // 2 % in the pipeline: stays on the 128-row tile).
         if (lin) {
-            if (n256 && ((p.epilogue == VV_EPI_GEGLU && p.K >= 640) || (p.K >= 1280 && p.Npad >= 3840) || p.K >= 5120)) { win = true; form = 3; }
+            if (p.K >= 5120 && p.Npad % 320 == 0 && p.Npad < 3840 && p.epilogue != VV_EPI_GEGLU) { win = true; form = 1; }
+            else if (n256 && ((p.epilogue == VV_EPI_GEGLU && p.K >= 640) || (p.K >= 1280 && p.Npad >= 3840) || p.K >= 5120)) { win = true; form = 3; }
             else if (p.K >= 5120) { win = true; form = 1; }
-        } else if (p.ksize == 3 && p.stride == 1 && p.K >= 5760 && (p.C1 == 0 || M64 <= 65536)) { win = true; form = 1; }
+        } else if (p.ksize == 3 && p.stride == 1 && p.K >= 5760 && M64 <= 65536) { win = true; form = 1; }
         const int64_t tiles = ((M64 + 255) / 256) * (p.Npad / (form == 3 ? 256 : BN));
         if (!win || tiles < 400) return -1000;
     }
