@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from videovanish_amd import hip, packing
+if os.environ.get("VV_LIB_PATH"):
+    hip._LIB_PATH = os.environ["VV_LIB_PATH"]          # lab: another build of the library (e.g. the VV_AB build with its VV_GEMM_* switches)
 
 dev = torch.device("cuda:0")
 dname = sys.argv[1] if len(sys.argv) > 1 else "bf16"
@@ -83,7 +85,7 @@ def main():
     only = os.environ.get("VV_BENCH_ONLY")
     tot = {1: 0.0, 2: 0.0, "best": 0.0}
     for name, Fr, H, W, cin, cout, k, stride, flags, calls in CASES:
-        if only and only not in name:
+        if only and not any(o in name for o in only.split("|")):
             continue
         c0, c1 = cin if isinstance(cin, tuple) else (cin, 0)
         Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
@@ -112,6 +114,8 @@ def main():
         hints = (1, 2, 3, 4) if (cout % 256 == 0) else (1, 2)
         if SECONDS > 0:
             hints = (0,) + hints                       # 0 = what the product's heuristic picks
+        if os.environ.get("VV_BENCH_HINTS"):
+            hints = tuple(int(h) for h in os.environ["VV_BENCH_HINTS"].split(","))
         for hint in hints:
             out = torch.zeros(M, cout // 2 if geglu else cout, dtype=od, device=dev)
             fn = lambda: hip.conv_gemm(DT, x0, wp, cout, K, x1=x1, F=Fr, Hin=H, Win=W, Hout=Ho, Wout=Wo, ksize=k, stride=stride, pad_t=k // 2,
@@ -119,9 +123,12 @@ def main():
                                        tile_hint=hint, **skw)
             times[hint] = timeit(fn)
             outs[hint] = out.float()
+        fl = 2.0 * M * cout * K
+        if 1 not in times or 2 not in times:
+            print(f"{name:34s} M={M:7d} " + " | ".join(f"hint{h} {times[h]*1e3:7.3f} ms {fl/times[h]/1e12:7.1f} TF/s" for h in hints), flush=True)
+            continue
         diff = max((outs[1] - outs[h]).abs().max().item() for h in hints)
         scale = outs[1].abs().max().item()
-        fl = 2.0 * M * cout * K
         t1, t2 = times[1], times[2]
         for h in (1, 2):
             tot[h] += times[h] * calls
