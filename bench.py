@@ -121,6 +121,54 @@ def strong_scaling(args, model, dist, rank, world, H, W, ucfg, vcfg):
     }
 
 
+class PowerTrace:
+    """Socket power / shader clock of one GPU while the timed region runs, sampled by `rocm-smi` from a side thread (one short-lived child process
+    every ~0.5 s; the timed region only launches kernels, nothing of it waits on this).  Context for `roofline`: the job runs at the board's power cap
+    (DESIGN.md 5.00), so the nominal MFMA peak is not reachable whatever the kernels do.  Every failure (no rocm-smi, no permission, odd output) ends
+    in `None`: the bench line never depends on it."""
+
+    def __init__(self, device_index):
+        import threading
+        self.dev, self.samples, self._stop = int(device_index), [], threading.Event()
+        self._thread = threading.Thread(target=self._run, name="vv-power-trace", daemon=True)
+
+    def _run(self):
+        import re, subprocess
+        while not self._stop.is_set() and len(self.samples) < 4000:
+            try:
+                out = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                pw = re.search(r"Package Power \(W\):\s*([0-9.]+)", out)
+                ck = re.search(r"sclk clock level:[^(]*\((\d+)Mhz\)", out)
+                if pw:
+                    self.samples.append((float(pw.group(1)), int(ck.group(1)) if ck else 0))
+            except Exception:
+                return
+            self._stop.wait(0.3)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=15)
+
+    def summary(self):
+        if len(self.samples) < 4:
+            return None
+        pw = [p for p, _ in self.samples]
+        cap = None
+        try:
+            import re, subprocess
+            m = re.search(r"Package Power \(W\):\s*([0-9.]+)", subprocess.run(["rocm-smi", "-d", str(self.dev), "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout)
+            cap = float(m.group(1)) if m else None
+        except Exception:
+            cap = None
+        return {"source": "rocm-smi --showpower --showclocks, one sample every ~0.5 s during the timed region (rank 0's GPU)", "samples": len(pw),
+                "mean_w": round(sum(pw) / len(pw), 1), "max_w": max(pw), "cap_w": cap, "share_of_samples_at_or_above_1200_w": round(sum(p >= 1200 for p in pw) / len(pw), 3),
+                "mean_sclk_mhz": round(sum(c for _, c in self.samples) / len(self.samples))}
+
+
 def parity_summary():
     """The measured parity lines of the default precision plan, read from the newest committed GPU parity log
     (profiles/r*_parity_gpu.txt, written by `VV_PARITY_REPORT=... pytest -m gpu tests/test_configs_gpu.py`): nothing is hard-coded here."""
@@ -213,6 +261,7 @@ def main():
                     help="VAE decoder in one pass of h16 operands instead of split precision (3 MFMA passes per GEMM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-power-trace", action="store_true", help="do not sample rocm-smi beside the timed region (the `power` object of the line)")
     ap.add_argument("--lanes", type=int, default=None, help="chunks of one rank in flight at once, each on its own HIP stream "
                     "(RunConfig.concurrent_chunks; default: the product default)")
     ap.add_argument("--one-stream", action="store_true", help="A/B: the round-3 schedule (one chunk at a time, BrushNet and UNet on one stream)")
@@ -283,11 +332,16 @@ def main():
         model.forward_device(fr, pr, mk, T, base, steps=args.denoise_steps, scheduler="ddim", dist=dist)
         del fr, pr, mk
     T, base, fr, pr, mk = resident_inputs(args.steps)
+    power = PowerTrace(local_rank) if (rank == 0 and not args.no_power_trace) else None
     barrier()
     t0 = time.time()
+    if power is not None:
+        power.__enter__()
     out, (lo, hi) = model.forward_device(fr, pr, mk, T, base, steps=args.denoise_steps, scheduler="ddim", dist=dist)
     barrier()
     dt = time.time() - t0
+    if power is not None:
+        power.__exit__()
     if world > 1:
         import torch.distributed as td
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -364,7 +418,7 @@ def main():
                                                  "kernel_seconds": round(sum(v[1] for v in kernels.values()), 3),
                                                  "note": "one chunk of the same resident inputs re-run after the timed region on ONE stream, every launch bracketed "
                                                          "by HIP events on its launch stream; the timed region itself overlaps kernels of several streams"},
-        "roofline": roof, "temporal_block": temporal, "cpu_baseline": cpu,
+        "roofline": roof, "temporal_block": temporal, "cpu_baseline": cpu, "power": power.summary() if power is not None else None,
         "job_tflops": round(__import__("videovanish_amd.flops", fromlist=["x"]).per_output_frame(H, W, args.chunk, args.denoise_steps, ucfg, vcfg)
                             * args.chunk * args.steps * world / dt / 1e12, 1),
         "kernel_times_s": {k: [v[0], round(v[1], 3), round(v[2] / v[1] / 1e12, 1) if v[2] else round(v[3] / v[1] / 1e9, 1)] for k, v in

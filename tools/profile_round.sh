@@ -12,9 +12,9 @@ export TMPDIR=/tmp
 W=/tmp/vvprof_$TAG
 rm -rf $W; mkdir -p $W
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $W/stats -o bench -- python3 $ROOT/bench.py --steps 2 --warmup 1 --one-stream --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $W/stats -o bench -- python3 $ROOT/bench.py --steps 2 --warmup 1 --one-stream --no-cpu-baseline --no-power-trace > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 find $W/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
-P2="--steps 1 --warmup 0 --denoise-steps 2 --no-cpu-baseline --no-kernel-events"
+P2="--steps 1 --warmup 0 --denoise-steps 2 --no-cpu-baseline --no-kernel-events --no-power-trace"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $W/fetch -o f -- python3 $ROOT/bench.py $P2 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $W/write -o w -- python3 $ROOT/bench.py $P2 > $OUT/pmc_write.log 2>&1
 F=$(find $W/fetch -name "*counter_collection.csv" | head -1); WR=$(find $W/write -name "*counter_collection.csv" | head -1)
