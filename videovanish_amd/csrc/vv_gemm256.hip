@@ -423,7 +423,7 @@ extern "C" int vv_gemm256_try(const vv_conv_params* pp, int dtype, int force, vo
             if (p.K >= 5120 && p.Npad % 320 == 0 && p.Npad < 3840 && p.epilogue != VV_EPI_GEGLU) { win = true; form = 1; }
             else if (n256 && ((p.epilogue == VV_EPI_GEGLU && p.K >= 640) || (p.K >= 1280 && p.Npad >= 3840) || p.K >= 5120)) { win = true; form = 3; }
             else if (p.K >= 5120) { win = true; form = 1; }
-        } else if (p.ksize == 3 && p.stride == 1 && p.K >= 5760 && M64 <= 65536) { win = true; form = 1; }
+        } else if (p.ksize == 3 && p.stride == 1 && p.K >= 5760 && M64 <= 65536 && BN == 320) { win = true; form = 1; }      // (the 256x256 form lost on every VAE shape)
         const int64_t tiles = ((M64 + 255) / 256) * (p.Npad / (form == 3 ? 256 : BN));
         if (!win || tiles < 400) return -1000;
     }

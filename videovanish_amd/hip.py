@@ -230,7 +230,7 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
                     form = 3
                 elif K >= 5120:
                     form = 1
-            elif ksize == 3 and stride == 1 and K >= 5760 and M <= 65536:
+            elif ksize == 3 and stride == 1 and K >= 5760 and M <= 65536 and Npad % 320 == 0:
                 form = 1
             bn = 256 if form == 3 else (320 if (Npad % 320 == 0 and epilogue != EPI_GEGLU) else 256)
             if form and ((M + 255) // 256) * (Npad // bn) >= 400:
