@@ -14,9 +14,15 @@ compile() {   # compile <src> <obj> [extra flags]
 }
 # VV_AB=1 ./build.sh builds the lab variant: environment-selected A/B kernels + the opt-in vv_conv3 kernel
 AB=""
-SRCS="vv_api vv_gemm vv_gemm256 vv_motion vv_chain vv_norm vv_elem vv_image vv_flow vv_deform vv_sam2"
+SRCS="vv_api vv_motion vv_chain vv_norm vv_elem vv_image vv_flow vv_deform vv_sam2"
 if [ -n "$VV_AB" ]; then AB="-DVV_AB"; SRCS="$SRCS vv_conv3"; else rm -f build/vv_conv3.o; fi
 if [ "$(cat build/.ab 2>/dev/null)" != "$AB" ]; then rm -f build/*.o; echo "$AB" > build/.ab; fi
+# the two GEMM sources hold every tile form x loader mode x operand type: one translation unit per operand type (BF16 / F16) halves the longest pole
+rm -f build/vv_gemm.o build/vv_gemm256.o
+for f in vv_gemm vv_gemm256; do
+  compile $f ${f}_bf16 -DVV_DT_ONLY=0 $AB
+  compile $f ${f}_f16 -DVV_DT_ONLY=1 $AB
+done
 for f in $SRCS; do
   [ -f $f.hip ] && compile $f $f $AB
 done

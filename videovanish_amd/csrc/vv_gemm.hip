@@ -34,7 +34,7 @@ extern "C" int vv_conv3_halo_try(const vv_conv_params* pp, int dtype, void* stre
 
 namespace {
 
-constexpr int BK = 64;
+[[maybe_unused]] constexpr int BK = 64;
 enum { MODE_H16 = 0, MODE_F32 = 1, MODE_FAST = 2, MODE_FAST32 = 3, MODE_HALO = 4, MODE_LIN = 5, MODE_FAST9 = 6 };
 constexpr int HALO_PX = 184;   // (8+2) x (16+2) = 180 halo pixels of an 8x16 output patch, padded to whole 1 KB DMA blocks
 
@@ -478,6 +478,14 @@ int launch_mode(const vv_conv_params& p, int M, hipStream_t st) {
 
 }  // namespace
 
+// Build split (build.sh): compiled twice, -DVV_DT_ONLY=0 = the BF16 instantiations behind vv_conv_gemm_launch_bf16, -DVV_DT_ONLY=1 = the F16 ones plus
+// the entry point (see vv_gemm256.hip).
+#if defined(VV_DT_ONLY) && VV_DT_ONLY == 0
+extern "C" int vv_conv_gemm_launch_bf16(const vv_conv_params* pp, int M, void* stream) { return launch_mode<BF16>(*pp, M, (hipStream_t)stream); }
+#else
+#if defined(VV_DT_ONLY)
+extern "C" int vv_conv_gemm_launch_bf16(const vv_conv_params* pp, int M, void* stream);
+#endif
 extern "C" int vv_conv_gemm(const vv_conv_params* pp, int dtype, void* stream) {
     if (!pp) VV_FAIL(VV_E_ARG, "vv_conv_gemm: null params");
     const vv_conv_params& p = *pp;
@@ -513,5 +521,10 @@ extern "C" int vv_conv_gemm(const vv_conv_params* pp, int dtype, void* stream) {
     if (M64 > 0x7fffffff || (int64_t)p.F * p.Hin * p.Win > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_conv_gemm: more than 2^31 pixels");
     const int M = (int)M64;
     hipStream_t st = (hipStream_t)stream;
+#if defined(VV_DT_ONLY)
+    return dtype == VV_BF16 ? vv_conv_gemm_launch_bf16(&p, M, stream) : launch_mode<F16>(p, M, st);
+#else
     return dtype == VV_BF16 ? launch_mode<BF16>(p, M, st) : launch_mode<F16>(p, M, st);
+#endif
 }
+#endif

@@ -393,6 +393,17 @@ int launch256_t(const vv_conv_params& p, int M, bool lin, int form, hipStream_t 
 // Eligibility + launch.  Returns VV_OK / an error after launching, or -1000 when the shape is not eligible (caller falls back
 // to the 128-row kernels).  `force`: 0 = only where the heuristic expects a win; 1 = the 2-phase kernel whenever the shape is
 // ELIGIBLE; 2 = the 8-phase kernel whenever eligible (needs Npad % 256 == 0).
+// Build split (build.sh): this source is compiled twice, -DVV_DT_ONLY=0 holds the BF16 instantiations behind vv_gemm256_launch_bf16, -DVV_DT_ONLY=1 the
+// F16 ones plus the entry point below (two translation units of ~50 s instead of one of ~100 s: the longest pole of a clean build).  Without the
+// macro everything lives in one unit.
+#if defined(VV_DT_ONLY) && VV_DT_ONLY == 0
+extern "C" int vv_gemm256_launch_bf16(const vv_conv_params* pp, int M, int lin, int form, void* stream) {
+    return launch256_t<BF16>(*pp, M, lin != 0, form, (hipStream_t)stream);
+}
+#else
+#if defined(VV_DT_ONLY)
+extern "C" int vv_gemm256_launch_bf16(const vv_conv_params* pp, int M, int lin, int form, void* stream);
+#endif
 extern "C" int vv_gemm256_try(const vv_conv_params* pp, int dtype, int force, void* stream) {
     const vv_conv_params& p = *pp;
     const int kw = p.ksize_w > 0 ? p.ksize_w : p.ksize;
@@ -428,5 +439,10 @@ extern "C" int vv_gemm256_try(const vv_conv_params* pp, int dtype, int force, vo
         if (!win || tiles < 400) return -1000;
     }
     hipStream_t st = (hipStream_t)stream;
+#if defined(VV_DT_ONLY)
+    return dtype == VV_BF16 ? vv_gemm256_launch_bf16(&p, M, lin ? 1 : 0, form, stream) : launch256_t<F16>(p, M, lin, form, st);
+#else
     return dtype == VV_BF16 ? launch256_t<BF16>(p, M, lin, form, st) : launch256_t<F16>(p, M, lin, form, st);
+#endif
 }
+#endif
