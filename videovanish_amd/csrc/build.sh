@@ -7,7 +7,7 @@ mkdir -p build
 pids=()
 compile() {   # compile <src> <obj> [extra flags]
   local src=$1 obj=$2; shift 2
-  if [ ! -f build/$obj.o ] || [ $src.hip -nt build/$obj.o ] || [ vv_common.h -nt build/$obj.o ] || [ vv_gemm_epilogue.h -nt build/$obj.o ] || [ ../../include/vvhip.h -nt build/$obj.o ] || [ build.sh -nt build/$obj.o ]; then
+  if [ ! -f build/$obj.o ] || [ $src.hip -nt build/$obj.o ] || [ vv_common.h -nt build/$obj.o ] || [ vv_attn_common.h -nt build/$obj.o ] || [ vv_gemm_epilogue.h -nt build/$obj.o ] || [ ../../include/vvhip.h -nt build/$obj.o ] || [ build.sh -nt build/$obj.o ]; then
     hipcc $FLAGS "$@" -c $src.hip -o build/$obj.o &
     pids+=($!)
   fi
@@ -29,6 +29,7 @@ done
 # attention, small head dims: MFMA results feed VALU code (softmax) every tile -> keep accumulators in arch VGPRs
 # (no v_accvgpr_read/write traffic); large head dims need the AGPR half of the register file
 compile vv_attn vv_attn_small -DVV_ATTN_PART=0 -mllvm -amdgpu-mfma-vgpr-form $AB
+compile vv_attn32 vv_attn32 -mllvm -amdgpu-mfma-vgpr-form $AB      # d = 40 / 80 on the 32x32x16 MFMA (the dominant kernels)
 compile vv_attn vv_attn_large -DVV_ATTN_PART=1 $AB
 if [ -n "$VV_AB" ]; then      # lab build: every attention A/B variant and timing probe (VV_ATTN_VARIANT), kept out of the product sources
   compile vv_attn_lab vv_attn_lab_small -DVV_ATTN_PART=0 -mllvm -amdgpu-mfma-vgpr-form $AB

@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr int MC = 320, MF = 32, MH = 8, MD = 40;
+[[maybe_unused]] constexpr int MC = 320, MF = 32, MH = 8, MD = 40;
 constexpr int NSLOT = 10, AHEAD = 6, SLAB = 8192;     // slabs are consumed in PAIRS: one wait + barrier per 16 KB
 // fp32 parameter block (floats): offsets
 constexpr int P_GN_A = 0, P_GN_B = 320, P_BIN = 640, P_LN1G = 960, P_LN1B = 1280, P_BO1 = 1600, P_LN2G = 1920, P_LN2B = 2240, P_BO2 = 2560,
