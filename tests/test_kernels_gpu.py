@@ -373,7 +373,7 @@ def test_attention_online_softmax_rescale(gpu):
 @pytest.mark.parametrize("D", [40, 80])                                   # d = 80: attn80_kernel (N >= 512; the reference enters through the MFMA's C operand)
 @pytest.mark.parametrize("dname,td,ulp", [("bf16", torch.bfloat16, 2 ** -8), ("fp16", torch.float16, 2 ** -11)])
 def test_attention_d40_lazy_reference_maximum(gpu, dname, td, ulp, N, D):
-    """The d = 40 spatial kernels subtract a softmax reference ON THE MATRIX PIPE (vv_attn.hip attn40_kernel / attn40q2_kernel: the reference is
+    """The d = 40 spatial kernels subtract a softmax reference ON THE MATRIX PIPE (vv_attn32.hip attn40_kernel / attn40q2_kernel / attn80_kernel: the reference is
     fixed once from a 64-key sample, P may exceed 1, a block whose denominator overflows repeats its keys with the exact maximum): exercise
     what that adds -- q_prescaled (scale * log2 e folded into q before its one rounding), maxima that creep up tile after tile, maxima that
     jump by hundreds in a late tile (fp16: overflow -> the exact-maximum repeat), a first tile far BELOW the rest, a ragged last tile,
