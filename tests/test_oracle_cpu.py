@@ -224,3 +224,55 @@ def test_c_oracle_equals_numpy_oracle():
         assert np.array_equal(IC.feather_composite(inp, orig, m, f), I.composite(inp, orig, I.feather_alpha(m, f)))
     for (Hd, Wd) in [(17, 50), (60, 72), (30, 36)]:
         assert np.array_equal(IC.resize_bilinear_u8(inp, Wd, Hd), I.resize_bilinear_u8(inp, Wd, Hd))
+
+
+def test_cv2_restatements_against_independent_implementations():
+    """The cv2 restatements of oracle/imageops_ref.py are "parity unpinned" against a real cv2 (absent from the image).  What CAN be checked offline
+    is that they implement the conventions they cite, against independent code: scipy.ndimage for the sampling grid / border rule, a graph search
+    for the chamfer metric.  (Not a pin: cv2's own tap tables and fixed-point constants stay as restated from its published sources.)"""
+    import heapq
+    from scipy import ndimage
+    rng = np.random.default_rng(11)
+    # 1. INTER_LINEAR: half-pixel-centre grid, edge clamp -- scipy's zoom(order=1, grid_mode=True, mode="nearest") uses the same grid in floating point;
+    #    the oracle's 11-bit fixed-point path may differ from it by one grey level, never more
+    img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    for H, W in ((74, 106), (20, 31), (37, 80), (55, 53)):
+        got = I.resize_bilinear_u8(img, W, H).astype(np.int64)
+        ref = ndimage.zoom(img.astype(np.float64), (H / 37, W / 53), order=1, grid_mode=True, mode="nearest")
+        assert ref.shape == (H, W) and np.abs(got - ref).max() <= 1.0 + 1e-9, (H, W, np.abs(got - ref).max())
+    # 2. GaussianBlur(21, sigma 3.5), BORDER_REFLECT_101 = scipy's "mirror": separable correlation with the same taps
+    m = rng.random((40, 29)).astype(np.float32)
+    k = I.gaussian_kernel_21().astype(np.float64)
+    assert abs(k.sum() - 1.0) < 1e-6 and np.allclose(k, k[::-1]) and abs(k[10] / k[9] - np.exp(0.5 / 3.5 ** 2)) < 1e-6       # sigma = 3.5
+    ref = ndimage.correlate1d(ndimage.correlate1d(m.astype(np.float64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+    assert np.abs(I.gaussian_blur_21(m) - ref).max() <= 2e-6
+    # 3. distanceTransform(DIST_L2, 5): the cheapest path to a zero pixel with steps (1,0) = 1, (1,1) = 1.4, (2,1) = 2.1969 -- Dijkstra over that graph
+    #    (borders: paths may not leave the image) against the two-pass raster algorithm
+    src = (rng.random((19, 23)) > 0.08).astype(np.uint8)
+    src[7:12, 9:15] = 1
+    steps = [(dy, dx, c) for dy, dx, c in ((0, 1, I.HV), (1, 0, I.HV), (1, 1, I.DIAG), (1, 2, I.LONG), (2, 1, I.LONG))]
+    steps = [(sy * dy, sx * dx, c) for dy, dx, c in steps for sy in (1, -1) for sx in (1, -1)]
+    H, W = src.shape
+    dist = np.full((H, W), np.iinfo(np.int64).max, np.int64)
+    heap = [(0, y, x) for y in range(H) for x in range(W) if src[y, x] == 0]
+    for _, y, x in heap:
+        dist[y, x] = 0
+    heapq.heapify(heap)
+    while heap:
+        d, y, x = heapq.heappop(heap)
+        if d > dist[y, x]:
+            continue
+        for dy, dx, c in steps:
+            yy, xx = y + dy, x + dx
+            if 0 <= yy < H and 0 <= xx < W and d + c < dist[yy, xx]:
+                dist[yy, xx] = d + c
+                heapq.heappush(heap, (d + c, yy, xx))
+    got = I.distance_transform_l2_5(src)
+    want = (dist.astype(np.float64) / (1 << I.DIST_SHIFT)).astype(np.float32)
+    # the raster passes may route a knight step through the 2-pixel border of "infinity", the graph search may not: equal wherever the optimal path stays
+    # inside, and never smaller
+    assert (got >= want - 1e-6).all() and np.abs(got - want)[2:-2, 2:-2].max() <= 1e-6
+    # the metric approximates the Euclidean distance to within its published 2 % (a = 1, b = 1.4, c = 2.1969)
+    edt = ndimage.distance_transform_edt(src)
+    inner = (edt > 0)
+    assert (np.abs(got - edt)[inner] / edt[inner]).max() <= 0.045
