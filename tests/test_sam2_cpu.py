@@ -313,3 +313,35 @@ def test_trim_memory_keeps_the_forward_pass_identical():
         sizes[trim] = len(st["output_dict_per_obj"][0]["non_cond_frame_outputs"])
     assert len(outs[True]) == len(outs[False]) == 13 and all(torch.equal(a, b) for a, b in zip(outs[True], outs[False]))
     assert sizes[False] == 12 and sizes[True] <= 8
+
+
+def test_remove_object_leaves_the_other_objects_untouched():
+    """Sam2VideoPredictor.remove_object (upstream semantics): objects are tracked independently, so a clip prompted with three objects and then
+    relieved of the middle one tracks the remaining two exactly as a clip prompted with those two alone -- ids, order, logits bit for bit --
+    before AND after a tracking pass; unknown ids are ignored (or refused with strict=True); removing the last object resets the state."""
+    from oracle.sam2_ref import OracleSam2
+    rng = np.random.default_rng(9)
+    frames = [rng.integers(0, 256, (64, 64, 3), dtype=np.uint8) for _ in range(4)]
+    clicks = {7: [[12.0, 14.0]], 3: [[40.0, 22.0]], 5: [[30.0, 50.0]]}
+
+    def prompted(ids):
+        p = Sam2VideoPredictor(OracleSam2(TINY_SAM2, seed=6))
+        st = p.init_state(video_path=frames)
+        for oid in ids:
+            p.add_new_points_or_box(st, 0 if oid != 5 else 1, oid, points=np.array(clicks[oid], dtype=np.float32), labels=np.array([1], dtype=np.int32))
+        return p, st
+    p, st = prompted([7, 3, 5])
+    ids, updated = p.remove_object(st, 3)
+    assert ids == [7, 5] and list(st["obj_id_to_idx"].items()) == [(7, 0), (5, 1)] and [f for f, _ in updated] == [0]
+    assert tuple(updated[0][1].shape) == (2, 1, 64, 64)
+    assert p.remove_object(st, 42) == ([7, 5], [])
+    with pytest.raises(RuntimeError, match="Cannot remove object id 42"):
+        p.remove_object(st, 42, strict=True)
+    got = list(p.propagate_in_video(st))
+    q, st2 = prompted([7, 5])
+    want = list(q.propagate_in_video(st2))
+    assert [g[0] for g in got] == [w[0] for w in want] and all(g[1] == [7, 5] for g in got)
+    assert all(torch.equal(g[2], w[2]) for g, w in zip(got, want))
+    ids, updated = p.remove_object(st, 7, need_output=False)            # after tracking: the tracked frames of object 5 stay, renumbered to index 0
+    assert ids == [5] and updated == [] and sorted(st["frames_tracked_per_obj"][0]) == [0, 1, 2, 3] and list(st["output_dict_per_obj"]) == [0]
+    assert p.remove_object(st, 5) == ([], []) and st["obj_ids"] == [] and st["num_frames"] == 4
