@@ -401,8 +401,29 @@ class OracleSam2:
         n = 0 if point_inputs is None else point_inputs["point_labels"].shape[1]
         return self.cfg.multimask_min_pt_num <= n <= self.cfg.multimask_max_pt_num        # multimask_output_in_sam and ..._for_tracking are on
 
+    def use_mask_as_output(self, feats, mask_inputs):
+        """SAM2Base._use_mask_as_output (use_mask_input_as_output_without_sam: on in the 2.1 configurations): a caller-supplied binary mask
+        [1, 1, S, S] IS the frame's output -- logits -10 / +10 at the image size, antialiased bilinear to the low resolution -- and the SAM heads run only
+        for the object pointer, prompted with the learned 4x4 / stride-4 `mask_downsample` of the mask on the frame's RAW top-level features (no
+        memory conditioning); whether the object appears is read off the mask, not off the decoder's score."""
+        fs = self.cfg.feat_size
+        m = mask_inputs.float()
+        high = m * 20.0 - 10.0
+        low = F.interpolate(high, size=(4 * fs, 4 * fs), mode="bilinear", align_corners=False, antialias=True)
+        md = self.conv(m, "mask_downsample", stride=4)
+        _, ptr, _ = self.sam_heads(feats["fpn"][2], feats["fpn"][:2], None, md, False)
+        lam = (m.flatten(1) > 0).any(dim=1, keepdim=True).float()
+        ptr = lam * ptr + (1 - lam) * self.w("no_obj_ptr")
+        return low, ptr, 20.0 * lam - 10.0
+
     def track_step(self, frame_idx, is_init_cond_frame, feats, point_inputs, output_dict, num_frames, track_in_reverse=False,
-                   run_mem_encoder=True, prev_sam_mask_logits=None):
+                   run_mem_encoder=True, prev_sam_mask_logits=None, mask_inputs=None):
+        if mask_inputs is not None:
+            masks, ptr, obj = self.use_mask_as_output(feats, mask_inputs)
+            out = {"pred_masks": masks, "obj_ptr": ptr, "object_score_logits": obj, "maskmem_features": None, "maskmem_pos_enc": None}
+            if run_mem_encoder:
+                out["maskmem_features"], out["maskmem_pos_enc"] = self.encode_memory_from_low_res(feats, masks, obj, True)
+            return out
         pix = self._memory_conditioned(frame_idx, is_init_cond_frame, feats, output_dict, num_frames, track_in_reverse)
         masks, ptr, obj = self.sam_heads(pix, feats["fpn"][:2], point_inputs, prev_sam_mask_logits,
                                          self.use_multimask(is_init_cond_frame, point_inputs))

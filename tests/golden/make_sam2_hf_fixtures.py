@@ -189,6 +189,22 @@ def main():
                         f"sam_{k}_ptr": r.object_pointer.numpy(), f"sam_{k}_obj": r.object_score_logits.numpy(), f"sam_{k}_iou": r.iou_scores.numpy()})
             if mask is not None:
                 out[f"sam_{k}_mask_in"] = mask
+        # ---- 2b. a caller-supplied MASK as the frame's output (SAM2Base._use_mask_as_output): logits -10 / +10, antialiased low-resolution copy, the
+        #          object pointer from the SAM heads prompted with mask_downsample(mask) on the RAW top-level features; an empty mask: "no object"
+        yy, xx = np.mgrid[0:S, 0:S]
+        blob = (((yy - 0.42 * S) ** 2 / (0.20 * S) ** 2 + (xx - 0.55 * S) ** 2 / (0.31 * S) ** 2) <= 1.0).astype(np.float32)
+        blob[int(0.40 * S):int(0.46 * S), int(0.50 * S):int(0.58 * S)] = 0.0                    # a hole
+        for tag, mk in (("blob", blob), ("empty", np.zeros((S, S), np.float32))):
+            mt = torch.tensor(mk)[None, None]
+            r = hf._use_mask_as_output(backbone_features=fpn[2], high_res_features=[fpn[0], fpn[1]], mask_inputs=mt)
+            # the pointer: transformers calls its SAM heads here with their default multimask_output=True (the best-IoU token); the `sam2` package the
+            # reference imports calls _forward_sam_heads with ITS default multimask_output=False (the single-mask token).  The vectors follow the
+            # package: the same transformers heads with the flag spelled out, then the published mixing rule of _use_mask_as_output.
+            p1 = hf._single_frame_forward(input_masks=hf.mask_downsample(mt), image_embeddings=[fpn[0], fpn[1], fpn[2]], multimask_output=False).object_pointer
+            lam = float(mk.max() > 0)
+            ptr = lam * p1 + (1.0 - lam) * hf.no_object_pointer
+            out.update({f"mask_{tag}_in": mk, f"mask_{tag}_low": r.pred_masks.numpy(), f"mask_{tag}_ptr": ptr.numpy(),
+                        f"mask_{tag}_ptr_transformers_default": r.object_pointer.numpy(), f"mask_{tag}_obj": r.object_score_logits.numpy()})
         # ---- 3. memory encoder, fp32 (the HF wrapper `_encode_new_memory` then rounds the features to bfloat16: stored too, looser check)
         low = torch.tensor(out["sam_click_masks"]).reshape(1, 1, 4 * fs, 4 * fs)
         high = torch.nn.functional.interpolate(low, size=(S, S), mode="bilinear", align_corners=False)

@@ -258,7 +258,8 @@ def _close(got, want, tol=2e-5, what=""):
 def test_oracle_matches_transformers_sam2_vectors():
     """oracle/sam2_ref.py == transformers' Sam2VideoModel on the same weights and inputs, stage by stage, fp32 (<= 2e-5 of the output range):
     Hiera trunk + FPN neck + conv_s0/s1, prompt encoder + two-way mask decoder (click / box + negative click / click + mask prompt; the
-    multimask choice and the stability rule included), memory encoder (binarised and sigmoid masks, occluded object), and a tracked frame
+    multimask choice and the stability rule included), a caller-supplied mask used as the output (mask_downsample, antialiased resize, pointer
+    mixing; an empty mask), memory encoder (binarised and sigmoid masks, occluded object), and a tracked frame
     (memory selection, temporal encodings, object-pointer tokens, RoPE memory attention)."""
     from oracle.sam2_ref import OracleSam2
     v = np.load(os.path.join(GOLD, "sam2_hf_vectors.npz"))
@@ -279,6 +280,11 @@ def test_oracle_matches_transformers_sam2_vectors():
             errs[f"sam_{k}_masks"] = _close(masks.reshape(-1), v[f"sam_{k}_masks"].reshape(-1), what=f"{k} masks")
             errs[f"sam_{k}_ptr"] = _close(ptr.reshape(-1), v[f"sam_{k}_ptr"].reshape(-1), what=f"{k} pointer")
             errs[f"sam_{k}_obj"] = _close(obj.reshape(-1), v[f"sam_{k}_obj"].reshape(-1), what=f"{k} object score")
+        for tag in ("blob", "empty"):                      # a caller-supplied mask as the frame's output (SAM2Base._use_mask_as_output)
+            lo_m, ptr, obj = O.use_mask_as_output(feats, torch.tensor(v[f"mask_{tag}_in"])[None, None])
+            errs[f"mask_{tag}_low"] = _close(lo_m.reshape(-1), v[f"mask_{tag}_low"].reshape(-1), what=f"mask prompt ({tag}): low-resolution logits")
+            errs[f"mask_{tag}_ptr"] = _close(ptr.reshape(-1), v[f"mask_{tag}_ptr"].reshape(-1), what=f"mask prompt ({tag}): object pointer")
+            assert float(obj) == float(v[f"mask_{tag}_obj"].reshape(-1)[0]) == (10.0 if tag == "blob" else -10.0)
         low = torch.tensor(v["mem_low_res_in"])
         for tag, from_pts in (("pts", True), ("trk", False)):
             obj = torch.tensor(v[f"mem_{tag}_obj"])
@@ -345,3 +351,40 @@ def test_remove_object_leaves_the_other_objects_untouched():
     ids, updated = p.remove_object(st, 7, need_output=False)            # after tracking: the tracked frames of object 5 stay, renumbered to index 0
     assert ids == [5] and updated == [] and sorted(st["frames_tracked_per_obj"][0]) == [0, 1, 2, 3] and list(st["output_dict_per_obj"]) == [0]
     assert p.remove_object(st, 5) == ([], []) and st["obj_ids"] == [] and st["num_frames"] == 4
+
+
+def test_add_new_mask_on_the_oracle():
+    """Sam2VideoPredictor.add_new_mask (upstream semantics; use_mask_input_as_output_without_sam): the prompted frame's output IS the mask (video-resolution
+    logits > 0 exactly on the mask, up to the resize), any mask size is accepted, tracking starts from it and carries the object forward, a later click on
+    the same frame replaces the mask prompt (and vice versa), an empty mask means "the object is not here"."""
+    from oracle.sam2_ref import OracleSam2
+    rng = np.random.default_rng(13)
+    frames = [rng.integers(0, 256, (64, 64, 3), dtype=np.uint8) for _ in range(4)]
+    p = Sam2VideoPredictor(OracleSam2(TINY_SAM2, seed=8))
+    st = p.init_state(video_path=frames)
+    mask = np.zeros((64, 64), bool)
+    mask[18:44, 22:50] = True
+    f, ids, logits = p.add_new_mask(st, 0, 5, mask)
+    assert (f, ids) == (0, [5]) and tuple(logits.shape) == (1, 1, 64, 64)
+    got = logits[0, 0].numpy() > 0
+    assert (got != mask).mean() <= 0.02 and got[24:38, 28:44].all() and not got[:12].any()          # the mask itself, up to the two resizes
+    out = st["temp_output_dict_per_obj"][0]["cond_frame_outputs"][0]
+    assert float(out["object_score_logits"]) == 10.0 and out["maskmem_features"] is None and 0 in st["mask_inputs_per_obj"][0]
+    big = np.kron(mask, np.ones((3, 3), bool))                                                     # 192 x 192: another size, same object
+    _, _, logits_big = p.add_new_mask(st, 0, 5, big)
+    assert ((logits_big[0, 0].numpy() > 0) != mask).mean() <= 0.03
+    tracked = list(p.propagate_in_video(st))
+    assert [t[0] for t in tracked] == [0, 1, 2, 3] and torch.equal(tracked[0][2], logits_big)
+    assert st["output_dict_per_obj"][0]["cond_frame_outputs"][0]["maskmem_features"] is not None      # the preflight encoded the mask's memory
+    # a click on the same frame replaces the mask prompt, a mask replaces the click
+    p.add_new_points_or_box(st, 0, 5, points=np.array([[30.0, 30.0]], dtype=np.float32), labels=np.array([1], dtype=np.int32))
+    assert 0 not in st["mask_inputs_per_obj"][0] and 0 in st["point_inputs_per_obj"][0]
+    p.add_new_mask(st, 0, 5, mask)
+    assert 0 in st["mask_inputs_per_obj"][0] and 0 not in st["point_inputs_per_obj"][0]
+    # an empty mask: the object does not appear on this frame
+    q = Sam2VideoPredictor(OracleSam2(TINY_SAM2, seed=8))
+    st2 = q.init_state(video_path=frames)
+    _, _, none = q.add_new_mask(st2, 1, 9, np.zeros((64, 64), np.uint8))
+    assert float(st2["temp_output_dict_per_obj"][0]["cond_frame_outputs"][1]["object_score_logits"]) == -10.0 and not (none > 0).any()
+    with pytest.raises(ValueError, match="2-D"):
+        q.add_new_mask(st2, 1, 9, np.zeros((4, 4, 3)))

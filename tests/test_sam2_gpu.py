@@ -480,3 +480,39 @@ def test_bf16_operands():
                  nhwc(ora.encode_memory_from_low_res(fo, o["pred_masks"], torch.tensor([[1.0]]), True)[0]))
     print(f"sam2_bf16[tiny]: image encoder rel {e:.2e}, prompted logits rel {e_m:.2e}, memory encoder rel {e_mem:.2e}")
     assert e < 1.6e-2 and e_m < 5e-2 and e_mem < 1.6e-2
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_mask_prompt_as_output_and_tracking(name):
+    """A caller-supplied mask as the prompt (Sam2VideoPredictor.add_new_mask -> HipSam2.use_mask_as_output; oracle pinned against transformers in
+    tests/test_sam2_cpu.py): the frame's logits are the host-prepared prompt (equal to the oracle's), the object pointer comes off the device SAM heads
+    prompted with mask_downsample(mask) (same tolerance as the other pointers), an empty mask gives the no-object pointer, and tracking from a mask prompt
+    through the predictor follows the oracle like tracking from clicks does."""
+    from videovanish_amd.sam2_config import SMALL_SAM2, TINY_SAM2
+    from videovanish_amd.sam2_predictor import Sam2VideoPredictor
+    cfg = {"tiny": TINY_SAM2, "small": SMALL_SAM2}[name]
+    ora, hipm = _models(cfg, seed=11)
+    S = cfg.image_size
+    frames = _frames(4, S, S)
+    yy, xx = np.mgrid[0:S, 0:S]
+    mask = ((yy - 0.45 * S) ** 2 / (0.22 * S) ** 2 + (xx - 0.5 * S) ** 2 / (0.3 * S) ** 2) <= 1.0
+    m = torch.tensor(mask.astype(np.float32))[None, None]
+    fo, fh = ora.encode_image(frames[0]), hipm.encode_image(frames[0])
+    lo_o, p_o, s_o = ora.use_mask_as_output(fo, m)
+    lo_h, p_h, s_h = hipm.use_mask_as_output(fh, m)
+    e_l, e_p = _rel(lo_h, lo_o.reshape(-1)), _rel(p_h, p_o)
+    print(f"sam2_mask_as_output[{name}]: low-resolution logits rel {e_l:.1e}, obj_ptr rel {e_p:.2e}, object score {float(s_o)} / {float(s_h.cpu())}")
+    assert e_l <= 1e-6 and e_p < 3.4e-3 and float(s_o) == float(s_h.cpu()) == 10.0
+    _, p_e, s_e = hipm.use_mask_as_output(fh, torch.zeros_like(m))
+    assert float(s_e.cpu()) == -10.0 and torch.equal(p_e.cpu(), hipm.no_obj_ptr.cpu())
+    outs = []
+    for model in (ora, hipm):
+        p = Sam2VideoPredictor(model)
+        st = p.init_state(video_path=frames)
+        first = p.add_new_mask(st, 0, 1, mask)
+        outs.append([first[2]] + [t[2] for t in p.propagate_in_video(st)])
+    (first_o, *trk_o), (first_h, *trk_h) = outs
+    assert torch.equal(first_o > 0, first_h > 0) and _rel(first_h, first_o) <= 1e-5            # the prompted frame: the mask itself on both paths
+    flips = [float(((a > 0) != (b > 0)).float().mean()) for a, b in zip(trk_o, trk_h)]
+    print(f"sam2_mask_prompt_tracking[{name}]: sign flips per frame {[round(f, 4) for f in flips]}")
+    assert len(trk_h) == 4 and torch.equal(trk_h[0], first_h) and max(flips) < 6e-3

@@ -221,6 +221,7 @@ class HipSam2:
         self.no_obj_embed_spatial = dev(W("no_obj_embed_spatial").reshape(Mm))
         self.no_mem_embed = dev(W("no_mem_embed").reshape(1, D).expand(fs * fs, D))
         self.no_obj_ptr = dev(W("no_obj_ptr").reshape(1, D))
+        self.mask_downsample_w, self.mask_downsample_b = W("mask_downsample.weight").float().cpu(), W("mask_downsample.bias").float().cpu()      # host: prompt preparation
         self.obj_ptr_proj = [_Lin(ctx, W(f"obj_ptr_proj.layers.{j}.weight"), W(f"obj_ptr_proj.layers.{j}.bias")) for j in range(3)]
         self.tpos_proj = _Lin(ctx, W("obj_ptr_tpos_proj.weight"), W("obj_ptr_tpos_proj.bias"))
         # ---- prompt encoder
@@ -519,8 +520,31 @@ class HipSam2:
         n = 0 if point_inputs is None else point_inputs["point_labels"].shape[1]
         return self.cfg.multimask_min_pt_num <= n <= self.cfg.multimask_max_pt_num
 
+    def use_mask_as_output(self, feats, mask_inputs):
+        """SAM2Base._use_mask_as_output (oracle/sam2_ref.py::use_mask_as_output): a caller-supplied binary mask [1, 1, S, S] (host tensor: it is a PROMPT) is
+        the frame's output.  Prompt preparation stays on the host like the click coordinates do -- logits -10 / +10, their antialiased low-resolution copy,
+        the learned 4x4 / stride-4 `mask_downsample` of the mask (17 parameters) --; the SAM heads then run on the device for the object pointer, on the frame's
+        RAW top-level features, with that downsampled mask as their mask prompt; "does the object appear" is read off the mask."""
+        cfg = self.cfg
+        lo = 4 * cfg.feat_size
+        m = mask_inputs.detach().float().cpu()
+        low = torch.nn.functional.interpolate(m * 20.0 - 10.0, size=(lo, lo), mode="bilinear", align_corners=False, antialias=True)
+        md = torch.nn.functional.conv2d(m, self.mask_downsample_w, self.mask_downsample_b, stride=4)
+        appears = bool((m > 0).any())
+        _, ptr, _ = self._sam_heads(feats["top"], feats, None, md.reshape(-1).contiguous().to(self.device), False)
+        if not appears:
+            ptr = self.no_obj_ptr.clone()
+        obj = torch.tensor([10.0 if appears else -10.0], dtype=torch.float32, device=self.device)
+        return low.reshape(-1).contiguous().to(self.device), ptr, obj
+
     def track_step(self, frame_idx, is_init_cond_frame, feats, point_inputs, output_dict, num_frames, track_in_reverse=False,
-                   run_mem_encoder=True, prev_sam_mask_logits=None):
+                   run_mem_encoder=True, prev_sam_mask_logits=None, mask_inputs=None):
+        if mask_inputs is not None:
+            masks, ptr, obj = self.use_mask_as_output(feats, mask_inputs)
+            out = {"pred_masks": masks, "obj_ptr": ptr, "object_score_logits": obj, "maskmem_features": None, "maskmem_pos_enc": None}
+            if run_mem_encoder:
+                out["maskmem_features"], out["maskmem_pos_enc"] = self.encode_memory_from_low_res(feats, masks, obj, True)
+            return out
         pix = self._memory_conditioned(frame_idx, is_init_cond_frame, feats, output_dict, num_frames, track_in_reverse)
         masks, ptr, obj = self._sam_heads(pix, feats, point_inputs, prev_sam_mask_logits, self.use_multimask(is_init_cond_frame, point_inputs))
         out = {"pred_masks": masks, "obj_ptr": ptr, "object_score_logits": obj, "maskmem_features": None, "maskmem_pos_enc": None}
