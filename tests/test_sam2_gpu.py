@@ -502,7 +502,7 @@ def test_mask_prompt_as_output_and_tracking(name):
     lo_h, p_h, s_h = hipm.use_mask_as_output(fh, m)
     e_l, e_p = _rel(lo_h, lo_o.reshape(-1)), _rel(p_h, p_o)
     print(f"sam2_mask_as_output[{name}]: low-resolution logits rel {e_l:.1e}, obj_ptr rel {e_p:.2e}, object score {float(s_o)} / {float(s_h.cpu())}")
-    assert e_l <= 1e-6 and e_p < 3.4e-3 and float(s_o) == float(s_h.cpu()) == 10.0
+    assert e_l <= 1e-6 and e_p < 2.8e-3 and float(s_o) == float(s_h.cpu()) == 10.0          # <= 2x the measured 1.39e-3 (tiny) / 5.8e-4 (small)
     _, p_e, s_e = hipm.use_mask_as_output(fh, torch.zeros_like(m))
     assert float(s_e.cpu()) == -10.0 and torch.equal(p_e.cpu(), hipm.no_obj_ptr.cpu())
     outs = []
@@ -515,4 +515,4 @@ def test_mask_prompt_as_output_and_tracking(name):
     assert torch.equal(first_o > 0, first_h > 0) and _rel(first_h, first_o) <= 1e-5            # the prompted frame: the mask itself on both paths
     flips = [float(((a > 0) != (b > 0)).float().mean()) for a, b in zip(trk_o, trk_h)]
     print(f"sam2_mask_prompt_tracking[{name}]: sign flips per frame {[round(f, 4) for f in flips]}")
-    assert len(trk_h) == 4 and torch.equal(trk_h[0], first_h) and max(flips) < 6e-3
+    assert len(trk_h) == 4 and torch.equal(trk_h[0], first_h) and max(flips) < 2.2e-3       # <= 2x the measured 1.1e-3
