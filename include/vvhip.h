@@ -18,6 +18,14 @@
  *   - activations are frames-major NHWC: [F][H][W][C] == a row-major [M = F*H*W][C] matrix;
  *   - "h16" = the 16-bit MFMA operand type selected by `dtype` (VV_BF16 or VV_F16); accumulation, norm
  *     statistics, softmax and the residual trunk are fp32.
+ *
+ * Deliberate deviation from the sketch in SURVEY.md section 8(b): the ABI is STATELESS.  There is no
+ * vv_init / vv_destroy / vv_ctx -- nothing here owns a device, a stream, a workspace or a communicator, so
+ * there is nothing a context would hold: the caller passes the stream and every workspace per call, and the
+ * error string is thread-local (vv_last_error).  There is no vv_exchange_overlap either: the overlap exchange
+ * at blend time is the host's torch.distributed point-to-point (backend "nccl" = RCCL over xGMI;
+ * videovanish_amd/pipeline.py), the only place the path communicates, and it moves whole decoded frames
+ * that no kernel of this library needs to see in flight.
  */
 #ifndef VVHIP_H
 #define VVHIP_H

@@ -84,8 +84,20 @@ def run_sam2_on_frames(frames_rgb, annotations, device=None, prog=None):
         predictor = build_sam2_video_predictor(SAM2_MODEL_CFG, os.environ.get("VV_SAM2_CHECKPOINT", SAM2_CHECKPOINT), device=device)
 
     if prog is not None: prog(25, "Loading frames in to sam2")
-    if hasattr(predictor, "trim_memory"):
-        predictor.trim_memory = True            # one forward pass after the prompts: outputs no later frame can select are freed as tracking advances
+    # one forward pass after the prompts: outputs no later frame can select are freed as tracking advances.  The flag is restored afterwards --
+    # a predictor the caller handed in through configure(predictor=...) must behave like upstream when it is reused
+    had_trim = hasattr(predictor, "trim_memory")
+    old_trim = getattr(predictor, "trim_memory", None)
+    if had_trim:
+        predictor.trim_memory = True
+    try:
+        return _run(predictor, frames_rgb, annotations, W0, H0, prog)
+    finally:
+        if had_trim:
+            predictor.trim_memory = old_trim
+
+
+def _run(predictor, frames_rgb, annotations, W0, H0, prog):
     inference_state = predictor.init_state(video_path=frames_rgb)
 
     # prompts in the order the reference issues them (reference :96-141): per keyframe (sorted by frame), the clicks of each object in one

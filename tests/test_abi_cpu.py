@@ -36,6 +36,24 @@ def test_binding_lists_match_header(lib):
     assert lib.vv_abi_version() == hip.ABI_VERSION == 9
 
 
+def test_integration_md_binding_snippet_version_check(lib):
+    """The reference-side ctypes snippet of INTEGRATION.md section 2 is executed up to (and including) its ABI assert, against the library as built:
+    a stale version number in the document fails here."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = next(b for b in re.findall(r"```python\n(.*?)```", md, flags=re.S) if "vv_abi_version" in b)
+    head = block.split("def dilate_masks")[0]
+    assert "ctypes.CDLL" in head and "assert lib.vv_abi_version() ==" in head
+    cwd = os.getcwd()
+    os.chdir(ROOT)      # the snippet loads the library by its path relative to the app directory
+    try:
+        exec(compile(head, "INTEGRATION.md", "exec"), {})
+    finally:
+        os.chdir(cwd)
+    hdr = open(os.path.join(ROOT, "include", "vvhip.h")).read()
+    ver = re.search(r"#define VV_ABI_VERSION (\d+)", hdr).group(1)
+    assert "vv_abi_version() == " + ver in head
+
+
 def test_vvio_header_symbols_are_exported():
     """include/vvio.h (frame codec, libvvio.so): every declared entry point is exported and the ABI versions agree."""
     src = open(os.path.join(ROOT, "include", "vvio.h")).read()

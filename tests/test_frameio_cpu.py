@@ -380,6 +380,34 @@ def test_ffv1_non_key_frames_continue_from_the_previous_frame(coder):
     assert all(np.array_equal(dec.decode(p), w) for p, w in zip(pkts, want))
 
 
+def test_mkv_seek_decodes_from_the_last_key_frame_only(tmp_path, monkeypatch):
+    """read_mkv(start_frame): packets before start_frame are decoded only from the last key frame at or before it -- an intra-only
+    stream (this module's writer) decodes exactly the frames it returns, a key / non / non / key / non stream decodes from the key frame of the
+    first wanted frame's GOP; the key-frame bit read from the packet agrees with the encoder's flag."""
+    from tests import ffv1_pyenc as PY
+    H, W, T = 12, 18, 6
+    frames = _clip_rgb(T, H, W, 77)
+    calls = []
+    real = FIO.Ffv1Decoder.decode
+    monkeypatch.setattr(FIO.Ffv1Decoder, "decode", lambda self, pkt: (calls.append(len(pkt)), real(self, pkt))[1])
+    intra = str(tmp_path / "intra.mkv")
+    FIO.write_video_frames_to_path(intra, frames, 25.0, H, W)
+    part, _ = FIO.load_video_frames_from_path(intra, start_frame=4, max_frames=2)
+    assert len(part) == 2 and np.array_equal(part[0], frames[4]) and np.array_equal(part[1], frames[5]) and len(calls) == 2
+    keys = [True, False, False, True, False, False]
+    st = {}
+    pkts = [PY.encode_frame(f, 1, 1, 1, keyframe=k, persist=st) for f, k in zip(frames, keys)]
+    assert [FIO._ffv1_is_key_packet(p) for p in pkts] == keys
+    gop = str(tmp_path / "gop.mkv")
+    FIO.write_mkv_packets(gop, W, H, PY.config_record(1, 1, 1, intra=0), pkts, 25.0, key_frames=keys)
+    for start, n_dec in ((0, 2), (2, 4), (3, 2), (4, 3), (5, 3)):
+        del calls[:]
+        part, _ = FIO.load_video_frames_from_path(gop, start_frame=start, max_frames=2)
+        want = frames[start:start + 2]
+        assert len(part) == len(want) and all(np.array_equal(a, b) for a, b in zip(part, want)), start
+        assert len(calls) == n_dec, (start, len(calls))
+
+
 @pytest.mark.parametrize("version", [0, 1])
 @pytest.mark.parametrize("coder", [0, 1, 2])
 def test_ffv1_version_0_and_1_streams(version, coder, tmp_path):

@@ -58,6 +58,10 @@ def test_conv_gemm(gpu, dname, td, ulp, case, monkeypatch):
     wp, K = packing.pack_conv(w, td)
     xin = _nhwc(x).to(gpu) if f32in else _nhwc(x).to(td).to(gpu)
     if case.get("halo256"):
+        # the 256-pixel halo kernel (vv_conv3.hip) exists only in the lab build (VV_AB=1 build.sh); in the product library these cases would
+        # silently repeat the generic path
+        if not hasattr(hip.lib(), "vv_conv3_halo_try"):
+            pytest.skip("lab build only: vv_conv3.hip is not part of the product library")
         monkeypatch.setenv("VV_CONV3_HALO256", "1")
     out = hip.conv_gemm(dt, xin, wp.to(gpu), cout, K, F=Fr, Hin=H, Win=W, Hout=Ho, Wout=Wo, ksize=k, stride=stride, pad_t=k // 2,
                         pad_l=k // 2, bias=b.to(gpu), out_dtype=torch.float32)

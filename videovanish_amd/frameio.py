@@ -344,6 +344,7 @@ def read_mkv(path, start_frame=0, max_frames=-1):
     fps = 0.0
     want = None
     idx = 0
+    pending = []                # FFV1 packets since the last key frame before start_frame
     for eid, a, b in _children(buf, 0, len(buf)):
         if eid != ID_SEGMENT:
             continue
@@ -382,12 +383,23 @@ def read_mkv(path, start_frame=0, max_frames=-1):
                     if num != want["num"]:
                         continue
                     payload = bytes(buf[p + 3: blk[1]])
-                    # FFV1 streams may hold non-key frames (adaptive states continue from the previous frame): every packet up to the last wanted
-                    # one is decoded in order, the ones before start_frame are dropped
+                    # FFV1 streams may hold non-key frames (adaptive states continue from the previous frame), so decoding has to start at a key
+                    # frame -- but only at the LAST one at or before start_frame: the packets before start_frame are buffered since the latest key
+                    # frame (one GOP at most) and decoded only if the first wanted frame is not a key frame itself.  An intra-only stream (what
+                    # this module's writer and `-g 1` encoders produce) therefore costs no decode per skipped frame (O(start_frame)
+                    # decodes per call, O(N^2) for a clip read in windows).
                     if max_frames <= 0 or len(frames) < max_frames:
-                        fr = _decode_payload(want, payload, keep=idx >= start_frame)
-                        if idx >= start_frame:
-                            frames.append(fr)
+                        if idx < start_frame:
+                            if _is_ffv1(want):
+                                if _ffv1_is_key_packet(payload):
+                                    pending = []
+                                pending.append(payload)
+                        else:
+                            if pending and not _ffv1_is_key_packet(payload):
+                                for q in pending:
+                                    _decode_payload(want, q, keep=False)
+                            pending = []
+                            frames.append(_decode_payload(want, payload, keep=True))
                     idx += 1
                     if max_frames > 0 and len(frames) >= max_frames:
                         break
@@ -396,6 +408,20 @@ def read_mkv(path, start_frame=0, max_frames=-1):
     if want.get("dur"):
         fps = 1e9 / want["dur"]
     return frames, fps
+
+
+def _is_ffv1(tr):
+    codec = tr.get("codec", "")
+    return codec == "V_FFV1" or (codec == "V_MS/VFW/FOURCC" and tr.get("private", b"")[16:20] == b"FFV1")
+
+
+def _ffv1_is_key_packet(payload):
+    """The first symbol of every FFV1 frame (all versions, either sample coder) is the range-coded `keyframe` bit with the fixed initial state 128
+    (RFC 9043 section 4.4; 3.8.1.1: low = the first two bytes capped at 0xFF00, range = 0xFF00): range1 = 0xFF00 * 128 >> 8 = 0x7F80 and
+    the bit is 1 exactly when low >= range - range1 = 0x7F80."""
+    if len(payload) < 2:
+        return True
+    return min((payload[0] << 8) | payload[1], 0xFF00) >= 0x7F80
 
 
 def _ffv1_track_decoder(tr, config):

@@ -543,7 +543,9 @@ class HipSam2:
             masks, ptr, obj = self.use_mask_as_output(feats, mask_inputs)
             out = {"pred_masks": masks, "obj_ptr": ptr, "object_score_logits": obj, "maskmem_features": None, "maskmem_pos_enc": None}
             if run_mem_encoder:
-                out["maskmem_features"], out["maskmem_pos_enc"] = self.encode_memory_from_low_res(feats, masks, obj, True)
+                # upstream SAM2Base._encode_memory_in_output: is_mask_from_pts = (point_inputs is not None) -- False for a mask prompt: the
+                # memory encoder sees sigmoid(logits), not the binarised mask
+                out["maskmem_features"], out["maskmem_pos_enc"] = self.encode_memory_from_low_res(feats, masks, obj, point_inputs is not None)
             return out
         pix = self._memory_conditioned(frame_idx, is_init_cond_frame, feats, output_dict, num_frames, track_in_reverse)
         masks, ptr, obj = self._sam_heads(pix, feats, point_inputs, prev_sam_mask_logits, self.use_multimask(is_init_cond_frame, point_inputs))

@@ -94,7 +94,7 @@ class _Backbone:
     def temb(self, t, key=None):
         """SiLU(time embedding) of timestep t -- or, after prepare_temb(), the table {id(ResBlock): conv1 bias + time_emb_proj row} of t.
         key: the stream the tables were prepared on (default: the current one; the two-stream schedule passes its main stream)."""
-        hit = self.__dict__.get("_temb_tables", {}).get((torch.cuda.current_stream().cuda_stream if key is None else key, int(t)))
+        hit = self.__dict__.get("_temb_tables", {}).get(torch.cuda.current_stream().cuda_stream if key is None else key, {}).get(int(t))
         if hit is not None:
             return hit
         e = self.ctx.dev(timestep_embedding(t, self.cfg.block_out[0]))
@@ -110,19 +110,19 @@ class _Backbone:
         time_emb_proj of every ResBlock run ONCE for all S timesteps of the schedule as GEMMs with S rows (instead of ~27 one-row launches of
         ~50 us latency each per backbone and step: 0.7 % of a step).  Row s of an S-row GEMM is computed exactly like the one-row launch
         (same tile kernel, same k order), so the values are bit-identical.  Tables are kept per launch stream (chunks of one rank may run
-        on several streams: a table is produced and consumed on the same stream, or on its side stream behind a wait)."""
+        on several streams: a table is produced and consumed on the same stream, or on its side stream behind a wait).
+        The chunk lanes are host threads that share this object: one dict PER STREAM KEY, built aside and published by a single
+        item assignment, so no lane ever iterates or resizes a dict another lane is reading."""
         ts = [int(t) for t in ts]
         key = torch.cuda.current_stream().cuda_stream
         tables = self.__dict__.setdefault("_temb_tables", {})
-        if all((key, t) in tables for t in ts):
+        mine = tables.get(key)
+        if mine is not None and all(t in mine for t in ts):
             return
-        for k in [k for k in tables if k[0] == key]:
-            del tables[k]                           # another schedule on this stream: drop the old rows
         e = self.ctx.dev(torch.cat([timestep_embedding(t, self.cfg.block_out[0]) for t in ts], 0))
         st = hip.silu(self.t2(hip.silu(self.t1(e))))
         rows = {id(r): r.temb_bias(st) for r in self.resblocks()}
-        for i, t in enumerate(ts):
-            tables[(key, t)] = {rid: b[i] for rid, b in rows.items()}
+        tables[key] = {t: {rid: b[i] for rid, b in rows.items()} for i, t in enumerate(ts)}      # another schedule on this stream: the old rows go
 
     def run_down(self, x_in, F, h, w, st):
         """x_in: h16 [F*h*w, in_pad].  Returns (x, skips=[(tensor,H,W)...], (H,W))."""
