@@ -30,6 +30,9 @@ __device__ __forceinline__ void glds16_asm(const void* gptr, void* lds_wave_base
 
 // two GELUs at once on packed fp32 math (exact erf GELU through Abramowitz-Stegun 7.1.26; see vv_motion.hip)
 __device__ __forceinline__ vv_f32x2 gelu2(vv_f32x2 x) {
+#ifdef VV_CHAIN_PROBE_NOGELU      // timing probe only (wrong results): what the activation's VALU work costs
+    return x;
+#endif
     const vv_f32x2 ax = {fabsf(x.x), fabsf(x.y)};
     const vv_f32x2 z = ax * 0.70710678118654752f;
     const vv_f32x2 d = __builtin_elementwise_fma(z, (vv_f32x2){0.3275911f, 0.3275911f}, (vv_f32x2){1.0f, 1.0f});
@@ -45,25 +48,44 @@ __device__ __forceinline__ vv_f32x2 gelu2(vv_f32x2 x) {
     return __builtin_elementwise_fma(ax * 0.5f, (vv_f32x2){1.0f, 1.0f} - erfc, x * 0.5f);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_params p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char ring[NSLOT * SLAB];
+// TT = token tiles (of 16) per wave.  TT = 2: the round-3 form, 4 waves x 32 tokens, one wave per SIMD with the whole 512-entry register file
+// (trunk in AGPRs: every VALU touch of it pays v_accvgpr_read / write, and nothing runs on the SIMD while the wave's GELU / LayerNorm / softmax do).
+// TT = 1 (round 5, default): 8 waves x 16 tokens, two waves per SIMD at <= 256 registers each (all architectural: no AGPR copies); waves 4..7 --
+// the SIMD partners of 0..3 -- run LAG slab PAIRS behind the others through the same ring, so one partner's VALU phase (GELU of an FF chunk, a
+// LayerNorm, the cross-attention softmax) falls under the other's MFMAs instead of both stalling the matrix pipe together (the waves of a block
+// meet at one barrier per slab pair: without the lag the two partners run in lockstep).  Ring: NS slots; a slot is re-filled AHEAD slabs ahead of the
+// leaders, and the laggards may still have fragment reads of pair b - LAG - 1 in flight when pair b is being synchronised: NS >= AHEAD + 4 + 2 LAG.
+template <typename T, int TT, int LAG, int AH>
+__global__ __launch_bounds__(128 / (16 * TT) * 64, TT == 2 ? 1 : 2) void chain_c320_kernel(const vv_chain_params p) {
+    constexpr int NW = 128 / (16 * TT), NS = AH + 4 + 2 * LAG, NPIECE = 8 / NW;       // waves, ring slots, 1 KB LDS-DMA pieces per wave and slab
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[NS * SLAB];
     __shared__ __attribute__((aligned(16))) float prm[Q_TOTAL];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * (16 * TT);
 
-    for (int i = tid * 4; i < Q_TOTAL; i += 256 * 4) *(float4*)(prm + i) = *(const float4*)(p.params + i);
-    // ---- weight stream: slab s at p.stream + s * SLAB; each wave copies 2 KB of every slab
-    const unsigned char* sbase = (const unsigned char*)p.stream + (wave * 2) * 1024 + lane * 16;
+    for (int i = tid * 4; i < Q_TOTAL; i += NW * 64 * 4) *(float4*)(prm + i) = *(const float4*)(p.params + i);
+    // ---- weight stream: slab s at p.stream + s * SLAB; each wave copies 8 / NW KB of every slab
+    const unsigned char* sbase = (const unsigned char*)p.stream + (wave * NPIECE) * 1024 + lane * 16;
     int issued = 0, consumed = 0;
     auto issue = [&]() {
-        unsigned char* dst = ring + (issued % NSLOT) * SLAB + (wave * 2) * 1024;
+        unsigned char* dst = ring + (issued % NS) * SLAB + (wave * NPIECE) * 1024;
         const unsigned char* src = sbase + (int64_t)issued * SLAB;
+#ifndef VV_PROBE_NODMA
         glds16_asm(src, dst);
-        glds16_asm(src + 1024, dst + 1024);
+        if constexpr (NPIECE == 2) glds16_asm(src + 1024, dst + 1024);
+#else
+        asm volatile("" :: "v"(src), "v"(dst));
+#endif
         ++issued;
+    };
+    auto wait_landed = [&]() {      // all but the newest AHEAD slabs of this wave's share have landed
+        static_assert(AH * NPIECE == 6 || AH * NPIECE == 8 || AH * NPIECE == 10 || AH * NPIECE == 12, "vmcnt literal");
+        if constexpr (AH * NPIECE == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if constexpr (AH * NPIECE == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if constexpr (AH * NPIECE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     };
     // next slab of the stream.  Slabs are synchronised in PAIRS (vv_motion.hip): the EVEN slab of a pair issues two more slabs, waits until all but
     // the newest AHEAD have landed (this wave's share) and joins the barrier; the odd one just advances.  The parity of every slab's stream index is
@@ -72,22 +94,24 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
     // `tail_tag`: only the last group of the stream (proj_out) can run out of slabs to issue; everywhere else the issue is unconditional (no branch).
     auto next_slab = [&](auto even_tag, auto tail_tag) -> const unsigned char* {
         if constexpr (decltype(even_tag)::value) {
-            if (!decltype(tail_tag)::value || issued < N_SLABS) { issue(); issue(); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+            if (!decltype(tail_tag)::value || issued < N_SLABS) { issue(); issue(); wait_landed(); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef VV_PROBE_NOBARRIER
             __builtin_amdgcn_s_barrier();
+#endif
         }
-        const unsigned char* s = ring + (consumed % NSLOT) * SLAB;
+        const unsigned char* s = ring + (consumed % NS) * SLAB;
         ++consumed;
         return s;
     };
 
     // ---- inputs: a = o (h16, fragments in PERM32 k order), t = t_in (fp32 trunk).  Rows past M repeat row M - 1 (never stored)
-    uint4 a[10][2];
-    f32x4 t[20][2];
+    uint4 a[10][TT];
+    f32x4 t[20][TT];
     {
         __syncthreads();       // parameter block visible
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TT; ++tt) {
             int64_t row = row0 + tt * 16 + li;
             if (row >= p.M) row = p.M - 1;
             const unsigned short* orow = (const unsigned short*)p.o + row * CC;
@@ -105,7 +129,11 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 1
-        for (int i = 0; i < AHEAD; ++i) issue();
+        for (int i = 0; i < AH; ++i) issue();
+        if (LAG > 0 && wave >= NW / 2) {      // the laggards pass LAG synchronisation steps without consuming: from here on they run 2 LAG slabs behind
+#pragma unroll 1
+            for (int i = 0; i < LAG; ++i) { issue(); issue(); wait_landed(); __builtin_amdgcn_s_barrier(); }
+        }
     }
 
     // D += W_slab * X^T for RT row tiles and KK k steps of one slab, split into the fragment reads (LDS -> registers) and the MFMAs so that a group
@@ -120,17 +148,21 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
         for (int kk = 0; kk < KK; ++kk) {
             const int off = ((kk * 4 + lg) ^ sw) << 4;
 #pragma unroll
+#ifndef VV_PROBE_NOLDS
             for (int rt = 0; rt < RT; ++rt) f.w[kk][rt] = *(const uint4*)(s + (rt * 16 + li) * 128 + off);
+#else
+            for (int rt = 0; rt < RT; ++rt) { f.w[kk][rt] = make_uint4(off + rt, (unsigned)(size_t)s, kk, rt); asm volatile("" : "+v"(f.w[kk][rt].x)); }
+#endif
         }
     };
-    auto slab_fma = [&](const WF& f, auto rt_tag, auto kk_tag, f32x4* acc /* [RT][2] */, const uint4 (&x0)[2], const uint4 (&x1)[2]) {
+    auto slab_fma = [&](const WF& f, auto rt_tag, auto kk_tag, f32x4* acc /* [RT][TT] */, const uint4 (&x0)[TT], const uint4 (&x1)[TT]) {
         constexpr int RT = decltype(rt_tag)::value, KK = decltype(kk_tag)::value;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) acc[rt * 2 + tt] = T::mfma(f.w[kk][rt], kk ? x1[tt] : x0[tt], acc[rt * 2 + tt]);
+                for (int tt = 0; tt < TT; ++tt) acc[rt * TT + tt] = T::mfma(f.w[kk][rt], kk ? x1[tt] : x0[tt], acc[rt * TT + tt]);
     };
     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     using I4 = std::integral_constant<int, 4>;
@@ -149,15 +181,21 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
             }
             slab_fma(f[i & 1], rt_tag, kk_tag, acc_of(i), x0_of(i), x1_of(i));
             if (i + 1 < N) __builtin_amdgcn_sched_group_barrier(0x100, KK * RT, 0);      // next slab's reads first ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * KK * RT, 0);                 // ... then this slab's MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x008, TT * KK * RT, 0);                 // ... then this slab's MFMAs
+#ifdef VV_CHAIN_PIN
+            // ... and nothing crosses into the next slab's region: without this fence hipcc fills the MFMA group with the MFMAs of the slab whose reads it
+            // has just issued (the group barriers order instruction TYPES, not instances), folds f[0] / f[1] into one register set and every slab waits
+            // out its own LDS round trip (round 5: the ISA of rounds 3-4 was never software pipelined)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     };
     using P0E = std::integral_constant<int, 0>; using P0O = std::integral_constant<int, 1>;
     using N5 = std::integral_constant<int, 5>; using N10 = std::integral_constant<int, 10>; using N25 = std::integral_constant<int, 25>;
     using BODY = std::false_type; using TAIL = std::true_type;
-    auto dense320 = [&](auto p0_tag, f32x4 (&acc)[20][2], auto tail) {      // 5 row blocks x 5 k tiles
-        slab_group(p0_tag, N25{}, I4{}, I2{}, [&](int i) { return &acc[(i / 5) * 4][0]; }, [&](int i) -> const uint4 (&)[2] { return a[2 * (i % 5)]; },
-                   [&](int i) -> const uint4 (&)[2] { return a[2 * (i % 5) + 1]; }, tail);
+    auto dense320 = [&](auto p0_tag, f32x4 (&acc)[20][TT], auto tail) {      // 5 row blocks x 5 k tiles
+        slab_group(p0_tag, N25{}, I4{}, I2{}, [&](int i) { return &acc[(i / 5) * 4][0]; }, [&](int i) -> const uint4 (&)[TT] { return a[2 * (i % 5)]; },
+                   [&](int i) -> const uint4 (&)[TT] { return a[2 * (i % 5) + 1]; }, tail);
     };
     auto frag = [&](const f32x4& lo, const f32x4& hi) -> uint4 {
         return make_uint4(pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]), pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3]));
@@ -167,12 +205,12 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
         for (int j = 0; j < 20; ++j) {
             const float4 b = *(const float4*)(prm + off + 16 * j + 4 * lg);
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) { t[j][tt][0] += b.x; t[j][tt][1] += b.y; t[j][tt][2] += b.z; t[j][tt][3] += b.w; }
+            for (int tt = 0; tt < TT; ++tt) { t[j][tt][0] += b.x; t[j][tt][1] += b.y; t[j][tt][2] += b.z; t[j][tt][3] += b.w; }
         }
     };
     auto layer_norm = [&](const int goff, const int boff) {
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TT; ++tt) {
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 20; ++j) s += (t[j][tt][0] + t[j][tt][1]) + (t[j][tt][2] + t[j][tt][3]);
@@ -211,22 +249,22 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int h = 0; h < CH; ++h) {
-        f32x4 qa[3][2];
+        f32x4 qa[3][TT];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) qa[i][tt] = z4;
+            for (int tt = 0; tt < TT; ++tt) qa[i][tt] = z4;
         // (a head is 14 slabs and starts at an odd stream index: 25 + 14 h)
-        slab_group(P0O{}, N5{}, I3{}, I2{}, [&](int) { return &qa[0][0]; }, [&](int i) -> const uint4 (&)[2] { return a[2 * i]; },
-                   [&](int i) -> const uint4 (&)[2] { return a[2 * i + 1]; }, BODY{});
-        uint4 q0[2], q1[2];                          // [token tile]: k steps 0 (d = PERM32) and 1 (d = 32 + 4 lg + e, e < 4)
+        slab_group(P0O{}, N5{}, I3{}, I2{}, [&](int) { return &qa[0][0]; }, [&](int i) -> const uint4 (&)[TT] { return a[2 * i]; },
+                   [&](int i) -> const uint4 (&)[TT] { return a[2 * i + 1]; }, BODY{});
+        uint4 q0[TT], q1[TT];                          // [token tile]: k steps 0 (d = PERM32) and 1 (d = 32 + 4 lg + e, e < 4)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) { q0[tt] = frag(qa[0][tt], qa[1][tt]); q1[tt] = frag(qa[2][tt], z4); }
-        f32x4 sT[5][2];                              // [key tile][token tile]: lane = token li, registers = keys 16 kt + 4 lg + r
+        for (int tt = 0; tt < TT; ++tt) { q0[tt] = frag(qa[0][tt], qa[1][tt]); q1[tt] = frag(qa[2][tt], z4); }
+        f32x4 sT[5][TT];                              // [key tile][token tile]: lane = token li, registers = keys 16 kt + 4 lg + r
 #pragma unroll
         for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) sT[kt][tt] = z4;
+            for (int tt = 0; tt < TT; ++tt) sT[kt][tt] = z4;
         {      // K_h: key rows 0..63 (4 tiles), then 64..79 (1 tile)
             WF f0, f1;
             slab_load(next_slab(EVEN{}, BODY{}), I4{}, I2{}, f0);
@@ -234,12 +272,12 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
             slab_fma(f0, I4{}, I2{}, &sT[0][0], q0, q1);
             slab_fma(f1, I1{}, I2{}, &sT[4][0], q0, q1);
             __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 10 * TT, 0);
         }
-        uint4 pf[3][2];                              // [k step of 32 keys][token tile]
-        float inv[2];
+        uint4 pf[3][TT];                              // [k step of 32 keys][token tile]
+        float inv[TT];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < TT; ++qt) {
             if (lg == 3) { sT[4][qt][1] = -1e30f; sT[4][qt][2] = -1e30f; sT[4][qt][3] = -1e30f; }      // keys 77, 78, 79 do not exist
             float m = sT[0][qt][0];
 #pragma unroll
@@ -257,11 +295,11 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
             inv[qt] = 1.0f / l;
             pf[0][qt] = frag(sT[0][qt], sT[1][qt]); pf[1][qt] = frag(sT[2][qt], sT[3][qt]); pf[2][qt] = frag(sT[4][qt], z4);
         }
-        f32x4 oT[3][2];                              // [d tile][token tile]
+        f32x4 oT[3][TT];                              // [d tile][token tile]
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) oT[i][tt] = z4;
+            for (int tt = 0; tt < TT; ++tt) oT[i][tt] = z4;
         {      // V_h^T: keys 0..63 (2 k steps), then 64..95 (1 k step)
             WF f0, f1;
             slab_load(next_slab(EVEN{}, BODY{}), I3{}, I2{}, f0);
@@ -269,17 +307,17 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
             slab_fma(f0, I3{}, I2{}, &oT[0][0], pf[0], pf[1]);
             slab_fma(f1, I3{}, I1{}, &oT[0][0], pf[2], pf[2]);
             __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 9 * TT, 0);
         }
-        uint4 o0[2], o1[2];
+        uint4 o0[TT], o1[TT];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) oT[i][tt] *= inv[tt];
             o0[tt] = frag(oT[0][tt], oT[1][tt]); o1[tt] = frag(oT[2][tt], z4);
         }
-        slab_group(P0E{}, N5{}, I4{}, I2{}, [&](int i) { return &t[i * 4][0]; }, [&](int) -> const uint4 (&)[2] { return o0; },
-                   [&](int) -> const uint4 (&)[2] { return o1; }, BODY{});
+        slab_group(P0E{}, N5{}, I4{}, I2{}, [&](int i) { return &t[i * 4][0]; }, [&](int) -> const uint4 (&)[TT] { return o0; },
+                   [&](int) -> const uint4 (&)[TT] { return o1; }, BODY{});
     }
     add_bias(Q_BO2);
 
@@ -287,16 +325,16 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
     layer_norm(Q_LN3G, Q_LN3B);
     // (chunk c is 15 slabs and starts at stream index 137 + 15 c: odd for even c, even for odd c -> two chunks per loop iteration)
     auto ff_chunk = [&](const int c, auto p0_tag) {
-        f32x4 g[8][2];
+        f32x4 g[8][TT];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) g[i][tt] = z4;
-        slab_group(p0_tag, N10{}, I4{}, I2{}, [&](int i) { return &g[(i / 5) * 4][0]; }, [&](int i) -> const uint4 (&)[2] { return a[2 * (i % 5)]; },
-                   [&](int i) -> const uint4 (&)[2] { return a[2 * (i % 5) + 1]; }, BODY{});
-        uint4 hf0[2], hf1[2];
+            for (int tt = 0; tt < TT; ++tt) g[i][tt] = z4;
+        slab_group(p0_tag, N10{}, I4{}, I2{}, [&](int i) { return &g[(i / 5) * 4][0]; }, [&](int i) -> const uint4 (&)[TT] { return a[2 * (i % 5)]; },
+                   [&](int i) -> const uint4 (&)[TT] { return a[2 * (i % 5) + 1]; }, BODY{});
+        uint4 hf0[TT], hf1[TT];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TT; ++tt) {
             f32x4 hv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -308,8 +346,8 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
             }
             hf0[tt] = frag(hv[0], hv[1]); hf1[tt] = frag(hv[2], hv[3]);
         }
-        slab_group(p0_tag, N5{}, I4{}, I2{}, [&](int i) { return &t[i * 4][0]; }, [&](int) -> const uint4 (&)[2] { return hf0; },
-                   [&](int) -> const uint4 (&)[2] { return hf1; }, BODY{});
+        slab_group(p0_tag, N5{}, I4{}, I2{}, [&](int i) { return &t[i * 4][0]; }, [&](int) -> const uint4 (&)[TT] { return hf0; },
+                   [&](int) -> const uint4 (&)[TT] { return hf1; }, BODY{});
     };
 #pragma unroll 1
     for (int c = 0; c < 20; c += 2) { ff_chunk(c, P0O{}); ff_chunk(c + 1, P0E{}); }
@@ -317,16 +355,16 @@ __global__ __launch_bounds__(256, 1) void chain_c320_kernel(const vv_chain_param
 
     // ---- proj_out (+ bias + x [+ res1])
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
         for (int s2 = 0; s2 < 10; ++s2) a[s2][tt] = frag(t[2 * s2][tt], t[2 * s2 + 1][tt]);
 #pragma unroll
     for (int j = 0; j < 20; ++j)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) t[j][tt] = z4;
+        for (int tt = 0; tt < TT; ++tt) t[j][tt] = z4;
     dense320(P0O{}, t, TAIL{});          // stream slabs 437..461
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int tt = 0; tt < TT; ++tt) {
         const int64_t r = row0 + tt * 16 + li;
         if (r < p.M) {
             const int64_t row = r * CC;
@@ -556,8 +594,18 @@ extern "C" int vv_spatial_chain_c320(const vv_chain_params* pp, int dtype, void*
     const int64_t nblk = (p.M + 127) / 128;
     if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == VV_BF16) hipLaunchKernelGGL(chain_c320_kernel<BF16>, dim3((unsigned)nblk), dim3(256), 0, st, p);
-    else if (dtype == VV_F16) hipLaunchKernelGGL(chain_c320_kernel<F16>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+#ifndef VV_CHAIN_TT
+#define VV_CHAIN_TT 1      // token tiles per wave: 1 = 8 waves x 16 tokens, two per SIMD, staggered (round 5); 2 = the round-3 form (lab A/B: -DVV_CHAIN_TT=2)
+#endif
+#ifndef VV_CHAIN_LAG
+#define VV_CHAIN_LAG 0     // slab pairs the second half of the block runs behind the first
+#endif
+#ifndef VV_CHAIN_AHEAD
+#define VV_CHAIN_AHEAD 6
+#endif
+    constexpr int TT = VV_CHAIN_TT, LAG = TT == 2 ? 0 : VV_CHAIN_LAG, NT = 128 / (16 * TT) * 64, AH = VV_CHAIN_AHEAD;
+    if (dtype == VV_BF16) hipLaunchKernelGGL((chain_c320_kernel<BF16, TT, LAG, AH>), dim3((unsigned)nblk), dim3(NT), 0, st, p);
+    else if (dtype == VV_F16) hipLaunchKernelGGL((chain_c320_kernel<F16, TT, LAG, AH>), dim3((unsigned)nblk), dim3(NT), 0, st, p);
     else VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: bad dtype");
     VV_CHECK_LAUNCH("vv_spatial_chain_c320");
     return VV_OK;
