@@ -7,6 +7,9 @@ import torch
 from videovanish_amd import hip, nn as vnn
 if os.environ.get("VV_LIB_PATH"):
     hip._LIB_PATH = os.environ["VV_LIB_PATH"]          # A/B of two builds of the library on one device
+from videovanish_amd import packing
+if os.environ.get("VV_CHAIN_LAYOUT"):
+    packing.CHAIN_LAYOUT = os.environ["VV_CHAIN_LAYOUT"]     # lab builds of the token-split kernels (-DVV_CHAIN_FORM=0) read the "tokens" stream order
 from videovanish_amd.config import UNetConfig
 
 dname = sys.argv[1] if len(sys.argv) > 1 else "fp16"

@@ -383,6 +383,439 @@ __global__ __launch_bounds__(128 / (16 * TT) * 64, TT == 2 ? 1 : 2) void chain_c
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// ROW-SPLIT form of the same tail (round 5).  What the counters said about the forms above (profiles/r5_chain_forms.txt): the kernel is not at the
+// board's power limit (2.39 GHz), its LDS pipe is 16 % busy in the 4-wave form -- the matrix pipe idles because ONE wave per SIMD cannot overlap its
+// own VALU phases (GELU, LayerNorm, softmax, the AGPR copies of a 512-register kernel) and waits (barrier, LDS round trips) with MFMAs; and the
+// 8 x 16-token form needs one ds_read_b128 per 16-cycle MFMA per wave = exactly the LDS pipe's 256 B/clk when the matrix pipe is full.
+// Here a block is still 128 tokens behind one weight ring, but its 8 waves are 4 token groups x 2 ROW HALVES: the two waves of a pair own the same
+// 32 tokens and split every [64 x 64] slab by rows (wave hf reads row tiles 2 hf, 2 hf + 1: 4 fragment reads feed 8 MFMAs -- half the LDS bytes
+// per MFMA of the 16-token form at two waves per SIMD and <= 256 architectural registers each).  A wave therefore holds the fp32 trunk of
+// 160 channels x 32 tokens (80 registers; channel = 64 rb + 32 hf + 16 rt + 4 lg + r) and the FULL h16 activation row of its tokens as B fragments
+// (80 registers), of which it produces only the k steps s = 2 kt + hf itself: whenever a layer ends (LayerNorm, GEGLU, the trunk before proj_out) the
+// partners swap their halves through LDS, lane for lane (the fragment a lane needs from its partner is the one the same lane of the partner holds).
+// LayerNorm statistics: each wave's (mean, M2) over its 160 channels, swapped and merged with Chan's formula.
+// Cross-attention (77 text keys): per head the q projection, S^T, softmax and V^T P^T run on ONE token tile per wave (tile hf: the 16-token form, 9 of a
+// head's 14 slabs), the head's O goes through LDS and its output projection is row-split again; stream order per head pair: q K V^T | q K V^T | Wo | Wo.
+// Synchronisation: explicit steps (LDS-DMA issue of the slabs about to be consumed + counted vmcnt + one barrier) in front of every slab pair of a group.
+constexpr int RS_NS = 10, RS_AH = 6, RS_XBUF = 40960;
+#ifdef VV_PROBE_NOVMWAIT
+#define VV_WAIT6 do {} while (0)
+#else
+#define VV_WAIT6 asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+#endif
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void chain_rs_c320_kernel(const vv_chain_params p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[RS_NS * SLAB];
+    __shared__ __attribute__((aligned(16))) unsigned char xbuf[RS_XBUF];
+    __shared__ __attribute__((aligned(16))) float sbuf[8 * 2 * 64 * 2];
+    __shared__ __attribute__((aligned(16))) float prm[Q_TOTAL];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int grp = wave & 3, hf = wave >> 2, pw = wave ^ 4;
+    const bool hi = hf != 0;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + grp * 32;
+
+    for (int i = tid * 4; i < Q_TOTAL; i += 512 * 4) *(float4*)(prm + i) = *(const float4*)(p.params + i);
+    // ---- weight stream: every wave copies 1 KB of every slab
+    const unsigned char* sbase = (const unsigned char*)p.stream + wave * 1024 + lane * 16;
+    int issued = 0, islot = 0, cslot = 0;
+    auto issue = [&]() {
+#if defined(VV_PROBE_REGLOAD)       // timing probe (wrong results): the same VMEM instruction count and bytes as the DMA, into a sink register set instead of LDS
+        asm volatile("global_load_dwordx4 a[0:3], %0, off" :: "v"(sbase + (int64_t)issued * SLAB) : "memory", "a0", "a1", "a2", "a3");
+#elif defined(VV_PROBE_SAMESLAB)      // timing probe (wrong results): every DMA reads slab (issued & 7) -- the issue cost without the stream's memory side
+        glds16_asm(sbase + (int64_t)(issued & 7) * SLAB, ring + islot * SLAB + wave * 1024);
+#elif !defined(VV_PROBE_NODMA)
+        glds16_asm(sbase + (int64_t)issued * SLAB, ring + islot * SLAB + wave * 1024);
+#endif
+        ++issued;
+        islot = islot + 1 == RS_NS ? 0 : islot + 1;
+    };
+    using BODY = std::false_type; using TAIL = std::true_type;
+    using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+    // one synchronisation step in front of NI slabs: issue NI more, wait until all but the newest RS_AH have landed (this wave's share), meet.
+    // XCH: the step also publishes LDS writes of this wave (an exchange): they have to be complete before the barrier.
+    auto sync = [&](auto ni_tag, auto tail_tag, auto xch_tag) {
+        constexpr int NI = decltype(ni_tag)::value;
+        if constexpr (decltype(tail_tag)::value) {
+            if (issued + NI <= N_SLABS) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) issue();
+                VV_WAIT6;
+            } else {
+                while (issued < N_SLABS) issue();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) issue();
+            VV_WAIT6;
+        }
+        if constexpr (decltype(xch_tag)::value) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef VV_PROBE_NOBARRIER
+        if constexpr (decltype(xch_tag)::value)
+#endif
+        __builtin_amdgcn_s_barrier();
+    };
+    using NOX = std::false_type; using XCH = std::true_type;
+    auto slab = [&]() -> const unsigned char* {
+        const unsigned char* s = ring + cslot * SLAB;
+        cslot = cslot + 1 == RS_NS ? 0 : cslot + 1;
+        return s;
+    };
+    auto meet = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };      // exchange-only barrier (no slab)
+
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    auto frag = [&](const f32x4& lo, const f32x4& hi_) -> uint4 {
+        return make_uint4(pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]), pack2<T>(hi_[0], hi_[1]), pack2<T>(hi_[2], hi_[3]));
+    };
+    auto sel = [&](const uint4& a_, const uint4& b_) -> uint4 { return hi ? b_ : a_; };      // wave-uniform select
+
+    // ---- row-split slab groups: this wave's two row tiles (2 hf, 2 hf + 1) of N [64 x 64] slabs
+    struct WF2 { uint4 w[2][2]; };      // [kk][rt]
+    const int rs_off = hf * 4096 + li * 128, sw = li & 7;
+    auto load_rs = [&](const unsigned char* s, WF2& f) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int off = ((kk * 4 + lg) ^ sw) << 4;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) f.w[kk][rt] = *(const uint4*)(s + rs_off + rt * 2048 + off);
+        }
+    };
+    auto fma_rs = [&](const WF2& f, f32x4* acc /* [2][2] = [rt][tt] */, const uint4 (&x0)[2], const uint4 (&x1)[2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) acc[rt * 2 + tt] = T::mfma(f.w[kk][rt], kk ? x1[tt] : x0[tt], acc[rt * 2 + tt]);
+    };
+    // N slabs, a step in front of every pair (PRE: the caller has already made the first one)
+    auto group_rs = [&](auto n_tag, auto pre_tag, auto&& acc_of, auto&& x0_of, auto&& x1_of, auto tail) {
+        constexpr int N = decltype(n_tag)::value;
+        WF2 f[2];
+        if constexpr (!decltype(pre_tag)::value) { if constexpr (N >= 2) sync(I2{}, tail, NOX{}); else sync(I1{}, tail, NOX{}); }
+        load_rs(slab(), f[0]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (i + 1 < N) {
+                if (((i + 1) & 1) == 0) { if (i + 2 < N) sync(I2{}, tail, NOX{}); else sync(I1{}, tail, NOX{}); }
+                load_rs(slab(), f[(i + 1) & 1]);
+            }
+            fma_rs(f[i & 1], acc_of(i), x0_of(i), x1_of(i));
+            if (i + 1 < N) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#ifdef VV_CHAIN_PIN
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    };
+    using N5 = std::integral_constant<int, 5>; using N10 = std::integral_constant<int, 10>; using N25 = std::integral_constant<int, 25>;
+    using NOPRE = std::false_type; using PRE = std::true_type;
+
+    // ---- state: trunk t[2 rb + rt][tt] (own channels), activations a0[kt][tt] / a1[kt][tt] = k steps 2 kt / 2 kt + 1 of the full row
+    f32x4 t[10][2];
+    uint4 a0[5][2], a1[5][2];
+    auto chan = [&](const int j) -> int { return 64 * (j >> 1) + 32 * hf + 16 * (j & 1) + 4 * lg; };      // first of the 4 channels of t[j][.][0..3]
+    {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            int64_t row = row0 + tt * 16 + li;
+            if (row >= p.M) row = p.M - 1;
+            const unsigned short* orow = (const unsigned short*)p.o + row * CC;
+            const float* trow = p.t_in + row * CC;
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt) {
+                const uint2 l0 = *(const uint2*)(orow + 64 * kt + 4 * lg), h0 = *(const uint2*)(orow + 64 * kt + 16 + 4 * lg);
+                const uint2 l1 = *(const uint2*)(orow + 64 * kt + 32 + 4 * lg), h1 = *(const uint2*)(orow + 64 * kt + 48 + 4 * lg);
+                a0[kt][tt] = make_uint4(l0.x, l0.y, h0.x, h0.y);
+                a1[kt][tt] = make_uint4(l1.x, l1.y, h1.x, h1.y);
+            }
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const float4 v = *(const float4*)(trow + chan(j));
+                t[j][tt] = f32x4{v.x, v.y, v.z, v.w};
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();       // parameter block visible
+#pragma unroll 1
+        for (int i = 0; i < RS_AH; ++i) issue();
+    }
+    auto add_bias = [&](const int off) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const float4 b = *(const float4*)(prm + off + chan(j));
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) { t[j][tt][0] += b.x; t[j][tt][1] += b.y; t[j][tt][2] += b.z; t[j][tt][3] += b.w; }
+        }
+    };
+    auto dense320 = [&](f32x4 (&acc)[10][2], auto tail) {      // 5 row blocks x 5 k tiles
+        group_rs(N25{}, NOPRE{}, [&](int i) { return &acc[(i / 5) * 2][0]; }, [&](int i) -> const uint4 (&)[2] { return a0[i % 5]; },
+                 [&](int i) -> const uint4 (&)[2] { return a1[i % 5]; }, tail);
+    };
+    // own[rb][tt] = h16(LN(t) g + b) of this wave's channels = k step 2 rb + hf of the row; statistics merged with the partner's
+    auto layer_norm = [&](const int goff, const int boff, uint4 (&own)[5][2]) {
+        float mloc[2], m2loc[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) s += (t[j][tt][0] + t[j][tt][1]) + (t[j][tt][2] + t[j][tt][3]);
+            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+            mloc[tt] = s * (1.0f / 160);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 10; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = t[j][tt][r] - mloc[tt]; q += d * d; }
+            q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+            m2loc[tt] = q;
+        }
+        *(float4*)(sbuf + (wave * 64 + lane) * 4) = make_float4(mloc[0], m2loc[0], mloc[1], m2loc[1]);
+        meet();
+        const float4 o4 = *(const float4*)(sbuf + (pw * 64 + lane) * 4);
+        const float om[2] = {o4.x, o4.z}, oq[2] = {o4.y, o4.w};
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const float mean = 0.5f * (mloc[tt] + om[tt]), dm = mloc[tt] - om[tt];
+            const float rstd = rsqrtf((m2loc[tt] + oq[tt] + 80.0f * dm * dm) * (1.0f / CC) + 1e-5f);
+#pragma unroll
+            for (int rb = 0; rb < 5; ++rb) {
+                f32x4 y[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = 2 * rb + h, c = chan(j);
+                    const float4 g = *(const float4*)(prm + goff + c), b = *(const float4*)(prm + boff + c);
+                    y[h][0] = (t[j][tt][0] - mean) * rstd * g.x + b.x; y[h][1] = (t[j][tt][1] - mean) * rstd * g.y + b.y;
+                    y[h][2] = (t[j][tt][2] - mean) * rstd * g.z + b.z; y[h][3] = (t[j][tt][3] - mean) * rstd * g.w + b.w;
+                }
+                own[rb][tt] = frag(y[0], y[1]);
+            }
+        }
+    };
+    unsigned char* const xmine = xbuf + wave * 5120 + lane * 16;
+    const unsigned char* const xpart = xbuf + pw * 5120 + lane * 16;
+    // full swap of the partners' halves: a0 / a1 <- (own, partner's) for both token tiles (two rounds through the 40 KB buffer)
+    auto swap_full = [&](const uint4 (&own)[5][2]) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            if (tt) meet();      // the partner has read round 0
+#pragma unroll
+            for (int rb = 0; rb < 5; ++rb) *(uint4*)(xmine + rb * 1024) = own[rb][tt];
+            meet();
+#pragma unroll
+            for (int rb = 0; rb < 5; ++rb) {
+                const uint4 o = *(const uint4*)(xpart + rb * 1024);
+                a0[rb][tt] = sel(own[rb][tt], o);
+                a1[rb][tt] = sel(o, own[rb][tt]);
+            }
+        }
+    };
+
+    // ---- attn1 output projection: t = t_in + Wo1 o + bo1        (stream slabs 0..24)
+    dense320(t, BODY{});
+    add_bias(Q_BO1);
+
+    // ---- attn2: cross-attention to the 77 text keys, on token tile hf of the pair (x0[kt] / x1[kt]: the tile's full row)
+    {
+        uint4 own[5][2];
+        layer_norm(Q_LN2G, Q_LN2B, own);
+        uint4 x0[5], x1[5];
+        // the partner needs my k steps of ITS tile (1 - hf); I need its k steps of mine
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb) *(uint4*)(xmine + rb * 1024) = sel(own[rb][1], own[rb][0]);
+        meet();
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb) {
+            const uint4 o = *(const uint4*)(xpart + rb * 1024), m = sel(own[rb][0], own[rb][1]);
+            x0[rb] = sel(m, o);
+            x1[rb] = sel(o, m);
+        }
+        meet();      // everybody has read: the buffer is free for the heads' O
+        const float sc = 0.15811388300841897f * 1.4426950408889634f;      // 40^-1/2 * log2(e)
+        struct WF { uint4 w[2][4]; };
+        auto load_full = [&](const unsigned char* s, auto rt_tag, auto kk_tag, WF& f) {
+            constexpr int RT = decltype(rt_tag)::value, KK = decltype(kk_tag)::value;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const int off = ((kk * 4 + lg) ^ sw) << 4;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) f.w[kk][rt] = *(const uint4*)(s + (rt * 16 + li) * 128 + off);
+            }
+        };
+        auto fma_full = [&](const WF& f, auto rt_tag, auto kk_tag, f32x4* acc /* [RT] */, const uint4& y0, const uint4& y1) {
+            constexpr int RT = decltype(rt_tag)::value, KK = decltype(kk_tag)::value;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = T::mfma(f.w[kk][rt], kk ? y1 : y0, acc[rt]);
+        };
+        auto head_core = [&](const int hs) {      // q K V^T of one head for token tile hf -> O fragments into xbuf slot hs
+            f32x4 qa[3] = {z4, z4, z4};
+            {
+                WF f[2];
+                sync(I2{}, BODY{}, NOX{});
+                load_full(slab(), I3{}, I2{}, f[0]);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    if (i + 1 < 5) {
+                        if (((i + 1) & 1) == 0) { if (i + 2 < 5) sync(I2{}, BODY{}, NOX{}); else sync(I1{}, BODY{}, NOX{}); }
+                        load_full(slab(), I3{}, I2{}, f[(i + 1) & 1]);
+                    }
+                    fma_full(f[i & 1], I3{}, I2{}, qa, x0[i], x1[i]);
+                    if (i + 1 < 5) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                }
+            }
+            const uint4 q0 = frag(qa[0], qa[1]), q1 = frag(qa[2], z4);
+            f32x4 sT[5] = {z4, z4, z4, z4, z4};      // [key tile]: lane = token li, registers = keys 16 kt + 4 lg + r
+            {
+                WF f0, f1;
+                sync(I2{}, BODY{}, NOX{});
+                load_full(slab(), I4{}, I2{}, f0);
+                load_full(slab(), I1{}, I2{}, f1);
+                fma_full(f0, I4{}, I2{}, &sT[0], q0, q1);
+                fma_full(f1, I1{}, I2{}, &sT[4], q0, q1);
+            }
+            if (lg == 3) { sT[4][1] = -1e30f; sT[4][2] = -1e30f; sT[4][3] = -1e30f; }      // keys 77, 78, 79 do not exist
+            float m = sT[0][0];
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, sT[kt][r]);
+            m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+            const float mc = m * sc;
+            float l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(sT[kt][r] * sc - mc); sT[kt][r] = e; l += e; }
+            l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+            const float inv = 1.0f / l;
+            const uint4 pf0 = frag(sT[0], sT[1]), pf1 = frag(sT[2], sT[3]), pf2 = frag(sT[4], z4);
+            f32x4 oT[3] = {z4, z4, z4};
+            {
+                WF f0, f1;
+                sync(I2{}, BODY{}, NOX{});
+                load_full(slab(), I3{}, I2{}, f0);
+                load_full(slab(), I3{}, I1{}, f1);
+                fma_full(f0, I3{}, I2{}, oT, pf0, pf1);
+                fma_full(f1, I3{}, I1{}, oT, pf2, pf2);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) oT[i] *= inv;
+            unsigned char* dst = xbuf + (hs * 8 + wave) * 2048 + lane * 16;
+            *(uint4*)dst = frag(oT[0], oT[1]);
+            *(uint4*)(dst + 1024) = frag(oT[2], z4);
+        };
+        auto head_out = [&](const int hs, auto xch) {      // t += Wo2[:, head] O for both token tiles of the group (row-split)
+            sync(I2{}, BODY{}, xch);
+            uint4 o0[2], o1[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const unsigned char* src = xbuf + (hs * 8 + grp + 4 * tt) * 2048 + lane * 16;
+                o0[tt] = *(const uint4*)src;
+                o1[tt] = *(const uint4*)(src + 1024);
+            }
+            group_rs(N5{}, PRE{}, [&](int i) { return &t[i * 2][0]; }, [&](int) -> const uint4 (&)[2] { return o0; },
+                     [&](int) -> const uint4 (&)[2] { return o1; }, BODY{});
+        };
+#pragma unroll 1
+        for (int hp = 0; hp < CH / 2; ++hp) {
+            head_core(0);
+            head_core(1);
+            head_out(0, XCH{});
+            head_out(1, NOX{});
+        }
+    }
+    add_bias(Q_BO2);
+
+    // ---- GEGLU feed-forward, 20 chunks of 64 hidden units: 10 slabs of W1, 5 slabs of W2.  W1 rows per slab: [value | gate] of 16 hidden units for
+    //      each half (packing.pack_chain_stream): this wave gets value and gate of hidden 0..15 (+ 32 hf) from the first five slabs and of 16..31 (+ 32 hf)
+    //      from the next five = exactly k step hf of W2's 64-wide k; the other k step comes from the partner
+    {
+        uint4 own[5][2];
+        layer_norm(Q_LN3G, Q_LN3B, own);
+        swap_full(own);
+    }
+#pragma unroll 1
+    for (int c = 0; c < 20; ++c) {
+        f32x4 g[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) g[i][tt] = z4;
+        group_rs(N10{}, NOPRE{}, [&](int i) { return &g[(i / 5) * 2][0]; }, [&](int i) -> const uint4 (&)[2] { return a0[i % 5]; },
+                 [&](int i) -> const uint4 (&)[2] { return a1[i % 5]; }, BODY{});
+        uint4 hown[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            f32x4 hv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* bp = prm + Q_B1 + c * 128 + i * 64 + hf * 32 + 4 * lg;
+                const float4 bv = *(const float4*)bp, bg = *(const float4*)(bp + 16);
+                const vv_f32x2 g01 = gelu2((vv_f32x2){g[2 * i + 1][tt][0] + bg.x, g[2 * i + 1][tt][1] + bg.y});
+                const vv_f32x2 g23 = gelu2((vv_f32x2){g[2 * i + 1][tt][2] + bg.z, g[2 * i + 1][tt][3] + bg.w});
+                hv[i][0] = (g[2 * i][tt][0] + bv.x) * g01.x; hv[i][1] = (g[2 * i][tt][1] + bv.y) * g01.y;
+                hv[i][2] = (g[2 * i][tt][2] + bv.z) * g23.x; hv[i][3] = (g[2 * i][tt][3] + bv.w) * g23.y;
+            }
+            hown[tt] = frag(hv[0], hv[1]);
+        }
+        unsigned char* dst = xbuf + ((c & 1) * 8 + wave) * 2048 + lane * 16;
+        *(uint4*)dst = hown[0];
+        *(uint4*)(dst + 1024) = hown[1];
+        sync(I2{}, BODY{}, XCH{});
+        const unsigned char* src = xbuf + ((c & 1) * 8 + pw) * 2048 + lane * 16;
+        const uint4 hp0 = *(const uint4*)src, hp1 = *(const uint4*)(src + 1024);
+        const uint4 h0[2] = {sel(hown[0], hp0), sel(hown[1], hp1)}, h1[2] = {sel(hp0, hown[0]), sel(hp1, hown[1])};
+        group_rs(N5{}, PRE{}, [&](int i) { return &t[i * 2][0]; }, [&](int) -> const uint4 (&)[2] { return h0; },
+                 [&](int) -> const uint4 (&)[2] { return h1; }, BODY{});
+    }
+    add_bias(Q_B2);
+
+    // ---- proj_out (+ bias + x [+ res1])
+    {
+        uint4 own[5][2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int rb = 0; rb < 5; ++rb) own[rb][tt] = frag(t[2 * rb][tt], t[2 * rb + 1][tt]);
+        meet();      // the last FF exchange buffer has been read by everybody
+        swap_full(own);
+    }
+#pragma unroll
+    for (int j = 0; j < 10; ++j)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) t[j][tt] = z4;
+    dense320(t, TAIL{});          // stream slabs 437..461
+#ifdef VV_PROBE_REGLOAD
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int64_t r = row0 + tt * 16 + li;
+        if (r < p.M) {
+            const int64_t row = r * CC;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int c = chan(j);
+                const float4 b = *(const float4*)(prm + Q_BOUT + c);
+                const float4 xr = *(const float4*)(p.x + row + c);
+                float v0 = t[j][tt][0] + b.x + xr.x, v1 = t[j][tt][1] + b.y + xr.y, v2 = t[j][tt][2] + b.z + xr.z, v3 = t[j][tt][3] + b.w + xr.w;
+                if (p.res1) { const float4 r4 = *(const float4*)(p.res1 + row + c); v0 += r4.x; v1 += r4.y; v2 += r4.z; v3 += r4.w; }
+                if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + row + c) = make_float4(v0, v1, v2, v3);
+                else *(uint2*)((unsigned short*)p.out + row + c) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // Front half of the same block: everything BEFORE the self-attention core is per token too --
 //   t = Win GN(x) + bin        (GroupNorm apply with per-frame statistics + proj_in; t = the block's fp32 residual stream, written out for the tail)
@@ -603,9 +1036,17 @@ extern "C" int vv_spatial_chain_c320(const vv_chain_params* pp, int dtype, void*
 #ifndef VV_CHAIN_AHEAD
 #define VV_CHAIN_AHEAD 6
 #endif
+#ifndef VV_CHAIN_FORM
+#define VV_CHAIN_FORM 1    // 1 = row-split pairs (chain_rs_c320_kernel; stream order packing.pack_chain_stream(layout="rowsplit")); 0 = the token-split forms (lab A/B)
+#endif
+#if VV_CHAIN_FORM == 1
+    if (dtype == VV_BF16) hipLaunchKernelGGL((chain_rs_c320_kernel<BF16>), dim3((unsigned)nblk), dim3(512), 0, st, p);
+    else if (dtype == VV_F16) hipLaunchKernelGGL((chain_rs_c320_kernel<F16>), dim3((unsigned)nblk), dim3(512), 0, st, p);
+#else
     constexpr int TT = VV_CHAIN_TT, LAG = TT == 2 ? 0 : VV_CHAIN_LAG, NT = 128 / (16 * TT) * 64, AH = VV_CHAIN_AHEAD;
     if (dtype == VV_BF16) hipLaunchKernelGGL((chain_c320_kernel<BF16, TT, LAG, AH>), dim3((unsigned)nblk), dim3(NT), 0, st, p);
     else if (dtype == VV_F16) hipLaunchKernelGGL((chain_c320_kernel<F16, TT, LAG, AH>), dim3((unsigned)nblk), dim3(NT), 0, st, p);
+#endif
     else VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: bad dtype");
     VV_CHECK_LAUNCH("vv_spatial_chain_c320");
     return VV_OK;

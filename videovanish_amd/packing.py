@@ -154,34 +154,50 @@ def _head_k_columns(D):
     return torch.cat([torch.arange(32), 32 + p[ok]]), torch.cat([perm, d1[ok]])
 
 
-def pack_chain_stream(w, h16, heads=8):
+CHAIN_LAYOUT = "rowsplit"      # stream order of vv_chain.hip's product kernel (chain_rs_c320_kernel); "tokens": the round-3 / lab kernels (VV_CHAIN_FORM=0)
+
+
+def pack_chain_stream(w, h16, heads=8, layout=None):
     """w: dict of fp32 tensors of the tail of one spatial transformer block at C = 320 -- o1.w/.b (attn1.to_out.0), ln2.g/.b, q2.w (attn2.to_q),
     k2 / v2 ([77, C]: the text tokens already projected by attn2.to_k / to_v), o2.w/.b (attn2.to_out.0), ln3.g/.b, ff1.w/.b ([8C, C]),
-    ff2.w/.b ([C, 4C]), out.w/.b (proj_out).  Returns (stream [462, 64, 64] h16, params [5120] fp32) in the consumption order of vv_chain.hip."""
+    ff2.w/.b ([C, 4C]), out.w/.b (proj_out).  Returns (stream [462, 64, 64] h16, params [5120] fp32) in the consumption order of vv_chain.hip.
+    layout "rowsplit" (product): cross-attention slabs per head PAIR as q K V^T | q K V^T | Wo | Wo, and the GEGLU rows of a 64-unit chunk ordered so
+    that row tiles (0, 1) / (2, 3) of its two slab groups are [value | gate] of hidden units 0..15 / 32..47 and 16..31 / 48..63: the wave that owns
+    row half hf of every slab then produces exactly k step hf of the second projection."""
+    layout = layout or CHAIN_LAYOUT
+    assert layout in ("rowsplit", "tokens")
     C = w["o1.w"].shape[0]
     D = C // heads
     assert C == 320 and D == 40 and w["k2"].shape == (77, C) and w["v2"].shape == (77, C)
     dst, src = _head_k_columns(D)
     slabs = _dense_slabs(_permute_k(w["o1.w"]), h16, 64)
+    core, outp = [], []
     for h in range(heads):
         wh = torch.zeros((48, C))
         wh[:D] = w["q2.w"][h * D:(h + 1) * D]
-        slabs += _dense_slabs(_permute_k(wh), h16, 48)                     # q = Wq[head] a: 5 slabs of 48 rows
+        hs = _dense_slabs(_permute_k(wh), h16, 48)                         # q = Wq[head] a: 5 slabs of 48 rows
         kh = torch.zeros((128, 64))                                        # K_h: rows = keys (77 -> 80 used), columns = d in the packed order
         kh[:77, dst] = w["k2"][:, h * D + src]
-        slabs += [_slab(kh[0:64], h16), _slab(kh[64:80], h16)]
+        hs += [_slab(kh[0:64], h16), _slab(kh[64:80], h16)]
         vt = torch.zeros((48, 128))                                        # V_h^T: rows = d, columns = keys (PERM32 inside every 32-key step)
         vt[:D, :77] = w["v2"][:, h * D:(h + 1) * D].t()
         vt = _permute_k(vt)
-        slabs += [_slab(vt[:, 0:64], h16), _slab(vt[:, 64:128], h16)]
+        hs += [_slab(vt[:, 0:64], h16), _slab(vt[:, 64:128], h16)]
         wo = torch.zeros((C, 64))
         wo[:, dst] = w["o2.w"][:, h * D + src]
-        slabs += _dense_slabs(wo, h16, 64)
+        core.append(hs)
+        outp.append(_dense_slabs(wo, h16, 64))
+    if layout == "rowsplit":
+        for h in range(0, heads, 2):
+            slabs += core[h] + core[h + 1] + outp[h] + outp[h + 1]
+    else:
+        for h in range(heads):
+            slabs += core[h] + outp[h]
     inner = 4 * C
     b1 = []
     for c in range(inner // 64):
         rows = []
-        for i in range(4):
+        for i in ((0, 2, 1, 3) if layout == "rowsplit" else (0, 1, 2, 3)):
             rows += list(range(64 * c + 16 * i, 64 * c + 16 * i + 16)) + list(range(inner + 64 * c + 16 * i, inner + 64 * c + 16 * i + 16))
         rows = torch.tensor(rows)
         slabs += _dense_slabs(_permute_k(w["ff1.w"][rows]), h16, 64)
