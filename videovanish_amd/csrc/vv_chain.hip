@@ -816,6 +816,308 @@ __global__ __launch_bounds__(512, 2) void chain_rs_c320_kernel(const vv_chain_pa
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// COLUMN-SPLIT form of the tail (round 5; LAB form, -DVV_CHAIN_FORM=2: correct, 2.16 ms against 2.07 ms of the row-split form -- one wave per SIMD pays its
+// GELU / LayerNorm / AGPR-copy VALU time and every LDS round trip in full; kept because it has no weight ring at all, see profiles/r5_chain_forms.txt).  What the probes of the ring forms said (profiles/r5_chain_forms.txt): with the weight
+// stream's LDS-DMA removed the row-split kernel runs 2.08 -> 1.31 ms, with the same bytes loaded into registers instead 1.57 ms -- staging weights
+// that every wave reads anyway through LDS costs more than the MFMAs they feed.  So here NO weight touches LDS: wave w of a 4-wave block owns output
+// channels 80 w .. 80 w + 79 of every layer for all 128 tokens, its weights are a PRIVATE stream of ready-made A-operand fragments (1 KB each:
+// packing.pack_chain_stream_columns) read with plain global_load_dwordx4 through a 10-fragment register ring that runs 2 k steps ahead across
+// layer boundaries, and what the waves share -- the layer's INPUT activations, h16 [128 tokens][320] -- sits in LDS (80 KB, 16-byte chunks XOR-swizzled
+// by the token so that the B-operand reads are conflict free) and is read 8 fragments per 40 MFMAs.  The fp32 trunk [80 channels x 128 tokens] stays in
+// 160 accumulator registers; a layer's output is written back to the activation buffer (own columns) behind a barrier: ~35 barriers per block instead
+// of 231 ring steps.  LayerNorm: per-wave (mean, M2) over its 80 channels through LDS, merged by Chan's formula.  Cross-attention: wave w does heads
+// 2 w, 2 w + 1 (q projection padded to 48 rows, K_h / V_h^T fragments from the stream, scores / softmax / PV per token-tile pair as in the forms
+// above); the four heads of a phase leave O in a 40 KB buffer and the matching half of Wo2 follows.  GEGLU: 10 chunks of 128 hidden units (32 per wave).
+constexpr int CS_NF = 10, CS_FRAGS = 870;
+constexpr int P_BO1 = 0, P_LN2G = 320, P_LN2B = 640, P_BO2 = 960, P_LN3G = 1280, P_LN3B = 1600, P_B1V = 1920, P_B1G = 3200, P_B2 = 4480, P_BOUT = 4800;
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void chain_cs_c320_kernel(const vv_chain_params p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char act[128 * 640];
+    __shared__ __attribute__((aligned(1024))) unsigned char hbuf[40960];
+    __shared__ __attribute__((aligned(16))) float stats[4 * 128 * 2];
+    __shared__ __attribute__((aligned(16))) float prm[Q_TOTAL];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int i = tid * 4; i < Q_TOTAL; i += 256 * 4) *(float4*)(prm + i) = *(const float4*)(p.params + i);
+    // block barrier for LDS hand-offs: raw s_barrier behind an LDS-only wait (__syncthreads() would also drain vmcnt: the weight ring's loads in flight)
+    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+
+    // ---- the wave's weight stream and its register ring
+    const unsigned char* wst = (const unsigned char*)p.stream + (int64_t)wave * CS_FRAGS * 1024 + lane * 16;
+    uint4 wr[CS_NF];
+#pragma unroll
+    for (int i = 0; i < CS_NF; ++i) { wr[i] = *(const uint4*)wst; wst += 1024; }
+    // take fragment i of the ring and refill the slot with the stream's next fragment
+#ifdef VV_PROBE_NOWLOAD      // timing probe (wrong results): the ring is never refilled
+    auto take = [&](const int i) -> uint4 { uint4 v = wr[i]; asm volatile("" : "+v"(v.x)); return v; };
+#else
+    auto take = [&](const int i) -> uint4 { const uint4 v = wr[i]; wr[i] = *(const uint4*)wst; wst += 1024; return v; };
+#endif
+
+    // ---- activation buffers.  act: [128][320] h16, chunk c (16 B) of token row n at chunk c ^ ((n >> 1) & 7); hbuf as 2 x [128][64] (GEGLU chunks): chunk c
+    //      at c ^ ((n >> 1) & 7); as [128][160] (O of four heads): chunk c at c ^ ((n >> 2) & 3)
+    const int sA = li >> 1, sO = li >> 2;
+    auto act_rd = [&](const int ks, const int tt) -> uint4 { return *(const uint4*)(act + (16 * tt + li) * 640 + (((4 * ks + lg) ^ sA) << 4)); };
+    auto act_wr = [&](const int ch /* multiple of 4 */, const int tt, const uint2 v) {
+        *(uint2*)(act + (16 * tt + li) * 640 + ((((ch >> 3)) ^ sA) << 4) + ((ch & 4) << 1)) = v;
+    };
+    auto ob_rd = [&](const int ks, const int tt) -> uint4 { return *(const uint4*)(hbuf + (16 * tt + li) * 320 + (((4 * ks + lg) ^ sO) << 4)); };
+    auto ob_wr = [&](const int ch, const int tt, const uint2 v) { *(uint2*)(hbuf + (16 * tt + li) * 320 + (((ch >> 3) ^ sO) << 4) + ((ch & 4) << 1)) = v; };
+    auto pk4 = [&](const f32x4& v) -> uint2 { return make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])); };
+    auto frag = [&](const f32x4& lo, const f32x4& hi) -> uint4 {
+        return make_uint4(pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]), pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3]));
+    };
+
+    // ---- inputs: o (h16) -> act; t_in (own channels) -> trunk.  Rows past M repeat row M - 1 (never stored)
+    f32x4 t[5][8];
+    {
+        // o: 128 rows x 40 chunks = 5120 chunks, 20 per thread: chunk q of the block = (row q / 40, chunk q % 40)
+#pragma unroll 4
+        for (int q = tid; q < 128 * 40; q += 256) {
+            const int n = q / 40, c = q - n * 40;
+            int64_t row = row0 + n;
+            if (row >= p.M) row = p.M - 1;
+            const uint4 v = *(const uint4*)((const unsigned short*)p.o + row * CC + c * 8);
+            *(uint4*)(act + n * 640 + ((c ^ ((n >> 1) & 7)) << 4)) = v;
+        }
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+            int64_t row = row0 + tt * 16 + li;
+            if (row >= p.M) row = p.M - 1;
+            const float* trow = p.t_in + row * CC + 80 * wave + 4 * lg;
+#pragma unroll
+            for (int rt = 0; rt < 5; ++rt) { const float4 v = *(const float4*)(trow + 16 * rt); t[rt][tt] = f32x4{v.x, v.y, v.z, v.w}; }
+        }
+        __syncthreads();
+    }
+
+    // acc[RT][8] += W (RT row tiles of the stream, KS k steps) x buffer: per k step 8 B fragments (double buffered: the reads of step ks + 1 are issued
+    // before the MFMAs of step ks) and RT ring fragments starting at ring position (R0 + RT ks) % 10
+    auto layer = [&](auto rt_tag, auto ks_tag, auto r0_tag, f32x4* acc /* [RT][8] */, auto&& rd) {
+        constexpr int RT = decltype(rt_tag)::value, KS = decltype(ks_tag)::value, R0 = decltype(r0_tag)::value;
+        uint4 bb[2][8];
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) bb[0][tt] = rd(0, tt);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int tt = 0; tt < 8; ++tt) bb[(ks + 1) & 1][tt] = rd(ks + 1, tt);
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const uint4 wa = take((R0 + RT * ks + rt) % CS_NF);
+#pragma unroll
+                for (int tt = 0; tt < 8; ++tt) acc[rt * 8 + tt] = T::mfma(wa, bb[ks & 1][tt], acc[rt * 8 + tt]);
+            }
+#ifndef VV_CS_NO_PIN
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    };
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>; using I5 = std::integral_constant<int, 5>;
+    using I10 = std::integral_constant<int, 10>; using I0 = std::integral_constant<int, 0>;
+    auto rdA = [&](const int ks, const int tt) -> uint4 { return act_rd(ks, tt); };
+    auto rdO = [&](const int ks, const int tt) -> uint4 { return ob_rd(ks, tt); };
+    auto add_bias = [&](const int off) {
+#pragma unroll
+        for (int rt = 0; rt < 5; ++rt) {
+            const float4 b = *(const float4*)(prm + off + 80 * wave + 16 * rt + 4 * lg);
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) { t[rt][tt][0] += b.x; t[rt][tt][1] += b.y; t[rt][tt][2] += b.z; t[rt][tt][3] += b.w; }
+        }
+    };
+    // act <- h16(LN(t) g + b) (own columns); the caller's next barrier publishes it
+    auto layer_norm = [&](const int goff, const int boff) {
+        float ml[8], m2[8];
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+            float s = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 5; ++rt) s += (t[rt][tt][0] + t[rt][tt][1]) + (t[rt][tt][2] + t[rt][tt][3]);
+            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+            ml[tt] = s * (1.0f / 80);
+            float q = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 5; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = t[rt][tt][r] - ml[tt]; q += d * d; }
+            q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+            m2[tt] = q;
+            if (lg == 0) *(float2*)(stats + ((wave * 128) + 16 * tt + li) * 2) = make_float2(ml[tt], q);
+        }
+        bar();                // statistics of all four waves; everybody is also done reading the activation buffer
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+            float mw[4], qw[4];
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) { const float2 v = *(const float2*)(stats + (w4 * 128 + 16 * tt + li) * 2); mw[w4] = v.x; qw[w4] = v.y; }
+            const float mean = 0.25f * ((mw[0] + mw[1]) + (mw[2] + mw[3]));
+            float M2 = (qw[0] + qw[1]) + (qw[2] + qw[3]);
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) { const float d = mw[w4] - mean; M2 += 80.0f * d * d; }
+            const float rstd = rsqrtf(M2 * (1.0f / CC) + 1e-5f);
+#pragma unroll
+            for (int rt = 0; rt < 5; ++rt) {
+                const int c = 80 * wave + 16 * rt + 4 * lg;
+                const float4 g = *(const float4*)(prm + goff + c), b = *(const float4*)(prm + boff + c);
+                const f32x4 y = {(t[rt][tt][0] - mean) * rstd * g.x + b.x, (t[rt][tt][1] - mean) * rstd * g.y + b.y,
+                                 (t[rt][tt][2] - mean) * rstd * g.z + b.z, (t[rt][tt][3] - mean) * rstd * g.w + b.w};
+                act_wr(c, tt, pk4(y));
+            }
+        }
+    };
+
+    // ---- attn1 output projection: t = t_in + Wo1 o + bo1
+    layer(I5{}, I10{}, I0{}, &t[0][0], rdA);
+    add_bias(P_BO1);
+
+    // ---- attn2: cross-attention to the 77 text keys; this wave's heads 2 w (phase 0) and 2 w + 1 (phase 1)
+    layer_norm(P_LN2G, P_LN2B);
+    bar();
+    const float sc = 0.15811388300841897f * 1.4426950408889634f;      // 40^-1/2 * log2(e)
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+        uint4 qf0[8], qf1[8];      // q of the head as B fragments: k step 0 = d in PERM32 order, k step 1 = d 32..39 + zeros
+        {
+            f32x4 qa[3][8];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int tt = 0; tt < 8; ++tt) qa[i][tt] = z4;
+            layer(I3{}, I10{}, I0{}, &qa[0][0], rdA);
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) { qf0[tt] = frag(qa[0][tt], qa[1][tt]); qf1[tt] = frag(qa[2][tt], z4); }
+        }
+        uint4 kw[10], vw[9];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) kw[i] = take(i);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) { const uint4 v = take(i); if (i < 9) vw[i] = v; }
+        if (ph) bar();                // the O buffer: phase 0's half of Wo2 has been read by everybody
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {      // token tile pairs
+            f32x4 sT[5][2];                    // [key tile][tile of the pair]: lane = token li, registers = keys 16 kt + 4 lg + r
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) sT[kt][u] = z4;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) sT[kt][u] = T::mfma(kw[kk * 5 + kt], kk ? qf1[2 * pp + u] : qf0[2 * pp + u], sT[kt][u]);
+            uint4 pf[3][2];
+            float inv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (lg == 3) { sT[4][u][1] = -1e30f; sT[4][u][2] = -1e30f; sT[4][u][3] = -1e30f; }      // keys 77, 78, 79 do not exist
+                float m = sT[0][u][0];
+#pragma unroll
+                for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmaxf(m, sT[kt][u][r]);
+                m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+                const float mc = m * sc;
+                float l = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(sT[kt][u][r] * sc - mc); sT[kt][u][r] = e; l += e; }
+                l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+                inv[u] = 1.0f / l;
+                pf[0][u] = frag(sT[0][u], sT[1][u]); pf[1][u] = frag(sT[2][u], sT[3][u]); pf[2][u] = frag(sT[4][u], z4);
+            }
+            f32x4 oT[3][2];                    // [d tile][tile of the pair]
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) oT[i][u] = z4;
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) oT[dt][u] = T::mfma(vw[kk * 3 + dt], pf[kk][u], oT[dt][u]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt)
+                    if (16 * dt + 4 * lg < CD) ob_wr(CD * wave + 16 * dt + 4 * lg, 2 * pp + u, pk4(oT[dt][u] * inv[u]));
+        }
+        bar();                // O of the phase's four heads complete
+        // t += Wo2[:, the phase's heads] O     (25 fragments + 5 of padding)
+        layer(I5{}, I5{}, I0{}, &t[0][0], rdO);
+#pragma unroll
+        for (int i = 5; i < 10; ++i) (void)take(i);
+    }
+    add_bias(P_BO2);
+
+    // ---- GEGLU feed-forward, 20 chunks of 64 hidden units (16 per wave): g = W1 LN3(t) (20 fragments), t += W2 GEGLU(g) (10); the chunk's hidden
+    //      activations alternate between the two halves of hbuf: one barrier per chunk
+    layer_norm(P_LN3G, P_LN3B);
+    bar();
+#pragma unroll 1
+    for (int c = 0; c < 20; ++c) {
+        f32x4 g[2][8];      // row tiles: value, gate of the wave's 16 units
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) g[i][tt] = z4;
+        layer(I2{}, I10{}, I0{}, &g[0][0], rdA);
+        unsigned char* hb = hbuf + (c & 1) * 16384;
+        {
+            const int u = 64 * c + 16 * wave + 4 * lg;
+            const float4 bv = *(const float4*)(prm + P_B1V + u), bg = *(const float4*)(prm + P_B1G + u);
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                const vv_f32x2 g01 = gelu2((vv_f32x2){g[1][tt][0] + bg.x, g[1][tt][1] + bg.y});
+                const vv_f32x2 g23 = gelu2((vv_f32x2){g[1][tt][2] + bg.z, g[1][tt][3] + bg.w});
+                const f32x4 hv = {(g[0][tt][0] + bv.x) * g01.x, (g[0][tt][1] + bv.y) * g01.y, (g[0][tt][2] + bv.z) * g23.x, (g[0][tt][3] + bv.w) * g23.y};
+                const int ch = 16 * wave + 4 * lg;
+                *(uint2*)(hb + (16 * tt + li) * 128 + (((ch >> 3) ^ sA) << 4) + ((ch & 4) << 1)) = pk4(hv);
+            }
+        }
+        bar();
+        layer(I5{}, I2{}, I0{}, &t[0][0], [&](const int ks, const int tt) -> uint4 { return *(const uint4*)(hb + (16 * tt + li) * 128 + (((4 * ks + lg) ^ sA) << 4)); });
+    }
+    add_bias(P_B2);
+
+    // ---- proj_out (+ bias + x [+ res1]); the trunk goes to the activation buffer as h16 first
+    bar();                    // everybody is done with LN3's output
+#pragma unroll
+    for (int rt = 0; rt < 5; ++rt)
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) { act_wr(80 * wave + 16 * rt + 4 * lg, tt, pk4(t[rt][tt])); t[rt][tt] = z4; }
+    bar();
+    layer(I5{}, I10{}, I0{}, &t[0][0], rdA);
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+        const int64_t r = row0 + tt * 16 + li;
+        if (r < p.M) {
+            const int64_t row = r * CC;
+#pragma unroll
+            for (int rt = 0; rt < 5; ++rt) {
+                const int c = 80 * wave + 16 * rt + 4 * lg;
+                const float4 b = *(const float4*)(prm + P_BOUT + c);
+                const float4 xr = *(const float4*)(p.x + row + c);
+                float v0 = t[rt][tt][0] + b.x + xr.x, v1 = t[rt][tt][1] + b.y + xr.y, v2 = t[rt][tt][2] + b.z + xr.z, v3 = t[rt][tt][3] + b.w + xr.w;
+                if (p.res1) { const float4 r4 = *(const float4*)(p.res1 + row + c); v0 += r4.x; v1 += r4.y; v2 += r4.z; v3 += r4.w; }
+                if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + row + c) = make_float4(v0, v1, v2, v3);
+                else *(uint2*)((unsigned short*)p.out + row + c) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // Front half of the same block: everything BEFORE the self-attention core is per token too --
 //   t = Win GN(x) + bin        (GroupNorm apply with per-frame statistics + proj_in; t = the block's fp32 residual stream, written out for the tail)
@@ -1023,7 +1325,11 @@ extern "C" int vv_spatial_chain_c320(const vv_chain_params* pp, int dtype, void*
     if (p.C != CC || p.heads != CH || p.text_len != NKEY) VV_FAIL(VV_E_UNSUPPORTED, "vv_spatial_chain_c320: built for C = 320, 8 heads, 77 text tokens (got %d, %d, %d)", p.C, p.heads, p.text_len);
     if (p.M <= 0) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: empty input");
     if (p.out_dtype != VV_F32 && p.out_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: out_dtype mismatch");
-    if (p.n_slabs != N_SLABS || p.n_params != Q_TOTAL) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: stream / parameter block size mismatch (%d slabs, %d floats)", p.n_slabs, p.n_params);
+#ifndef VV_CHAIN_FORM
+#define VV_CHAIN_FORM 1    // 1 = row-split pairs (chain_rs_c320_kernel, packing layout "rowsplit": the product form); 2 = column-split (chain_cs_c320_kernel, layout "columns": lab); 0 = token-split forms (layout "tokens": lab)
+#endif
+    const int want_slabs = VV_CHAIN_FORM == 2 ? 4 * CS_FRAGS : N_SLABS;
+    if (p.n_slabs != want_slabs || p.n_params != Q_TOTAL) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: stream / parameter block size mismatch (%d slabs, %d floats)", p.n_slabs, p.n_params);
     const int64_t nblk = (p.M + 127) / 128;
     if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: grid too large");
     hipStream_t st = (hipStream_t)stream;
@@ -1036,10 +1342,10 @@ extern "C" int vv_spatial_chain_c320(const vv_chain_params* pp, int dtype, void*
 #ifndef VV_CHAIN_AHEAD
 #define VV_CHAIN_AHEAD 6
 #endif
-#ifndef VV_CHAIN_FORM
-#define VV_CHAIN_FORM 1    // 1 = row-split pairs (chain_rs_c320_kernel; stream order packing.pack_chain_stream(layout="rowsplit")); 0 = the token-split forms (lab A/B)
-#endif
-#if VV_CHAIN_FORM == 1
+#if VV_CHAIN_FORM == 2
+    if (dtype == VV_BF16) hipLaunchKernelGGL((chain_cs_c320_kernel<BF16>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else if (dtype == VV_F16) hipLaunchKernelGGL((chain_cs_c320_kernel<F16>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+#elif VV_CHAIN_FORM == 1
     if (dtype == VV_BF16) hipLaunchKernelGGL((chain_rs_c320_kernel<BF16>), dim3((unsigned)nblk), dim3(512), 0, st, p);
     else if (dtype == VV_F16) hipLaunchKernelGGL((chain_rs_c320_kernel<F16>), dim3((unsigned)nblk), dim3(512), 0, st, p);
 #else

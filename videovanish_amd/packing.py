@@ -154,7 +154,75 @@ def _head_k_columns(D):
     return torch.cat([torch.arange(32), 32 + p[ok]]), torch.cat([perm, d1[ok]])
 
 
-CHAIN_LAYOUT = "rowsplit"      # stream order of vv_chain.hip's product kernel (chain_rs_c320_kernel); "tokens": the round-3 / lab kernels (VV_CHAIN_FORM=0)
+# ---- column-split fused kernels (round 5): weights as one PRIVATE stream of MFMA A-operand fragments per wave, read straight into registers ----
+def _frag16(w2d, r0, k0):
+    """fragment (16 rows r0.., 32 k k0..) of a [N, K] fp32 matrix as the v_mfma_f32_16x16x32 A operand: [64 lanes][8] with lane l = row r0 + (l & 15),
+    k = k0 + 8 (l >> 4) + j (zero outside the matrix).  1 KB in h16: one global_load_dwordx4 per wave."""
+    N, K = w2d.shape
+    out = torch.zeros((16, 32), dtype=torch.float32)
+    r1, k1 = min(N, r0 + 16), min(K, k0 + 32)
+    if r1 > r0 and k1 > k0:
+        out[:r1 - r0, :k1 - k0] = w2d[r0:r1, k0:k1]
+    return out.reshape(16, 4, 8).permute(1, 0, 2).reshape(64, 8)          # [lg][li][j] -> lane = 16 lg + li
+
+
+def _frags(w2d, row_tiles, ksteps):
+    """fragments in consumption order: k step major, row tile minor.  row_tiles: first rows of the 16-row tiles."""
+    return [_frag16(w2d, r0, 32 * ks) for ks in range(ksteps) for r0 in row_tiles]
+
+
+CS_RING = 10      # the kernels keep this many fragments in flight per wave; every layer's fragment count is a multiple of it
+
+
+def _pad_ring(fr):
+    return fr + [torch.zeros((64, 8))] * (-len(fr) % CS_RING)
+
+
+def pack_chain_stream_columns(w, h16, heads=8):
+    """The tail of a level-0 spatial transformer block for vv_chain.hip::chain_cs_c320_kernel (column-split: wave w of a block owns output channels
+    80 w .. 80 w + 79 of every layer for all 128 tokens).  Returns (stream [4 * 870, 64, 8] h16: wave w's fragments at [870 w, 870 (w + 1)), params [5120]
+    fp32 = bo1 | ln2 g, b | bo2 | ln3 g, b | b1 values (1280) | b1 gates (1280) | b2 | bout).  Per wave, in order: Wo1 (50 fragments); for its two heads
+    (2 w, 2 w + 1): q projection padded to 48 rows (30), K_h (10: keys x packed d), V_h^T (9 + 1), the half of Wo2 that multiplies the four heads
+    (s, 2 + s, 4 + s, 6 + s) written by the four waves in that phase (25 + 5); twenty 64-unit GEGLU chunks: W1 rows [value 16 | gate 16]
+    of the wave's 16 units (20) and W2 (10); proj_out (50); 10 zero fragments (the ring reads ahead)."""
+    C = w["o1.w"].shape[0]
+    D = C // heads
+    assert C == 320 and D == 40 and heads == 8 and w["k2"].shape == (77, C) and w["v2"].shape == (77, C)
+    dst, src = _head_k_columns(D)
+    inner = 4 * C
+    streams = []
+    for wv in range(4):
+        own = [80 * wv + 16 * i for i in range(5)]
+        fr = _frags(w["o1.w"], own, 10)
+        for s_ in range(2):
+            h = 2 * wv + s_
+            wq = torch.zeros((48, C))
+            wq[:D] = w["q2.w"][h * D:(h + 1) * D]
+            fr += _frags(wq, [0, 16, 32], 10)
+            kh = torch.zeros((80, 64))                                     # K_h: rows = keys (77 -> 80), columns = d in the packed (PERM32) order
+            kh[:77, dst] = w["k2"][:, h * D + src]
+            fr += _frags(kh, [0, 16, 32, 48, 64], 2)
+            vt = torch.zeros((48, 96))                                     # V_h^T: rows = d, columns = keys, PERM32 inside every 32-key step
+            vt[:D, :77] = w["v2"][:, h * D:(h + 1) * D].t()
+            fr += _pad_ring(_frags(_permute_k(vt), [0, 16, 32], 3))
+            cols = torch.cat([torch.arange((2 * q + s_) * D, (2 * q + s_ + 1) * D) for q in range(4)])      # O buffer channel order: wave q's head
+            fr += _pad_ring(_frags(w["o2.w"][:, cols], own, 5))
+        for c in range(inner // 64):
+            u0 = 64 * c + 16 * wv
+            rows = torch.cat([torch.arange(u0, u0 + 16), inner + torch.arange(u0, u0 + 16)])
+            fr += _frags(w["ff1.w"][rows], [0, 16], 10)
+            fr += _frags(w["ff2.w"][:, 64 * c:64 * c + 64], own, 2)
+        fr += _frags(w["out.w"], own, 10)
+        fr += [torch.zeros((64, 8))] * CS_RING
+        assert len(fr) == 870, len(fr)
+        streams.append(torch.stack(fr))
+    stream = torch.cat(streams).to(h16)
+    params = torch.cat([w["o1.b"], w["ln2.g"], w["ln2.b"], w["o2.b"], w["ln3.g"], w["ln3.b"], w["ff1.b"], w["ff2.b"], w["out.b"]]).float()
+    assert stream.shape[0] == 3480 and params.numel() == 5120
+    return stream.contiguous(), params.contiguous()
+
+
+CHAIN_LAYOUT = "rowsplit"      # stream layout of vv_chain.hip's product kernel (chain_rs_c320_kernel); "columns" / "tokens": the lab kernels (VV_CHAIN_FORM = 2 / 0)
 
 
 def pack_chain_stream(w, h16, heads=8, layout=None):
@@ -165,6 +233,8 @@ def pack_chain_stream(w, h16, heads=8, layout=None):
     that row tiles (0, 1) / (2, 3) of its two slab groups are [value | gate] of hidden units 0..15 / 32..47 and 16..31 / 48..63: the wave that owns
     row half hf of every slab then produces exactly k step hf of the second projection."""
     layout = layout or CHAIN_LAYOUT
+    if layout == "columns":
+        return pack_chain_stream_columns(w, h16, heads)
     assert layout in ("rowsplit", "tokens")
     C = w["o1.w"].shape[0]
     D = C // heads
