@@ -65,11 +65,11 @@ def strong_scaling(args, model, dist, rank, world, H, W, ucfg, vcfg):
     dev = model.ctx.device
 
     def barrier():
-        torch.cuda.synchronize()
+        model._sync()
         if world > 1:
             import torch.distributed as td
             td.barrier()
-            torch.cuda.synchronize()
+            model._sync()
 
     if args.warmup > 0:      # one chunk, untimed: kernels loaded, allocator warm (and one RCCL round trip)
         fr = torch.from_numpy(np.stack([frames[0]] * args.chunk)).to(dev)
@@ -105,6 +105,10 @@ def strong_scaling(args, model, dist, rank, world, H, W, ucfg, vcfg):
     if rank != 0:
         return None
     assert all(o is not None and o.shape == (H, W, 3) and o.dtype == np.uint8 for o in out)
+    digest = None
+    if args.dry_run:
+        import hashlib
+        digest = hashlib.sha256(np.stack(out).tobytes()).hexdigest()
     fl = flops.per_output_frame(H, W, args.chunk, args.denoise_steps, ucfg, vcfg) * args.chunk * len(plan) * reps
     ideal = len(plan) / max(len(s) for s in shard_chunks(len(plan), world))
     return {
@@ -117,7 +121,114 @@ def strong_scaling(args, model, dist, rank, world, H, W, ucfg, vcfg):
                    "frames": T, "chunks": len(plan), "parallelism": f"chunk-dp{world}", "ideal_speedup_from_chunk_quantisation": round(ideal, 3),
                    "precise_decoder": bool(args.precise_decoder)},
         "job_tflops": round(fl / dt / 1e12, 1), "collective_backend": backend, "ranks_seen": ranks_seen,
-        "per_rank_seconds": per_rank,
+        "per_rank_seconds": per_rank, **({"dry_run": True, "output_sha256": digest} if args.dry_run else {}),
+    }
+
+
+def kernel_table(prof):
+    """hip.PROFILE records -> {key: [launches, seconds, flops, algorithmic bytes]}"""
+    kernels = {}
+    for key, fl, nbytes, e0, e1 in prof:
+        k = kernels.setdefault(key, [0, 0.0, 0.0, 0.0])
+        k[0] += 1; k[1] += e0.elapsed_time(e1) * 1e-3; k[2] += fl; k[3] += nbytes
+    return kernels
+
+
+def full_pipeline_c5(args, run, rank, world, dist, H, W, ucfg, vcfg):
+    """BASELINE config 5 (--prior raft --dilate K): the WHOLE drop-in call diffuerase.run_infill_on_frames -- mask collapse + dilation, RAFT
+    (20 GRU iterations) + flow-guided propagation prior, VAE / denoise / decode per chunk, overlap blend, compose, resize-back, feathered
+    composite -- on one synthetic clip of steps x 24 + 8 frames, timed host memory -> host memory.  Credited frames = 24 per chunk like the
+    default line.  The priced pass (one stream, one 32-frame clip, HIP events per launch) gives the prior's kernels -- all-pairs correlation
+    GEMM, pyramid pooling, correlation lookup, GRU element-wise kernels, convex upsampling, the bilinear warps of the propagation -- with
+    their achieved rate against the HBM (or MFMA) peak; algorithmic bytes per launch as SURVEY 8(d) defines them (operands read once +
+    result written once; the lookup: 4 levels x 10 x 10 window samples x 4 B + 324 x 2 B per pixel and iteration)."""
+    import diffuerase
+    from videovanish_amd import flops, hip
+    stride = args.chunk - args.overlap
+    K = max(1, args.steps)
+    T = stride * K + args.overlap
+    diffuerase.configure(run=run, dist=dist, gather="rank0")
+
+    def clip(n, t0=0):
+        fr, mk, _ = synth_clip(n, H, W, seed=1234, t0=t0)
+        return list(fr), [np.repeat(m[..., None], 3, axis=2) for m in mk]      # the GUI hands over 3-channel mask frames (reference :29)
+
+    def call(frames, masks, steps):
+        return diffuerase.run_infill_on_frames(frames, masks, mask_dilation_iter=args.dilate, propainer_frames=None, max_img_size=max(H, W),
+                                               num_inference_steps=steps, scheduler="ddim")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as td
+            td.barrier()
+            torch.cuda.synchronize()
+
+    if args.warmup > 0:      # one chunk, 2 denoise steps: every kernel of the path loaded, models built, allocator warm
+        fw, mw = clip(args.chunk)
+        call(fw, mw, min(2, args.denoise_steps))
+    frames, masks = clip(T)
+    power = PowerTrace(int(os.environ.get("LOCAL_RANK", "0"))) if (rank == 0 and not args.no_power_trace) else None
+    barrier()
+    t0 = time.time()
+    if power is not None:
+        power.__enter__()
+    out = call(frames, masks, args.denoise_steps)
+    barrier()
+    dt = time.time() - t0
+    if power is not None:
+        power.__exit__()
+    if world > 1:
+        import torch.distributed as td
+        tt = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        return None
+    assert len(out) == T and all(o is not None and o.shape == (H, W, 3) and o.dtype == np.uint8 for o in out)
+    # ---- priced pass: one 32-frame clip through the same call on one stream
+    prior_tab, prior_s, priced_s, dom = None, None, None, None
+    if not args.no_kernel_events:
+        fw, mw = clip(args.chunk)
+        torch.cuda.synchronize()
+        hip.PROFILE = []
+        t1 = time.time()
+        call(fw, mw, args.denoise_steps)
+        torch.cuda.synchronize()
+        priced_s = time.time() - t1
+        prof, hip.PROFILE = hip.PROFILE, None
+        kernels = kernel_table(prof)
+        prior_s = sum(v[1] for k, v in kernels.items() if k.startswith("prior:"))
+        prior_tab = {}
+        for k, v in sorted(kernels.items(), key=lambda kv: -kv[1][1]):
+            if not (k.startswith("prior:") or k in ("mask_collapse_dilate", "feather_composite", "resize_u8")):
+                continue
+            n, tsec, fl, by = v
+            if fl > 0:
+                prior_tab[k] = {"launches": n, "seconds": round(tsec, 4), "bound": "mfma", "achieved_tflops": round(fl / tsec / 1e12, 1), "frac": round(fl / tsec / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+            else:
+                prior_tab[k] = {"launches": n, "seconds": round(tsec, 4), "bound": "hbm", "achieved_gbs": round(by / tsec / 1e9, 1), "frac": round(by / tsec / 1e9 / HBM_PEAK_GBS, 4),
+                                "algorithmic_bytes_per_launch": by / n}
+        dk = max(kernels, key=lambda k: kernels[k][1])
+        n, tsec, fl, by = kernels[dk]
+        dom = {"kernel": dk, "bound": "mfma" if fl > 0 else "hbm", "achieved": round((fl / tsec / 1e12) if fl > 0 else (by / tsec / 1e9), 2),
+               "peak": MFMA_PEAK_TFLOPS if fl > 0 else HBM_PEAK_GBS, "unit": "TFLOP/s" if fl > 0 else "GB/s",
+               "frac": round(((fl / tsec / 1e12) / MFMA_PEAK_TFLOPS) if fl > 0 else ((by / tsec / 1e9) / HBM_PEAK_GBS), 4), "traffic": None,
+               "launches": n, "avg_launch_ms": round(tsec / n * 1e3, 4), "share_of_step_time": round(tsec / priced_s, 3)}
+    credited = stride * K * world
+    return {
+        "metric": f"inpainted frames/sec at {H}p, {args.denoise_steps} denoise steps", "value": round(credited / dt, 5), "unit": "frames/s", "n_gpus": world,
+        "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 2), "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"c5: {T}-frame {W}x{H} clip through diffuerase.run_infill_on_frames with NO prior handed over: mask dilation {args.dilate} + RAFT (20 it.) "
+                               f"flow-propagation prior + {args.denoise_steps} DDIM steps per {args.chunk}/{args.overlap} chunk + blend + compose + feathered composite, "
+                               f"timed host memory -> host memory, {args.arch} width, random-init weights",
+                   "frames": T, "credited_frames": credited, "parallelism": f"chunk-dp{world}", "precise_decoder": bool(args.precise_decoder)},
+        "roofline": dom, "prior": None if prior_tab is None else {"seconds_per_32_frames": round(prior_s, 3), "share_of_priced_clip": round(prior_s / priced_s, 4),
+                                                                   "kernels": prior_tab},
+        "kernel_pricing": None if priced_s is None else {"how": "single-stream pass", "frames": args.chunk, "seconds": round(priced_s, 3)},
+        "cpu_baseline": None, "power": power.summary() if power is not None else None,
+        "job_tflops": round(flops.per_output_frame(H, W, args.chunk, args.denoise_steps, ucfg, vcfg) * args.chunk * K * world / dt / 1e12, 1),
     }
 
 
@@ -210,7 +321,10 @@ def cpu_baseline(H, W, steps, chunk, overlap, sample_hw=(256, 384), vae_hw=(192,
     from videovanish_amd import flops
     from videovanish_amd.config import UNetConfig, VAEConfig
     ucfg, vcfg = UNetConfig(), VAEConfig()
-    cores = min(32, os.cpu_count() or 1)      # a modest pool: one thread per core of a 128+-core host is SLOWER on this small-tensor oracle
+    # threads: SURVEY 8(d) says os.cpu_count(); on the GPU box (128+ logical CPUs) the small-tensor oracle is SLOWER with one thread per CPU than with a
+    # modest pool, so 32 are used and both numbers are stated (`cores` = threads used, `host_cpus` = os.cpu_count()); `extrapolated`: the sample is one
+    # denoise step + one VAE pass at reduced size, scaled to the job by the algorithmic FLOP model -- a baseline, not a measurement of the full job
+    cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     P = M.Params(0)
     sh, sw = sample_hw
@@ -236,7 +350,7 @@ def cpu_baseline(H, W, steps, chunk, overlap, sample_hw=(256, 384), vae_hw=(192,
     fl = flops.denoise_step_per_frame(h, w, sample_frames, ucfg) * sample_frames + enc + dec
     tfs = fl / (t_step + t_vae) / 1e12
     per_frame = flops.per_output_frame(H, W, chunk, steps, ucfg, vcfg) * chunk / float(chunk - overlap)
-    return {"value": tfs * 1e12 / per_frame, "unit": "frames/s", "cores": cores, "kind": "port", "cpu_tflops": round(tfs, 4),
+    return {"value": tfs * 1e12 / per_frame, "unit": "frames/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port", "extrapolated": True, "cpu_tflops": round(tfs, 4),
             "sample": f"{sample_frames}-frame clip: one denoise step at {sw}x{sh} ({t_step:.1f}s) + one VAE encode+decode at {vae_hw[1]}x{vae_hw[0]} ({t_vae:.1f}s), "
                       f"{fl / 1e12:.2f} TFLOP; scaled by the algorithmic FLOP model to {steps} steps + 2 enc + 1 dec per {W}x{H} frame, "
                       f"x{chunk / float(chunk - overlap):.2f} chunk overlap"}
@@ -265,6 +379,13 @@ def main():
     ap.add_argument("--lanes", type=int, default=None, help="chunks of one rank in flight at once, each on its own HIP stream "
                     "(RunConfig.concurrent_chunks; default: the product default)")
     ap.add_argument("--one-stream", action="store_true", help="A/B: the round-3 schedule (one chunk at a time, BrushNet and UNet on one stream)")
+    ap.add_argument("--dry-run", action="store_true", help="host logic only: gloo instead of RCCL, CPU tensors, pipeline.DryRunEraser instead of the model "
+                    "(no kernels, nothing is inpainted, every number of the line is meaningless) -- the sharding / exchange / gather / timing "
+                    "plumbing of the N-GPU lines exercised without a GPU (tests/test_dist_cpu.py); adds `output_sha256`")
+    ap.add_argument("--prior", default="none", choices=["none", "raft"], help="raft = BASELINE config 5: no prior is handed over; the RAFT (20 iterations) + "
+                    "flow-guided propagation prior, the mask dilation and the feathered composite run INSIDE the timed region through "
+                    "diffuerase.run_infill_on_frames, host memory -> host memory (reference diffuerase.py:27-31,47-57,69-112)")
+    ap.add_argument("--dilate", type=int, default=8, help="--prior raft: mask_dilation_iter of the drop-in call (reference default 8)")
     ap.add_argument("--dump-kernels", default=None, help="write the raw per-kernel table (launches, seconds, flops, bytes) to this JSON file")
     ap.add_argument("--profile-shapes", action="store_true", help="per-kernel keys carry the GEMM / attention shapes (M, N, K): tools/shape_table.py")
     args = ap.parse_args()
@@ -279,11 +400,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
+    if not args.dry_run:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dry_run:
+            td.init_process_group("gloo")
+        else:
+            td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = (rank, world)
 
     from videovanish_amd import hip
@@ -293,9 +418,23 @@ def main():
     ucfg, vcfg = {"full": (UNetConfig(), VAEConfig()), "small": (SMALL_UNET, SMALL_VAE), "tiny": (TINY_UNET, TINY_VAE)}[args.arch]
     run = RunConfig(steps=args.denoise_steps, chunk=args.chunk, overlap=args.overlap, seed=42, weight_seed=0, dtype=args.dtype, unet=ucfg, vae=vcfg,
                     precise_decoder=args.precise_decoder, **({"concurrent_chunks": args.lanes} if args.lanes else {}))
+    if args.prior == "raft":      # BASELINE config 5: the whole drop-in call, prior included (builds its own models through the drop-in's cache)
+        res = full_pipeline_c5(args, run, rank, world, dist, args.height, args.width, ucfg, vcfg)
+        if rank == 0:
+            print(json.dumps(res))
+        if world > 1:
+            import torch.distributed as td
+            td.destroy_process_group()
+        return
     t_build = time.time()
-    model = DiffuEraserHIP(run, f"cuda:{local_rank}")
-    torch.cuda.synchronize()
+    if args.dry_run:
+        from videovanish_amd.pipeline import DryRunEraser
+        if args.frames <= 0:
+            raise SystemExit("bench.py --dry-run needs --frames T (the fixed-clip form)")
+        model = DryRunEraser(run, "cpu")
+    else:
+        model = DiffuEraserHIP(run, f"cuda:{local_rank}")
+        torch.cuda.synchronize()
     t_build = time.time() - t_build
     H, W = args.height, args.width
     stride = args.chunk - args.overlap
@@ -310,6 +449,8 @@ def main():
             td.destroy_process_group()
         return
 
+    host_inputs = []
+
     def resident_inputs(n_chunks_per_rank):
         """This rank's slice of a (world * n) -chunk synthetic video, uploaded BEFORE the timed region."""
         T = stride * n_chunks_per_rank * world + args.overlap
@@ -318,6 +459,7 @@ def main():
         mine = shard_chunks(len(plan), world)[rank]
         base, end = plan[mine[0]][0], plan[mine[-1]][1]
         fr, mk, pr = synth_clip(end - base, H, W, seed=1234 + rank, t0=base)
+        host_inputs[:] = [fr, pr, mk]
         return T, base, torch.from_numpy(fr).to(dev), torch.from_numpy(pr).to(dev), torch.from_numpy(mk).to(dev)
 
     def barrier():
@@ -349,6 +491,18 @@ def main():
         dt = float(tt.item())
     distinct = stride * args.steps * world          # credited frames: every chunk contributes (chunk - overlap) new frames
     assert out is not None and out.dtype == torch.uint8 and out.shape[1:] == (H, W, 3)
+    # SURVEY 8(d) defines the metric host memory -> host memory; `value` keeps the inputs resident (the driver contract), the copies this rank would add
+    # are measured right here on the same tensors and reported beside it (`host_to_host`)
+    torch.cuda.synchronize()
+    t_up = time.time()
+    ups = [torch.from_numpy(a).to(dev) for a in host_inputs]
+    torch.cuda.synchronize()
+    t_up = time.time() - t_up
+    del ups
+    t_down = time.time()
+    out_host = out.cpu()
+    t_down = time.time() - t_down
+    del out_host
 
     if rank != 0:
         if world > 1:
@@ -418,6 +572,9 @@ def main():
                                                  "kernel_seconds": round(sum(v[1] for v in kernels.values()), 3),
                                                  "note": "one chunk of the same resident inputs re-run after the timed region on ONE stream, every launch bracketed "
                                                          "by HIP events on its launch stream; the timed region itself overlaps kernels of several streams"},
+        "host_to_host": {"value": round(distinct / (dt + t_up + t_down), 5), "unit": "frames/s", "upload_s": round(t_up, 4), "download_s": round(t_down, 4),
+                         "note": "SURVEY 8(d) form of the metric: the same timed region plus this rank's synchronous upload of its uint8 frames / prior / masks and "
+                                 "download of its uint8 output (pageable host memory, measured on the same tensors right after the timed region)"},
         "roofline": roof, "temporal_block": temporal, "cpu_baseline": cpu, "power": power.summary() if power is not None else None,
         "job_tflops": round(__import__("videovanish_amd.flops", fromlist=["x"]).per_output_frame(H, W, args.chunk, args.denoise_steps, ucfg, vcfg)
                             * args.chunk * args.steps * world / dt / 1e12, 1),

@@ -90,8 +90,12 @@ def run_infill_on_frames(frames_rgb, mask_frames, mask_dilation_iter=8, ckpt="2-
             w, stages = _resolve_weights("2-Step")
             propainter = Propainter("ruffy369/propainter", device=device, weights=w if (w is not None and "raft" in w.components) else None, **stages)
         if prog is not None: prog(20, "running propainter prior")
-        propainer_frames = propainter.forward(frames_rgb, dilated_mask_frames, ref_stride=10, neighbor_length=10,
-                                              subvideo_length=50, mask_dilation=0, progress=prog)
+        prev_tag, hip.PROFILE_TAG = hip.PROFILE_TAG, "prior:"                   # bench.py --prior raft prices the prior's kernels under this prefix
+        try:
+            propainer_frames = propainter.forward(frames_rgb, dilated_mask_frames, ref_stride=10, neighbor_length=10,
+                                                  subvideo_length=50, mask_dilation=0, progress=prog)
+        finally:
+            hip.PROFILE_TAG = prev_tag
 
     if prog is not None: prog(50, "running DiffuEraser")
     guidance_scale = None

@@ -124,3 +124,60 @@ def test_host_plan_matches_oracle():
     assert PL.ddim_timesteps(50) == R.M.ddim_timesteps(50) and PL.tcd_timesteps(2) == R.M.tcd_timesteps(2)
     assert torch.equal(PL.alphas_cumprod(), R.M.alphas_cumprod())
     assert torch.equal(PL.chunk_noise(42, 3, (2, 4, 5, 6)), R.chunk_noise(42, 3, (2, 4, 5, 6)))
+
+
+def test_streaming_blend_holds_only_chunks_in_flight():
+    """StreamingBlend (round 5): chunks are consumed in canonical order as soon as their predecessors exist and dropped -- fed in order the blender never
+    holds more than ONE decoded chunk, fed in the worst order two lanes can produce (k + 1 before k) never more than two; the result is bit for bit
+    the one-shot blend of the complete set."""
+    T, chunk, overlap, H, W = 200, 32, 8, 4, 5
+    plan = PL.chunk_plan(T, chunk, overlap)
+    wts = PL.blend_weights(plan)
+    owner, chunk_rank = PL.frame_owner(plan, PL.shard_chunks(len(plan), 1))
+    dec = {ci: _fake_decoded(ci, plan[ci][1] - plan[ci][0], H, W) for ci in range(len(plan))}
+    ref, _ = PL.exchange_and_blend(plan, wts, owner, chunk_rank, 0, 1, dict(dec), (H, W), torch.device("cpu"), blend_fn=_cpu_blend)
+    for order, bound in ((list(range(len(plan))), 1), ([i ^ 1 if (i ^ 1) < len(plan) else i for i in range(len(plan))], 2)):
+        sb = PL.StreamingBlend(plan, wts, owner, chunk_rank, 0, 1, list(range(len(plan))), (H, W), torch.device("cpu"), blend_fn=_cpu_blend)
+        for ci in order:
+            sb.add(ci, dec[ci])
+        acc, (lo, hi) = sb.finish()
+        assert (lo, hi) == (0, T) and sb.max_pending <= bound and not sb.pending
+        assert torch.equal(acc, ref)
+    with pytest.raises(AssertionError):
+        sb = PL.StreamingBlend(plan, wts, owner, chunk_rank, 0, 1, list(range(len(plan))), (H, W), torch.device("cpu"), blend_fn=_cpu_blend)
+        sb.add(1, dec[1])
+        sb.finish()
+
+
+def _bench_dry_run(world, T, H=16, W=24):
+    """bench.py --dry-run --frames T launched as the driver launches the N-GPU lines (one process per rank, RANK / WORLD_SIZE / MASTER_* in the
+    environment), over gloo with the CPU model stub: returns rank 0's JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--dry-run", "--frames", str(T), "--height", str(H),
+                                       "--width", str(W), "--steps", "1", "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (_, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-2000:]
+    assert all(not any(ln.startswith("{") for ln in o.splitlines()) for o, _ in outs[1:])      # only rank 0 prints a result line (gloo prints its own banner)
+    return json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("world,T,shards", [(4, 256, [3, 3, 3, 2]), (8, 1024, [6, 6, 6, 5, 5, 5, 5, 5])])
+def test_bench_dry_run_multi_rank_equals_one_rank(world, T, shards):
+    """The fixed-clip bench lines of BASELINE configs 3 / 4 (256 frames over 4 ranks, 1024 over 8) through bench.py ITSELF -- chunk plan, per-rank inputs,
+    streaming blend + overlap exchange, gather to rank 0, max-over-ranks timing all-reduce, `ranks_seen` -- under gloo: the collected frames are bit for
+    bit those of the one-rank run.  Unmeasured on hardware: no multi-GPU box in the build pool."""
+    one = _bench_dry_run(1, T)
+    many = _bench_dry_run(world, T)
+    assert one["dry_run"] and many["dry_run"] and one["n_gpus"] == 1 and many["n_gpus"] == world
+    assert many["ranks_seen"] == world and many["collective_backend"] == "gloo" and len(many["per_rank_seconds"]) == world
+    assert f"sharded {shards}" in many["config"]["workload"] and many["config"]["chunks"] == sum(shards)
+    assert many["output_sha256"] == one["output_sha256"]
+    assert all("exchange_blend_s" in t and "upload_s" in t for t in many["per_rank_seconds"])

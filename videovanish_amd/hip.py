@@ -446,7 +446,8 @@ def mask_collapse_dilate(masks, iters):
     out = torch.empty((T, H, W), dtype=torch.uint8, device=masks.device)
     tmp = torch.empty_like(out)
     flags = torch.empty(T, dtype=torch.int32, device=masks.device)
-    _check(lib().vv_mask_collapse_dilate(_p(masks), T, H, W, ch, int(iters), _p(out), _p(tmp), _p(flags), _stream()), "vv_mask_collapse_dilate")
+    with _Prof("mask_collapse_dilate", 0.0, T * H * W * (ch + 1)):
+        _check(lib().vv_mask_collapse_dilate(_p(masks), T, H, W, ch, int(iters), _p(out), _p(tmp), _p(flags), _stream()), "vv_mask_collapse_dilate")
     return out
 
 
@@ -456,7 +457,8 @@ def resize_u8(src, Hd, Wd, mode="bilinear"):
     T, Hs, Ws, ch = s4.shape
     dst = torch.empty((T, Hd, Wd, ch), dtype=torch.uint8, device=src.device)
     fn = lib().vv_resize_bilinear_u8 if mode == "bilinear" else lib().vv_resize_nearest_u8
-    _check(fn(_p(src), T, Hs, Ws, ch, _p(dst), Hd, Wd, _stream()), "vv_resize_u8")
+    with _Prof("resize_u8", 0.0, src.numel() + dst.numel()):
+        _check(fn(_p(src), T, Hs, Ws, ch, _p(dst), Hd, Wd, _stream()), "vv_resize_u8")
     return dst if src.dim() == 4 else dst[..., 0]
 
 
@@ -464,7 +466,8 @@ def feather_composite(inpainted, orig, mask2d, feather_px):
     _need_cuda(inpainted, orig, mask2d)
     T, H, W, _ = inpainted.shape
     out = torch.empty_like(inpainted)
-    _check(lib().vv_feather_composite(_p(inpainted), _p(orig), _p(mask2d), T, H, W, C.c_float(feather_px), _p(out), _stream()), "vv_feather_composite")
+    with _Prof("feather_composite", 0.0, T * H * W * (3 + 3 + 1 + 3)):
+        _check(lib().vv_feather_composite(_p(inpainted), _p(orig), _p(mask2d), T, H, W, C.c_float(feather_px), _p(out), _stream()), "vv_feather_composite")
     return out
 
 
@@ -606,7 +609,8 @@ def avgpool2(x):
     _need_cuda(x)
     N, h, w = x.shape
     out = torch.empty((N, h // 2, w // 2), dtype=torch.float32, device=x.device)
-    _check(lib().vv_avgpool2_f32(_p(x), C.c_int64(N), h, w, _p(out), _stream()), "vv_avgpool2_f32")
+    with _Prof("avgpool2[corr pyramid]", 0.0, x.numel() * 5):
+        _check(lib().vv_avgpool2_f32(_p(x), C.c_int64(N), h, w, _p(out), _stream()), "vv_avgpool2_f32")
     return out
 
 
@@ -615,40 +619,47 @@ def corr_lookup(dtype, pyr, coords, cpad=384):
     _need_cuda(*pyr, coords)
     N, h, w = pyr[0].shape
     out = torch.empty((N, cpad), dtype=h16(dtype), device=coords.device)
-    _check(lib().vv_corr_lookup(_p(pyr[0]), _p(pyr[1]), _p(pyr[2]), _p(pyr[3]), h, w, _p(coords), C.c_int64(N), cpad, _p(out), dtype, _stream()),
-           "vv_corr_lookup")
+    with _Prof("corr_lookup", 0.0, N * (4 * 100 * 4 + 324 * 2 + 8)):
+        _check(lib().vv_corr_lookup(_p(pyr[0]), _p(pyr[1]), _p(pyr[2]), _p(pyr[3]), h, w, _p(coords), C.c_int64(N), cpad, _p(out), dtype, _stream()),
+               "vv_corr_lookup")
     return out
 
 
 def raft_ctx_split(dtype, cn, net, net16, xbuf):
     _need_cuda(cn, net, net16, xbuf)
-    _check(lib().vv_raft_ctx_split(_p(cn), C.c_int64(cn.shape[0]), _p(net), _p(net16), _p(xbuf), dtype, _stream()), "vv_raft_ctx_split")
+    with _Prof("raft_elementwise", 0.0, cn.numel() * 4 + net.numel() * 6 + xbuf.shape[0] * 256):
+        _check(lib().vv_raft_ctx_split(_p(cn), C.c_int64(cn.shape[0]), _p(net), _p(net16), _p(xbuf), dtype, _stream()), "vv_raft_ctx_split")
 
 
 def raft_flow_prep(dtype, coords1, w, h, flow8, xbuf):
     _need_cuda(coords1, flow8, xbuf)
-    _check(lib().vv_raft_flow_prep(_p(coords1), C.c_int64(coords1.shape[0]), w, h, _p(flow8), _p(xbuf), dtype, _stream()), "vv_raft_flow_prep")
+    with _Prof("raft_elementwise", 0.0, coords1.numel() * 4 + flow8.numel() * 2 + coords1.shape[0] * 4):
+        _check(lib().vv_raft_flow_prep(_p(coords1), C.c_int64(coords1.shape[0]), w, h, _p(flow8), _p(xbuf), dtype, _stream()), "vv_raft_flow_prep")
 
 
 def gru_rh(dtype, zr, h, rh):
     _need_cuda(zr, h, rh)
-    _check(lib().vv_gru_rh(_p(zr), _p(h), C.c_int64(h.shape[0]), _p(rh), dtype, _stream()), "vv_gru_rh")
+    with _Prof("raft_elementwise", 0.0, h.numel() * (2 + 4 + 2)):
+        _check(lib().vv_gru_rh(_p(zr), _p(h), C.c_int64(h.shape[0]), _p(rh), dtype, _stream()), "vv_gru_rh")
 
 
 def gru_update(dtype, zr, q, h, h16_out):
     _need_cuda(zr, q, h, h16_out)
-    _check(lib().vv_gru_update(_p(zr), _p(q), C.c_int64(h.shape[0]), _p(h), _p(h16_out), dtype, _stream()), "vv_gru_update")
+    with _Prof("raft_elementwise", 0.0, h.numel() * (4 + 2 + 4 + 4 + 2)):
+        _check(lib().vv_gru_update(_p(zr), _p(q), C.c_int64(h.shape[0]), _p(h), _p(h16_out), dtype, _stream()), "vv_gru_update")
 
 
 def add_flow(coords1, dflow):
     _need_cuda(coords1, dflow)
-    _check(lib().vv_add_flow(_p(coords1), _p(dflow), dflow.shape[-1], C.c_int64(coords1.shape[0]), _stream()), "vv_add_flow")
+    with _Prof("raft_elementwise", 0.0, coords1.numel() * 12):
+        _check(lib().vv_add_flow(_p(coords1), _p(dflow), dflow.shape[-1], C.c_int64(coords1.shape[0]), _stream()), "vv_add_flow")
 
 
 def add_relu(a, b):
     _need_cuda(a, b)
     out = torch.empty_like(a)
-    _check(lib().vv_add_relu_f32(_p(a), _p(b), _p(out), C.c_int64(a.numel()), _stream()), "vv_add_relu_f32")
+    with _Prof("add_relu", 0.0, a.numel() * 12):
+        _check(lib().vv_add_relu_f32(_p(a), _p(b), _p(out), C.c_int64(a.numel()), _stream()), "vv_add_relu_f32")
     return out
 
 
@@ -656,7 +667,8 @@ def convex_upsample(coords1, mask, h, w, F=1):
     """coords1 [F*h*w, 2], mask [F*h*w, 576] -> flow [8h, 8w, 2] (F = 1) or [F, 8h, 8w, 2]."""
     _need_cuda(coords1, mask)
     out = torch.empty((F, 8 * h, 8 * w, 2), dtype=torch.float32, device=coords1.device)
-    _check(lib().vv_convex_upsample(_p(coords1), _p(mask), F, h, w, _p(out), _stream()), "vv_convex_upsample")
+    with _Prof("convex_upsample", 0.0, mask.numel() * mask.element_size() + coords1.numel() * 4 + out.numel() * 4):
+        _check(lib().vv_convex_upsample(_p(coords1), _p(mask), F, h, w, _p(out), _stream()), "vv_convex_upsample")
     return out[0] if F == 1 else out
 
 
@@ -664,14 +676,16 @@ def fb_valid(f_ab, f_ba):
     _need_cuda(f_ab, f_ba)
     H, W, _ = f_ab.shape
     out = torch.empty((H, W), dtype=torch.uint8, device=f_ab.device)
-    _check(lib().vv_fb_valid(_p(f_ab), _p(f_ba), H, W, _p(out), _stream()), "vv_fb_valid")
+    with _Prof("fb_valid[bilinear warp of the backward flow]", 0.0, H * W * (8 + 8 + 1)):
+        _check(lib().vv_fb_valid(_p(f_ab), _p(f_ba), H, W, _p(out), _stream()), "vv_fb_valid")
     return out
 
 
 def prop_fill(cur_t, cur_nb, known_t, known_nb, valid, flow, filled_t):
     _need_cuda(cur_t, cur_nb, known_t, known_nb, valid, flow, filled_t)
     H, W, _ = cur_t.shape
-    _check(lib().vv_prop_fill(_p(cur_t), _p(cur_nb), _p(known_t), _p(known_nb), _p(valid), _p(flow), H, W, _p(filled_t), _stream()), "vv_prop_fill")
+    with _Prof("prop_fill[bilinear warp]", 0.0, H * W * (3 + 3 + 2 + 1 + 8 + 3)):
+        _check(lib().vv_prop_fill(_p(cur_t), _p(cur_nb), _p(known_t), _p(known_nb), _p(valid), _p(flow), H, W, _p(filled_t), _stream()), "vv_prop_fill")
 
 
 def prop_combine(orig, a, b, fa, fb, hole, mean3):
@@ -679,7 +693,8 @@ def prop_combine(orig, a, b, fa, fb, hole, mean3):
     H, W, _ = orig.shape
     out = torch.empty((H, W, 3), dtype=torch.uint8, device=orig.device)
     filled = torch.empty((H, W), dtype=torch.uint8, device=orig.device)
-    _check(lib().vv_prop_combine(_p(orig), _p(a), _p(b), _p(fa), _p(fb), _p(hole), H, W, _p(mean3), _p(out), _p(filled), _stream()), "vv_prop_combine")
+    with _Prof("prop_combine", 0.0, H * W * (3 * 3 + 3 + 3 + 1)):
+        _check(lib().vv_prop_combine(_p(orig), _p(a), _p(b), _p(fa), _p(fb), _p(hole), H, W, _p(mean3), _p(out), _p(filled), _stream()), "vv_prop_combine")
     return out, filled
 
 
@@ -709,7 +724,8 @@ def raft_prep(dtype, img):
     """u8 [..., 3] -> h16 [..., 8] scaled to [-1,1]."""
     _need_cuda(img)
     out = torch.empty(img.shape[:-1] + (8,), dtype=h16(dtype), device=img.device)
-    _check(lib().vv_raft_prep(_p(img), C.c_int64(img.numel() // 3), _p(out), dtype, _stream()), "vv_raft_prep")
+    with _Prof("raft_prep", 0.0, img.numel() + out.numel() * 2):
+        _check(lib().vv_raft_prep(_p(img), C.c_int64(img.numel() // 3), _p(out), dtype, _stream()), "vv_raft_prep")
     return out
 
 

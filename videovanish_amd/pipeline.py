@@ -101,43 +101,90 @@ def chunk_noise(seed, index, shape):
     return torch.randn(shape, generator=g, dtype=torch.float32)
 
 
+class StreamingBlend:
+    """The blend-time step as a STREAM (round 5): a rank's decoded chunks are consumed in canonical chunk order as soon as they
+    (and their predecessors) exist -- the frames another rank owns leave with a non-blocking send (torch.distributed.batch_isend_irecv: RCCL
+    point-to-point over xGMI on GPUs, gloo in the CPU tests), the frames this rank owns are cross-faded into its accumulator, and the chunk is
+    dropped: the memory held is O(chunks in flight), not O(chunks of the rank) (354 MB per decoded 720p chunk, 796 MB at 1080p).  Frames this
+    rank owns that a HIGHER rank's chunk also covers (the 8-frame overlap behind a rank boundary) are received at finish() and blended last:
+    every contribution to a frame comes from chunks in increasing index, the owner holds the lowest, so the order of the arithmetic -- and every
+    bit of the result -- is that of the single-process blend for any world size and any lane count.
+    blend_fn(dec, w, acc_view) defaults to the HIP kernel vv_decode_blend."""
+
+    def __init__(self, plan, wts, owner, chunk_rank, rank, world, mine, hw, dev, blend_fn=None):
+        self.plan, self.wts, self.owner, self.chunk_rank, self.rank, self.world = plan, wts, owner, chunk_rank, rank, world
+        self.mine, self.hw, self.dev, self.blend_fn = list(mine), hw, dev, blend_fn or hip.decode_blend
+        own_idx = np.nonzero(owner == rank)[0]
+        self.lo, self.hi = (int(own_idx[0]), int(own_idx[-1]) + 1) if len(own_idx) else (0, 0)
+        self.acc = torch.zeros((self.hi - self.lo, hw[0], hw[1], 3), dtype=torch.float32, device=dev) if self.hi > self.lo else None
+        self.pos, self.pending, self.max_pending, self.sends = 0, {}, 0, []
+
+    def _owned_span(self, ci, who):
+        s, e = self.plan[ci]
+        idx = np.nonzero(self.owner[s:e] == who)[0]
+        return (s + int(idx[0]), s + int(idx[-1]) + 1) if len(idx) else None
+
+    def _blend(self, ci, a, b, dec):
+        s, _ = self.plan[ci]
+        w = torch.from_numpy(self.wts[ci][a - s: b - s]).to(self.dev)
+        self.blend_fn(dec.contiguous(), w, self.acc[a - self.lo: b - self.lo])
+
+    def add(self, ci, dec):
+        """chunk ci of this rank is decoded (fp32 [F,H,W,3]); chunks may arrive out of order (several lanes), they are consumed in order."""
+        self.pending[ci] = dec
+        self.max_pending = max(self.max_pending, len(self.pending))
+        while self.pos < len(self.mine) and self.mine[self.pos] in self.pending:
+            c = self.mine[self.pos]
+            self._consume(c, self.pending.pop(c))
+            self.pos += 1
+
+    def _consume(self, ci, dec):
+        s, e = self.plan[ci]
+        if self.world > 1:
+            import torch.distributed as td
+            ops, keep = [], []
+            for dst in sorted(set(int(o) for o in self.owner[s:e]) - {self.rank}):
+                a, b = self._owned_span(ci, dst)
+                piece = dec[a - s: b - s].clone()          # its own storage: the chunk itself can go as soon as this call returns
+                keep.append(piece)
+                ops.append(td.P2POp(td.isend, piece, dst))
+            if ops:
+                self.sends.append((td.batch_isend_irecv(ops), keep))
+        span = self._owned_span(ci, self.rank)
+        if span is not None:
+            self._blend(ci, span[0], span[1], dec[span[0] - s: span[1] - s])
+
+    def finish(self):
+        """-> (acc [hi-lo,H,W,3] fp32 or None, (lo, hi)).  Receives and blends what higher ranks' chunks contribute to this rank's frames."""
+        assert self.pos == len(self.mine) and not self.pending, "StreamingBlend.finish() before every chunk of the rank was added"
+        if self.world > 1:
+            import torch.distributed as td
+            H, W = self.hw
+            want = []
+            for ci, (s, e) in enumerate(self.plan):
+                if self.chunk_rank[ci] != self.rank:
+                    span = self._owned_span(ci, self.rank)
+                    if span is not None:
+                        want.append((ci, span, torch.empty((span[1] - span[0], H, W, 3), dtype=torch.float32, device=self.dev)))
+            if want:
+                for wk in td.batch_isend_irecv([td.P2POp(td.irecv, buf, self.chunk_rank[ci]) for ci, _, buf in want]):
+                    wk.wait()
+                for ci, (a, b), buf in want:            # increasing chunk index = canonical order
+                    self._blend(ci, a, b, buf)
+            for works, _ in self.sends:
+                for wk in works:
+                    wk.wait()
+            self.sends = []
+        return self.acc, (self.lo, self.hi)
+
+
 def exchange_and_blend(plan, wts, owner, chunk_rank, rank, world, pending, hw, dev, blend_fn=None):
-    """Blend-time step.  pending: {chunk index: decoded fp32 [F,H,W,3]} for THIS rank's chunks.  Every rank hands the
-    decoded frames that another rank owns to that rank (torch.distributed send/recv: RCCL over xGMI on GPUs, gloo in the
-    CPU tests), then each owner blends its frames in canonical chunk order.  Returns (acc [hi-lo,H,W,3] fp32, (lo, hi))
-    for the frames this rank owns.  blend_fn(dec, w, acc_view) defaults to the HIP kernel vv_decode_blend."""
-    H, W = hw
-    blend_fn = blend_fn or hip.decode_blend
-    contrib = {}       # chunk index -> (first frame, decoded [n,H,W,3] fp32) for frames this rank owns
-    for ci, dec in pending.items():
-        s, e = plan[ci]
-        idx = [fi for fi in range(s, e) if owner[fi] == rank]
-        if idx:
-            contrib[ci] = (idx[0], dec[idx[0] - s: idx[-1] + 1 - s])
-    if world > 1:
-        import torch.distributed as td
-        for ci, (s, e) in enumerate(plan):
-            src = chunk_rank[ci]
-            for dst in sorted(set(int(o) for o in owner[s:e]) - {src}):
-                idx = [fi for fi in range(s, e) if owner[fi] == dst]
-                if rank == src:
-                    td.send(pending[ci][idx[0] - s: idx[-1] + 1 - s].contiguous(), dst)
-                elif rank == dst:
-                    buf = torch.empty((len(idx), H, W, 3), dtype=torch.float32, device=dev)
-                    td.recv(buf, src)
-                    contrib[ci] = (idx[0], buf)
-    own_idx = np.nonzero(owner == rank)[0]
-    if not len(own_idx):
-        return None, (0, 0)
-    lo, hi = int(own_idx[0]), int(own_idx[-1]) + 1
-    accT = torch.zeros((hi - lo, H, W, 3), dtype=torch.float32, device=dev)
-    for ci in sorted(contrib):                       # canonical chunk order
-        s, _ = plan[ci]
-        a, dec = contrib[ci]
-        b = a + dec.shape[0]
-        w = torch.from_numpy(wts[ci][a - s: b - s]).to(dev)
-        blend_fn(dec.contiguous(), w, accT[a - lo: b - lo])
-    return accT, (lo, hi)
+    """Blend-time step over a complete set of decoded chunks (pending: {chunk index: decoded fp32 [F,H,W,3]} of THIS rank): StreamingBlend fed in
+    chunk order.  Returns (acc [hi-lo,H,W,3] fp32, (lo, hi)) for the frames this rank owns."""
+    sb = StreamingBlend(plan, wts, owner, chunk_rank, rank, world, sorted(pending), hw, dev, blend_fn=blend_fn)
+    for ci in sorted(pending):
+        sb.add(ci, pending[ci])
+    return sb.finish()
 
 
 def reference_contexts(n, nframes=22, overlap=4):
@@ -220,6 +267,17 @@ class DiffuEraserHIP:
         self.ac = alphas_cumprod()
         self.taps = imageops.gaussian_taps_21()
         self.vae_batch = 4
+
+    # hooks the CPU dry-run stub (DryRunEraser) replaces; the product path is the HIP kernels
+    _blend_fn = None           # None = hip.decode_blend
+    _lanes_ok = True
+    last_blend = None          # the StreamingBlend of the last forward_device() call (tests read its high-water mark)
+
+    def _sync(self):
+        torch.cuda.synchronize()
+
+    def _compose(self, acc, fr, mk):
+        return hip.blur_compose(acc, fr, mk, self.taps)
 
     # -- one clip -------------------------------------------------------------------------------------------------
     def encode(self, img8, F, H, W):
@@ -333,13 +391,13 @@ class DiffuEraserHIP:
         else:
             base, fr, pr, mk = 0, None, None, None
         if timings is not None:
-            torch.cuda.synchronize()
+            self._sync()
             timings["upload_s"] = time.time() - t_0
             t_0 = time.time()
         res = self.forward_device(fr, pr, mk, T, base, steps=steps, scheduler=scheduler, progress=progress, dist=dist, return_float=return_float,
                                   timings=timings)
         if timings is not None:
-            torch.cuda.synchronize()
+            self._sync()
             timings["compute_s"] = time.time() - t_0
             t_0 = time.time()
         if return_float:
@@ -444,17 +502,22 @@ class DiffuEraserHIP:
         out = hip.blur_compose(pix, fr_orig, mk_orig, self.taps)
         return list(out.cpu().numpy())
 
-    def _run_chunks_concurrently(self, mine, lanes, run_chunk, pending, progress, nst):
+    def _run_chunks_concurrently(self, mine, lanes, run_chunk, sink, progress, nst):
         """`lanes` host threads, each with its own HIP stream, pull this rank's chunks from a shared counter (RunConfig.concurrent_chunks).
         Every chunk is computed by the same kernels on the same inputs as in the one-stream schedule (noise is seeded per chunk index),
-        so which lane ran it does not change a bit of the result.  The launching thread's stream waits for every lane at the end."""
+        so which lane ran it does not change a bit of the result.  Finished chunks are handed to `sink(chunk index, decoded)` ON THE LAUNCHING
+        THREAD (it owns the blend accumulator and every RCCL call) behind an event of the lane's stream, as they complete; a lane does not start
+        a chunk more than `lanes` positions ahead of the oldest one still running, so at most 2 * lanes decoded chunks exist at any time."""
+        import queue
         import threading
         dev = self.ctx.device
         main = torch.cuda.current_stream()
         pool = self.__dict__.setdefault("_lane_streams", [])
         while len(pool) < lanes:
             pool.append(torch.cuda.Stream(device=dev))
-        lock, nxt, done, errors = threading.Lock(), [0], [0], []
+        lock, nxt, done, errors = threading.Condition(), [0], [0], []
+        finished, handed = set(), [0]          # positions whose chunk is decoded; number of positions consumed in order by the sink side
+        results = queue.Queue()
         n_my = len(mine)
 
         def step_done(i, n):
@@ -475,17 +538,39 @@ class DiffuEraserHIP:
                         with lock:
                             k = nxt[0]
                             nxt[0] += 1
+                            while k < n_my and k - handed[0] > lanes and not errors:
+                                lock.wait(0.5)
                         if k >= n_my:
                             break
                         out = run_chunk(k, mine[k], step_done if progress is not None else None)
                         out.record_stream(main)        # allocated on the lane's stream, consumed (blend / send) on the launching one
-                        pending[mine[k]] = out
+                        ev = torch.cuda.Event()
+                        ev.record(stream)
+                        results.put((k, out, ev))
             except BaseException as exc:               # re-raised on the launching thread
                 errors.append(exc)
+            finally:
+                results.put(None)
 
         threads = [threading.Thread(target=worker, args=(pool[i], i * float(self.run.lane_stagger_s)), name=f"vv-chunk-lane-{i}") for i in range(lanes)]
         for t in threads:
             t.start()
+        alive = lanes
+        while alive:
+            item = results.get()
+            if item is None:
+                alive -= 1
+                continue
+            k, out, ev = item
+            main.wait_event(ev)
+            sink(mine[k], out)
+            del out, item
+            with lock:
+                finished.add(k)
+                while handed[0] in finished:
+                    finished.discard(handed[0])
+                    handed[0] += 1
+                lock.notify_all()
         for t in threads:
             t.join()
         for i in range(lanes):
@@ -506,7 +591,9 @@ class DiffuEraserHIP:
         owner, chunk_rank = frame_owner(plan, shards)
         mine = shards[rank]
         H, W = (fr.shape[1], fr.shape[2]) if fr is not None else (0, 0)
-        pending = {}       # chunk index -> decoded fp32 [F,H,W,3], kept until blended / sent
+        # decoded chunks are blended / sent as they complete and dropped (StreamingBlend): O(lanes) of them exist at any time
+        blender = StreamingBlend(plan, wts, owner, chunk_rank, rank, world, mine, (H, W), dev, blend_fn=self._blend_fn)
+        self.last_blend = blender
         n_my = len(mine)
         nst = steps or run.steps
 
@@ -521,27 +608,62 @@ class DiffuEraserHIP:
                                       scheduler=scheduler, tcd_noise=tcd_noise, progress=cb)
 
         lanes = max(1, min(int(run.concurrent_chunks), n_my))
-        if hip.PROFILE is not None:
+        if hip.PROFILE is not None or not self._lanes_ok:
             lanes = 1              # per-kernel HIP events only mean something on one stream
         if lanes == 1:
             for k, ci in enumerate(mine):
                 cb = None
                 if progress is not None:
                     cb = lambda i, n, k=k: progress(k * n + i, n_my * n)
-                pending[ci] = run_chunk(k, ci, cb)
+                blender.add(ci, run_chunk(k, ci, cb))
         else:
-            self._run_chunks_concurrently(mine, lanes, run_chunk, pending, progress, nst)
+            self._run_chunks_concurrently(mine, lanes, run_chunk, blender.add, progress, nst)
         if timings is not None:
             import time
-            torch.cuda.synchronize()
+            self._sync()
             t_x = time.time()
-        accT, (lo, hi) = exchange_and_blend(plan, wts, owner, chunk_rank, rank, world, pending, (H, W), dev)
+        accT, (lo, hi) = blender.finish()
         if timings is not None:
-            torch.cuda.synchronize()
+            self._sync()
             timings["exchange_blend_s"] = time.time() - t_x
         if accT is None:
             return None, (0, 0)
         if return_float:
             return accT, (lo, hi)
-        out = hip.blur_compose(accT, fr[lo - base: hi - base], mk[lo - base: hi - base], self.taps)
+        out = self._compose(accT, fr[lo - base: hi - base], mk[lo - base: hi - base])
         return out, (lo, hi)
+
+
+class DryRunEraser(DiffuEraserHIP):
+    """CPU stand-in for the model (NO kernels, NOT a fallback: it inpaints nothing) that keeps every piece of HOST logic of the sharded path real --
+    chunk plan, sharding, resident inputs, per-chunk seeded noise, streaming blend + overlap exchange, frame gather -- so `bench.py --dry-run`
+    and the gloo tests can run the multi-rank control flow of the 1 / 2 / 4 / 8-GPU bench lines without a GPU.  A chunk's "decoded pixels" are a
+    fixed fp32 function of its inputs and its noise, so the output is a bit-exact fingerprint of which frames / noise / blend order were used."""
+
+    def __init__(self, run: RunConfig = None, device="cpu"):
+        import types
+        self.run = run or RunConfig()
+        self.ctx = types.SimpleNamespace(device=torch.device(device))
+        self.vae = types.SimpleNamespace(factor=8)
+        self.ac = alphas_cumprod()
+        self.taps = None
+
+    _lanes_ok = False
+
+    @staticmethod
+    def _blend_fn(dec, w, acc):      # restatement of vv_decode_blend (tests/test_dist_cpu.py::_cpu_blend)
+        pix = (dec / 2.0 + 0.5).clamp(0, 1)
+        ww = w[:, None, None, None]
+        acc.copy_(acc * (1.0 - ww) + pix * ww)
+        return acc
+
+    def _sync(self):
+        pass
+
+    def _compose(self, acc, fr, mk):
+        m = (mk > 0)[..., None]
+        return torch.where(m, (acc.clamp(0, 1) * 255.0).round().to(torch.uint8), fr)
+
+    def denoise_chunk(self, frames_u8, prior_u8, mask_u8, noise, steps=None, scheduler="ddim", tcd_noise=None, trace=None, progress=None):
+        n = torch.nn.functional.interpolate(noise.permute(0, 3, 1, 2)[:, :3], size=frames_u8.shape[1:3], mode="nearest").permute(0, 2, 3, 1)
+        return (prior_u8.float() / 127.5 - 1.0) * 0.75 + 0.125 * n.clamp(-2, 2)
