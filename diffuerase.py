@@ -29,7 +29,7 @@ _weights = None         # configure(weights=...) / $VV_WEIGHTS_DIR: a local mode
 _loaded = None          # (CheckpointWeights, prior stages) resolved from _weights, cached until configure() is called again
 
 
-def configure(run: RunConfig = None, dist=None, gather="all", prior=None, weights=None):
+def configure(run: RunConfig = None, dist=None, gather="all", prior=None, weights=None, reference_defaults=False):
     """Select architecture / chunking / dtype for subsequently constructed models (tests use small configs).
     dist = (rank, world) with torch.distributed initialised, one process per GPU (torchrun); gather = "all": every rank returns
     every frame; "rank0": only rank 0 does (the other ranks get None for frames they do not own and should not write a file).
@@ -37,8 +37,17 @@ def configure(run: RunConfig = None, dist=None, gather="all", prior=None, weight
     weights = a directory holding the four checkpoints the reference names (reference :41-43,49; layout: videovanish_amd/modelhub.py), or a
     checkpoint.CheckpointWeights.  Without it (and without $VV_WEIGHTS_DIR) the models are seeded random-init of the same architecture.
     With it every tensor is checked against the architecture first, the empty prompt is CLIP-encoded once, the PCM "2-Step" LoRA is merged,
-    and the learned ProPainter stages switch ON when their files are present (unless `prior` says otherwise)."""
+    and the learned ProPainter stages switch ON when their files are present (unless `prior` says otherwise).
+    reference_defaults=True: ONE switch for the computation the reference app runs by default (reference diffuerase.py:20-21,37,47-57 + the third-party
+    forward): the pipeline's own temporal scheme (22-frame windows shifted on odd steps, value / count averaging, key-frame pre-inference:
+    RunConfig.windowing="reference", one GPU), the 2-step TCD schedule of the "2-Step" checkpoint (already the default of this module), and the
+    COMPLETE ProPainter prior (recurrent flow completion + inpainting generator) when no prior is handed over -- instead of this build's defaults
+    (independent 32 / 8 chunks that shard over GPUs; RAFT + propagation only).  `run` / `prior` given explicitly still win field by field."""
     global _run_config, _dist, _gather, last_ckpt, _prior_stages, propainter, _weights, _loaded
+    if reference_defaults:
+        import dataclasses
+        run = dataclasses.replace(run or RunConfig(), windowing="reference")
+        prior = dict({"flow_completion": True, "generator": True}, **(prior or {}))
     _run_config, _dist, _gather, last_ckpt = run, dist, gather, None
     _prior_stages, propainter = dict(prior or {}), None
     _weights, _loaded = weights, None

@@ -170,23 +170,28 @@ def reference_contexts(n, nframes=22, overlap=4):
     return ctx, swap
 
 
-def _denoise_windows(P, lat, cond, m_lat, steps, ucfg, nframes, overlap):
+def _denoise_windows(P, lat, cond, m_lat, steps, ucfg, nframes, overlap, scheduler="ddim", tcd_noise=None):
     ac = M.alphas_cumprod()
     text = M.text_states(P, ucfg)
     n = lat.shape[0]
     ctxs, swap = reference_contexts(n, nframes, overlap)
-    for i, t in enumerate(M.ddim_timesteps(steps)):
+    ts = M.ddim_timesteps(steps) if scheduler == "ddim" else M.tcd_timesteps(steps)
+    for i, t in enumerate(ts):
         value, count = torch.zeros_like(lat), torch.zeros(n, 1, 1, 1)
         for (a, b) in (ctxs if i % 2 == 0 else swap):
             brush = M.brushnet_forward(P, torch.cat([lat[a:b], cond[a:b], m_lat[a:b]], 1), t, text, ucfg)
             value[a:b] += M.unet_forward(P, lat[a:b], t, text, ucfg, brush)
             count[a:b] += 1
-        lat = M.ddim_step(lat, value / count, t, steps, ac)
+        if scheduler == "ddim":
+            lat = M.ddim_step(lat, value / count, t, steps, ac)
+        else:
+            lat = M.tcd_step(lat, value / count, t, ts[i + 1] if i + 1 < len(ts) else None, ac,
+                             tcd_noise[i] if (tcd_noise is not None and i < len(tcd_noise)) else torch.zeros_like(lat))
     return lat
 
 
 def diffueraser_forward_reference_windows(frames, masks2d, priori, max_img_size=960, steps=50, seed=42, weight_seed=0, ucfg=None, vcfg=None,
-                                          nframes=22, overlap=4, P=None, return_float=False):
+                                          nframes=22, overlap=4, P=None, return_float=False, scheduler="ddim"):
     """DiffuEraser.forward with the third-party pipeline's own temporal scheme: windows of `nframes` shifted by half a window on
     odd steps, noise prediction averaged over the covering windows, key-frame pre-inference when T > 2 * nframes."""
     from videovanish_amd.config import UNetConfig, VAEConfig
@@ -203,7 +208,12 @@ def diffueraser_forward_reference_windows(frames, masks2d, priori, max_img_size=
     f = 2 ** (len(vcfg.block_out) - 1)
     h, w = H // f, W // f
     ac = M.alphas_cumprod()
-    t0 = M.ddim_timesteps(steps)[0]
+    t0 = (M.ddim_timesteps(steps) if scheduler == "ddim" else M.tcd_timesteps(steps))[0]
+    reps = (T + nframes - 1) // nframes
+    z_pre = z_all = None
+    if scheduler == "tcd":      # re-noising tensors: seeded per step, tiled over the windows like the initial noise
+        z_pre = [chunk_noise(seed + 104729 * (i + 1), 0, (nframes, 4, h, w)) for i in range(steps - 1)]
+        z_all = [z.repeat(reps, 1, 1, 1)[:T] for z in z_pre]
     with torch.no_grad():
         mt = lambda lst: torch.from_numpy(np.stack(lst) > 0).float()[:, None]
         prior_lat = M.vae_encode(P, to_model_tensor(pr), vcfg)
@@ -214,17 +224,16 @@ def diffueraser_forward_reference_windows(frames, masks2d, priori, max_img_size=
             idx = [int(i * step) for i in range(nframes)][:nframes]
             m_lat = torch.nn.functional.interpolate(mt([mk[i] for i in idx]), size=(h, w), mode="nearest")
             lat_pre = M.add_noise(prior_lat[idx], noise_pre, t0, ac)
-            out_pre = _denoise_windows(P, lat_pre, cond_lat[idx], m_lat, steps, ucfg, nframes, overlap)
+            out_pre = _denoise_windows(P, lat_pre, cond_lat[idx], m_lat, steps, ucfg, nframes, overlap, scheduler, z_pre)
             pix = (M.vae_decode(P, out_pre, vcfg) / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
             for j, i in enumerate(idx):
                 key = I.blur_compose(pix[j], fr[i], np.full((H, W), 255, np.uint8))
                 fr[i], mk[i] = key, np.zeros((H, W), np.uint8)
                 prior_lat[i] = out_pre[j]
                 cond_lat[i] = M.vae_encode(P, to_model_tensor([key]), vcfg)[0]
-        reps = (T + nframes - 1) // nframes
         noise = noise_pre.repeat(reps, 1, 1, 1)[:T]
         m_lat = torch.nn.functional.interpolate(mt(mk), size=(h, w), mode="nearest")
-        lat = _denoise_windows(P, M.add_noise(prior_lat, noise, t0, ac), cond_lat, m_lat, steps, ucfg, nframes, overlap)
+        lat = _denoise_windows(P, M.add_noise(prior_lat, noise, t0, ac), cond_lat, m_lat, steps, ucfg, nframes, overlap, scheduler, z_all)
         pix = (M.vae_decode(P, lat, vcfg) / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).contiguous().numpy()
     if return_float:
         return pix

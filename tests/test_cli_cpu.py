@@ -73,3 +73,19 @@ def test_cli_errors(cli):
     mp.setattr(sys, "argv", ["diffuerase.py", "--mask_video", "mask.mkv"])
     with pytest.raises(SystemExit):
         d.main()
+
+
+def test_configure_reference_defaults_is_one_switch():
+    """diffuerase.configure(reference_defaults=True) selects what the reference app computes by default (its third-party pipeline's temporal windows +
+    the complete ProPainter prior; the 2-step TCD schedule is this module's default already); explicit fields still win; configure() resets."""
+    import diffuerase
+    from videovanish_amd.config import RunConfig
+    try:
+        diffuerase.configure(reference_defaults=True)
+        assert diffuerase._run_config.windowing == "reference" and diffuerase._prior_stages == {"flow_completion": True, "generator": True}
+        diffuerase.configure(run=RunConfig(steps=7, dtype="bf16"), prior={"generator": False}, reference_defaults=True)
+        assert (diffuerase._run_config.windowing, diffuerase._run_config.steps, diffuerase._run_config.dtype) == ("reference", 7, "bf16")
+        assert diffuerase._prior_stages == {"flow_completion": True, "generator": False}
+    finally:
+        diffuerase.configure()
+    assert diffuerase._run_config is None and diffuerase._prior_stages == {}

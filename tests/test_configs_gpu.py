@@ -75,6 +75,10 @@ def _one_chunk_both(ucfg, vcfg, dname, T, H, W, steps, seed=7, **run_kw):
     return np.abs(got - ref), lat_err
 
 
+def _stats(err):
+    return float(err.mean()), float(np.sqrt((err.astype(np.float64) ** 2).mean()))
+
+
 UNCLAMPED = {}      # filled by _one_chunk_both: max-abs error of the unclamped decode, the reference's range, the saturated fraction
 
 
@@ -86,10 +90,15 @@ def test_parity_50_steps(gpu, dname, precise, tol, cname, ucfg, vcfg, T, H, W):
     err, lat_err = _one_chunk_both(ucfg, vcfg, dname, T, H, W, steps=50, precise_decoder=precise)
     _log(f"parity50[{cname},{dname}{',precise-decoder' if precise else ''}] pixel max_abs={err.max():.3e} mean_abs={err.mean():.3e} | latent rel. max-abs at steps 1/5/10/25/50: "
          + " ".join(f"{lat_err[i - 1]:.2e}" for i in (1, 5, 10, 25, 50)) + _unclamped_str())
+    mean, rms = _stats(err)
+    _log(f"parity50[{cname},{dname}{',precise-decoder' if precise else ''}] pixel rms={rms:.3e}")
     assert err.max() <= tol
     assert lat_err[-1] <= 12 * lat_err[0]                      # relative latent error grows ~5x over the 50 steps, no blow-up
     if precise:
         assert UNCLAMPED["abs_max"] <= 1.0e-3                                          # the same bound on the UNCLAMPED decode
+        # the maximum is an extreme-value statistic (+-10 % with any rounding change); the quantity an optimisation must not degrade is the mean / rms:
+        # <= 1.5 x the round-4 measurement (profiles/r4_parity_gpu.txt: mean 6.96e-5 tiny, 7.08e-5 small)
+        assert mean <= 1.06e-4 and rms <= 1.6e-4
 
 
 def _unclamped_str():
@@ -104,20 +113,53 @@ def test_parity_50_steps_full_width(gpu):
     err, lat_err = _one_chunk_both(UNetConfig(), VAEConfig(), "fp16", 4, 64, 64, steps=50, seed=11, precise_decoder=True)
     _log(f"parity50[full,fp16,precise-decoder] pixel max_abs={err.max():.3e} mean_abs={err.mean():.3e} | latent rel. max-abs at steps 1/5/10/25/50: "
          + " ".join(f"{lat_err[i - 1]:.2e}" for i in (1, 5, 10, 25, 50)) + _unclamped_str() + f" ({time.time() - t0:.0f} s)")
+    mean, rms = _stats(err)
+    _log(f"parity50[full,fp16,precise-decoder] pixel rms={rms:.3e}")
     assert err.max() <= 1.0e-3
     assert UNCLAMPED["abs_max"] <= 1.0e-3
     assert lat_err[-1] <= 12 * lat_err[0]
+    assert mean <= 1.18e-4 and rms <= 1.8e-4                        # <= 1.5 x the round-4 mean (7.89e-5); rms logged since round 5
 
 
-def test_config_c1_full_width_vs_oracle(gpu):
+@pytest.mark.parametrize("seed", [42, 7, 1234])
+def test_config_c1_full_width_vs_oracle(gpu, seed):
     """BASELINE config 1 as stated: 8 frames 256x256, 10 DDIM steps, FULL SD-1.5 / SD-VAE width, one 8-frame clip, against the
-    fp32 oracle on the host cores (~45 TFLOP of CPU work: minutes)."""
+    fp32 oracle on the host cores (~45 TFLOP of CPU work: minutes).  Three noise seeds (round 5): the per-pixel maximum of 1.5 M pixels is an
+    extreme-value statistic, the mean / rms asserts beside it guard the quantity a numerics change actually moves."""
     t0 = time.time()
-    err, lat_err = _one_chunk_both(UNetConfig(), VAEConfig(), "fp16", 8, 256, 256, steps=10, seed=42, precise_decoder=True)
-    _log(f"c1_full_width[fp16,precise-decoder,10 steps] pixel max_abs={err.max():.3e} mean_abs={err.mean():.3e} latent rel. max-abs per step: "
+    err, lat_err = _one_chunk_both(UNetConfig(), VAEConfig(), "fp16", 8, 256, 256, steps=10, seed=seed, precise_decoder=True)
+    mean, rms = _stats(err)
+    tag = "" if seed == 42 else f",seed {seed}"
+    _log(f"c1_full_width[fp16,precise-decoder,10 steps{tag}] pixel max_abs={err.max():.3e} mean_abs={err.mean():.3e} rms={rms:.3e} latent rel. max-abs per step: "
          + " ".join(f"{e:.2e}" for e in lat_err) + _unclamped_str() + f" ({time.time() - t0:.0f} s)")
-    assert err.max() <= 1.0e-3                                      # the north-star bound itself (measured 8.8e-4 .. 8.9e-4)
+    assert err.max() <= 1.0e-3                                      # the north-star bound itself (measured 8.0e-4 .. 8.9e-4)
     assert UNCLAMPED["abs_max"] <= 1.0e-3
+    assert mean <= 1.45e-4 and rms <= 2.0e-4                        # <= 1.5 x the round-4 measurement (mean 9.65e-5, rms ~1.3e-4)
+
+
+def test_raft_20_iterations_mid_size_vs_oracle(gpu):
+    """RAFT at the iteration count the product runs (20 GRU updates) against oracle/flowprop_ref.py at 184 x 320 (23 x 40 feature grid): the recurrent
+    error growth is measured, not inferred from the 3-iteration 720p check.  Translating block texture, random-init weights."""
+    from oracle import flowprop_ref as FP
+    from oracle.model_ref import Params
+    from videovanish_amd import flowprop
+    H, W = 184, 320
+    rng = np.random.default_rng(77)
+    base = rng.integers(0, 256, (H // 8 + 1, W // 8 + 2, 3), dtype=np.uint8)
+    base = np.repeat(np.repeat(base, 8, 0), 8, 1)
+    f0, f1 = np.ascontiguousarray(base[:H, :W]), np.ascontiguousarray(base[:H, 3: 3 + W])
+    ctx, raft = flowprop._model(None, "fp16", 0)
+    errs = {}
+    for iters in (3, 20):
+        with torch.no_grad():
+            ref = FP.raft_flow(Params(0), f0, f1, iters=iters)
+        f, c, h, w = raft.features(torch.from_numpy(np.stack([f0, f1])).to(ctx.device))
+        flow = raft.flow(f[0], f[1], c[0], h, w, iters=iters).cpu().permute(2, 0, 1)
+        d = (flow - ref).abs()
+        errs[iters] = (float(d.max() / ref.abs().max()), float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()))
+        _log(f"raft {W}x{H} fp16 vs oracle ({iters} it.): flow rel max {errs[iters][0]:.3e} rel rms {errs[iters][1]:.3e} (|flow| max {ref.abs().max().item():.2f} px)")
+    assert errs[3][0] <= 5e-2
+    assert errs[20][0] <= 5e-2 and errs[20][1] <= 2e-2             # 20 recurrent updates: the error may grow, it must not take off
 
 
 def _rect_masks(T, H, W):
@@ -227,3 +269,9 @@ def test_reference_windowing_vs_oracle(gpu):
     refu = R.diffueraser_forward_reference_windows(frames, m2d, prior, steps=3, seed=7, ucfg=TINY_UNET, vcfg=TINY_VAE)
     du = np.abs(np.stack(out).astype(int) - np.stack(refu).astype(int))
     assert len(out) == T and du.max() <= 2
+    # the reference's own regime (round 5): the same windows under the 2-step TCD schedule of its "2-Step" checkpoint
+    ref2 = R.diffueraser_forward_reference_windows(frames, m2d, prior, steps=2, seed=7, ucfg=TINY_UNET, vcfg=TINY_VAE, return_float=True, scheduler="tcd")
+    got2, _ = model.forward(frames, m2d, prior, steps=2, return_float=True, scheduler="tcd")
+    e2 = np.abs(got2 - ref2)
+    _log(f"reference_windowing[tiny,fp16,precise,T=46,2-step TCD] pixel max_abs={e2.max():.3e} mean_abs={e2.mean():.3e}")
+    assert e2.max() <= 6e-3

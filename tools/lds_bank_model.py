@@ -32,3 +32,57 @@ if __name__ == "__main__":
         bk = min((max(k_read(DK * 2 + pad, s) for s in range(DK // 32)), pad) for pad in range(0, 144, 16))
         bv = min((max(v_read(DV * 2 + pad, d) for d in range(DV // 16)), pad) for pad in range(0, 144, 8))
         print(f"D={D}: K pitch pad {bk[1]} -> {bk[0]} cycles (ideal 4); V pitch pad {bv[1]} -> {bv[0]} cycles (ideal 2)")
+
+
+# ---- round 5: the REAL access set of vv_attn32.hip::attn40q2_kernel per 64-key tile and wave (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE =
+#      19.8 % in the shipped kernel while DESIGN said "no LDS bank conflicts").  Dense 80-byte K / V rows (PR = 80), constant chunk of 1.0 behind the tile.
+def attn40q2_access_set(PR=80, TILE=64 * 80):
+    """-> list of (name, addrs[64], groups, width bytes).  K fragment reads are ds_read_b128 (lane = (r = lane & 31, h = lane >> 5)), V reads are
+    ds_read_b64_tr_b16; the second query block of the wave re-uses every fragment (CSE), so this is the whole per-tile traffic of one wave."""
+    acc = []
+    for kb in range(2):
+        for s in range(3):
+            a = []
+            for l in range(64):
+                r, h = l & 31, l >> 5
+                if s < 2:
+                    a.append(kb * 32 * PR + r * PR + 16 * h + 32 * s)
+                else:
+                    a.append(TILE if h else kb * 32 * PR + r * PR + 64)
+            acc.append((f"K kb{kb} s{s} (b128)", a, G128, 16))
+    for kb in range(2):
+        for s2 in range(2):
+            g0 = 16 * (2 * kb + s2) * PR
+            for half in range(2):
+                a = []
+                for l in range(64):
+                    vq, vpp, vcb, h = (l >> 2) & 3, l & 3, (l >> 4) & 1, l >> 5
+                    a.append(g0 + half * 2 * PR + (4 * vq + h) * PR + (16 * vcb + 4 * vpp) * 2)
+                acc.append((f"V^T d0..31 kb{kb} s2={s2} {'hi' if half else 'lo'} (b64_tr)", a, G64, 8))
+        for half in range(2):
+            a = []
+            for l in range(64):
+                vq, vpp, vcb, h = (l >> 2) & 3, l & 3, (l >> 4) & 1, l >> 5
+                a.append(TILE if vpp == 2 else kb * 32 * PR + half * 2 * PR + (16 * vcb + 4 * vq + h) * PR + 64 + 8 * (vpp & 1))
+            acc.append((f"V^T d32..47 kb{kb} {'hi' if half else 'lo'} (b64_tr)", a, G64, 8))
+    return acc
+
+
+def attn40q2_report():
+    tot = ideal = 0
+    rows = []
+    for name, a, groups, width in attn40q2_access_set():
+        c = cycles(a, groups, width)
+        i = len(groups)
+        tot += c; ideal += i
+        rows.append((name, c, i))
+    for name, c, i in rows:
+        print(f"  {name:38s} {c:2d} cycles (conflict-free {i})")
+    print(f"  per tile and wave: {tot} LDS cycles, {tot - ideal} of them conflicts = {100.0 * (tot - ideal) / tot:.1f} %   "
+          f"(measured, profiles/r4_attn40q2_pmc.txt: SQ_LDS_IDX_ACTIVE 60.5, SQ_LDS_BANK_CONFLICT 12.0 per tile and wave = 19.8 %)")
+    return tot, tot - ideal
+
+
+if __name__ == "__main__":
+    print("attn40q2_kernel, per 64-key tile and wave:")
+    attn40q2_report()

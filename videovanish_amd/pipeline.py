@@ -295,6 +295,24 @@ class DiffuEraserHIP:
             outs.append(self.vae.decode(lat[a:b].contiguous(), b - a, h, w))
         return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
 
+    def _sched_update(self, lat, eps, i, ts, steps, scheduler, tcd_noise):
+        """one scheduler step x_t -> x_prev (vv_sched_step): DDIM (eta 0), or TCD (gamma 0.3) with the explicit re-noising tensor of step i"""
+        t = ts[i]
+        a_t = float(self.ac[t])
+        if scheduler == "ddim":
+            prev = t - 1000 // steps
+            a_p = float(self.ac[prev]) if prev >= 0 else float(self.ac[0])
+            return hip.sched_step(lat, eps, None, a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5)
+        last = i + 1 >= len(ts)
+        tp = 0 if last else ts[i + 1]
+        s = int(math.floor((1 - 0.3) * tp))
+        a_s, a_p = float(self.ac[s]), float(self.ac[tp])
+        if last:
+            return hip.sched_step(lat, eps, None, a_t ** 0.5, (1 - a_t) ** 0.5, a_s ** 0.5, (1 - a_s) ** 0.5)
+        r = a_p / a_s
+        z = tcd_noise[i] if tcd_noise is not None else torch.zeros_like(lat)
+        return hip.sched_step(lat, eps, z, a_t ** 0.5, (1 - a_t) ** 0.5, (r ** 0.5) * a_s ** 0.5, (r ** 0.5) * (1 - a_s) ** 0.5, (1 - r) ** 0.5)
+
     def denoise_chunk(self, frames_u8, prior_u8, mask_u8, noise, steps=None, scheduler="ddim", tcd_noise=None, trace=None, progress=None):
         """frames/prior: u8 [F,H,W,3] device; mask: u8 [F,H,W]; noise: fp32 [F,h,w,4] device.  Returns decoded fp32
         [F,H,W,3] in [-1,1] (clamp/scale happens in the blend kernel)."""
@@ -323,23 +341,7 @@ class DiffuEraserHIP:
             eps = self.denoiser(lat, cond_lat, mask_u8, t, F, h, w, H, W)
             if trace is not None and i == 0:
                 trace.update(eps0=eps.clone())
-            a_t = float(self.ac[t])
-            if scheduler == "ddim":
-                prev = t - 1000 // steps
-                a_p = float(self.ac[prev]) if prev >= 0 else float(self.ac[0])
-                lat = hip.sched_step(lat, eps, None, a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5)
-            else:
-                last = i + 1 >= len(ts)
-                tp = 0 if last else ts[i + 1]
-                s = int(math.floor((1 - 0.3) * tp))
-                a_s, a_p = float(self.ac[s]), float(self.ac[tp])
-                if last:
-                    lat = hip.sched_step(lat, eps, None, a_t ** 0.5, (1 - a_t) ** 0.5, a_s ** 0.5, (1 - a_s) ** 0.5)
-                else:
-                    r = a_p / a_s
-                    z = tcd_noise[i] if tcd_noise is not None else torch.zeros_like(lat)
-                    lat = hip.sched_step(lat, eps, z, a_t ** 0.5, (1 - a_t) ** 0.5, (r ** 0.5) * a_s ** 0.5, (r ** 0.5) * (1 - a_s) ** 0.5,
-                                         (1 - r) ** 0.5)
+            lat = self._sched_update(lat, eps, i, ts, steps, scheduler, tcd_noise)
             if trace is not None:
                 trace.setdefault("lat_steps", []).append(lat.clone())
             if progress is not None:
@@ -362,11 +364,9 @@ class DiffuEraserHIP:
         if self.run.windowing == "reference":
             if dist is not None and dist[1] > 1:
                 raise RuntimeError('windowing="reference" couples every frame at every step and does not shard: run it on one GPU')
-            if scheduler not in (None, "ddim"):
-                raise RuntimeError('windowing="reference" is implemented for the DDIM scheduler')
             # same contract as the chunked path: (array, (lo, hi)) with return_float, `timings` filled, `progress` called per step
             res = self.forward_reference_windows(frames, masks2d, priori, max_img_size=max_img_size, steps=steps, return_float=return_float,
-                                                 progress=progress)
+                                                 progress=progress, scheduler=scheduler or "ddim")
             if timings is not None:
                 torch.cuda.synchronize()
                 timings.update(upload_s=0.0, compute_s=time.time() - t_0, exchange_blend_s=0.0, gather_download_s=0.0)
@@ -425,7 +425,7 @@ class DiffuEraserHIP:
     # -- reference temporal windowing: windows of 22 frames shifted by half a window on odd steps, value/count
     #    averaging of the noise prediction, key-frame pre-inference for long clips.  Single GPU ("replicas only": the windows couple
     #    all frames at every step, so this mode does not shard); the default chunked mode is the multi-GPU path.
-    def _denoise_windows(self, lat, cond, mask_u8, ts, steps, H, W, nframes, overlap, progress=None):
+    def _denoise_windows(self, lat, cond, mask_u8, ts, steps, H, W, nframes, overlap, progress=None, scheduler="ddim", tcd_noise=None):
         n, h, w, _ = lat.shape
         ctxs, swap = reference_contexts(n, nframes, overlap)
         self.denoiser.prepare(ts)
@@ -439,10 +439,7 @@ class DiffuEraserHIP:
             if (count == 0).any():
                 raise RuntimeError("reference windowing left a frame uncovered")
             eps_all = hip.window_average(value, torch.from_numpy(count).to(lat.device))
-            a_t = float(self.ac[t])
-            prev = t - 1000 // steps
-            a_p = float(self.ac[prev]) if prev >= 0 else float(self.ac[0])
-            lat = hip.sched_step(lat, eps_all, None, a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5)
+            lat = self._sched_update(lat, eps_all, i, ts, steps, scheduler, tcd_noise)
             if progress is not None:
                 progress(i + 1, len(ts))
         return lat
@@ -453,8 +450,9 @@ class DiffuEraserHIP:
         return hip.decode_blend(dec.contiguous(), torch.ones(F, dtype=torch.float32, device=dec.device), acc)
 
     def forward_reference_windows(self, frames, masks2d, priori, max_img_size=960, steps=None, nframes=22, overlap=4, return_float=False,
-                                  progress=None):
-        """The third-party pipeline's own temporal scheme instead of independent chunks (DDIM; one GPU).  Same I/O as forward()."""
+                                  progress=None, scheduler="ddim"):
+        """The third-party pipeline's own temporal scheme instead of independent chunks (one GPU; DDIM, or TCD as the reference's "2-Step" checkpoint
+        runs it: the re-noising tensors are seeded per step and tiled over the windows like the initial noise).  Same I/O as forward()."""
         run, dev = self.run, self.ctx.device
         steps = steps or run.steps
         T = len(frames)
@@ -471,8 +469,15 @@ class DiffuEraserHIP:
 
         fr, pr, mk = prep(frames), prep(priori), prep(masks2d, mask=True)
         mk_orig, fr_orig = mk.clone(), fr.clone()
-        ts = ddim_timesteps(steps)
+        if scheduler not in ("ddim", "tcd"):
+            raise ValueError(f"unknown scheduler {scheduler}")
+        ts = ddim_timesteps(steps) if scheduler == "ddim" else tcd_timesteps(steps)
         a0 = float(self.ac[ts[0]])
+        reps = (T + nframes - 1) // nframes
+        z_pre = z_all = None
+        if scheduler == "tcd":
+            z_pre = [chunk_noise(run.seed + 104729 * (i + 1), 0, (nframes, 4, h, w)).permute(0, 2, 3, 1).contiguous().to(dev) for i in range(steps - 1)]
+            z_all = [z.repeat(reps, 1, 1, 1)[:T].contiguous() for z in z_pre]
 
         def enc(img_u8, mask_u8, masked):
             img8, m8 = hip.preprocess(self.ctx.dt, img_u8.contiguous(), mask_u8.contiguous() if masked else None, want_img=not masked, want_masked=masked)
@@ -484,7 +489,8 @@ class DiffuEraserHIP:
         if T > 2 * nframes:                                   # key-frame pre-inference: 22 uniformly sampled frames in ONE window
             idx = torch.tensor(key_frame_indices(T, nframes), device=dev)
             lat_pre = hip.axpby(prior_lat[idx].contiguous(), noise_pre, a0 ** 0.5, (1 - a0) ** 0.5)
-            out_pre = self._denoise_windows(lat_pre, cond_lat[idx].contiguous(), mk[idx].contiguous(), ts, steps, H, W, nframes, overlap)
+            out_pre = self._denoise_windows(lat_pre, cond_lat[idx].contiguous(), mk[idx].contiguous(), ts, steps, H, W, nframes, overlap,
+                                            scheduler=scheduler, tcd_noise=z_pre)
             pix = self._to_pix01(self.decode(out_pre, nframes, h, w))
             ones = torch.full((nframes, H, W), 255, dtype=torch.uint8, device=dev)
             key_u8 = hip.blur_compose(pix, fr[idx].contiguous(), ones, self.taps)     # all-ones mask: the quantised generated frame
@@ -492,10 +498,9 @@ class DiffuEraserHIP:
             mk[idx] = 0                                       # prior latents = their denoised latents
             prior_lat[idx] = out_pre
             cond_lat[idx] = enc(key_u8, None, False)
-        reps = (T + nframes - 1) // nframes
         noise = noise_pre.repeat(reps, 1, 1, 1)[:T].contiguous()
         lat = hip.axpby(prior_lat.contiguous(), noise, a0 ** 0.5, (1 - a0) ** 0.5)
-        lat = self._denoise_windows(lat, cond_lat.contiguous(), mk, ts, steps, H, W, nframes, overlap, progress=progress)
+        lat = self._denoise_windows(lat, cond_lat.contiguous(), mk, ts, steps, H, W, nframes, overlap, progress=progress, scheduler=scheduler, tcd_noise=z_all)
         pix = self._to_pix01(self.decode(lat, T, h, w))
         if return_float:
             return pix.cpu().numpy()
@@ -663,6 +668,24 @@ class DryRunEraser(DiffuEraserHIP):
     def _compose(self, acc, fr, mk):
         m = (mk > 0)[..., None]
         return torch.where(m, (acc.clamp(0, 1) * 255.0).round().to(torch.uint8), fr)
+
+    def _sched_update(self, lat, eps, i, ts, steps, scheduler, tcd_noise):
+        """one scheduler step x_t -> x_prev (vv_sched_step): DDIM (eta 0), or TCD (gamma 0.3) with the explicit re-noising tensor of step i"""
+        t = ts[i]
+        a_t = float(self.ac[t])
+        if scheduler == "ddim":
+            prev = t - 1000 // steps
+            a_p = float(self.ac[prev]) if prev >= 0 else float(self.ac[0])
+            return hip.sched_step(lat, eps, None, a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5)
+        last = i + 1 >= len(ts)
+        tp = 0 if last else ts[i + 1]
+        s = int(math.floor((1 - 0.3) * tp))
+        a_s, a_p = float(self.ac[s]), float(self.ac[tp])
+        if last:
+            return hip.sched_step(lat, eps, None, a_t ** 0.5, (1 - a_t) ** 0.5, a_s ** 0.5, (1 - a_s) ** 0.5)
+        r = a_p / a_s
+        z = tcd_noise[i] if tcd_noise is not None else torch.zeros_like(lat)
+        return hip.sched_step(lat, eps, z, a_t ** 0.5, (1 - a_t) ** 0.5, (r ** 0.5) * a_s ** 0.5, (r ** 0.5) * (1 - a_s) ** 0.5, (1 - r) ** 0.5)
 
     def denoise_chunk(self, frames_u8, prior_u8, mask_u8, noise, steps=None, scheduler="ddim", tcd_noise=None, trace=None, progress=None):
         n = torch.nn.functional.interpolate(noise.permute(0, 3, 1, 2)[:, :3], size=frames_u8.shape[1:3], mode="nearest").permute(0, 2, 3, 1)
