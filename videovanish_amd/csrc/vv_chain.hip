@@ -900,7 +900,7 @@ __global__ __launch_bounds__(256, 1) void chain_cs_c320_kernel(const vv_chain_pa
 
     // acc[RT][8] += W (RT row tiles of the stream, KS k steps) x buffer: per k step 8 B fragments (double buffered: the reads of step ks + 1 are issued
     // before the MFMAs of step ks) and RT ring fragments starting at ring position (R0 + RT ks) % 10
-    auto layer = [&](auto rt_tag, auto ks_tag, auto r0_tag, f32x4* acc /* [RT][8] */, auto&& rd) {
+    auto layer_cb = [&](auto rt_tag, auto ks_tag, auto r0_tag, f32x4* acc /* [RT][8] */, auto&& rd, auto&& cb) {
         constexpr int RT = decltype(rt_tag)::value, KS = decltype(ks_tag)::value, R0 = decltype(r0_tag)::value;
         uint4 bb[2][8];
 #pragma unroll
@@ -917,11 +917,13 @@ __global__ __launch_bounds__(256, 1) void chain_cs_c320_kernel(const vv_chain_pa
 #pragma unroll
                 for (int tt = 0; tt < 8; ++tt) acc[rt * 8 + tt] = T::mfma(wa, bb[ks & 1][tt], acc[rt * 8 + tt]);
             }
+            cb(ks);      // independent VALU work of the caller (GEGLU of the previous chunk): scheduled among this step's MFMAs
 #ifndef VV_CS_NO_PIN
             __builtin_amdgcn_sched_barrier(0);
 #endif
         }
     };
+    auto layer = [&](auto rt_tag, auto ks_tag, auto r0_tag, f32x4* acc, auto&& rd) { layer_cb(rt_tag, ks_tag, r0_tag, acc, rd, [](int) {}); };
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>; using I5 = std::integral_constant<int, 5>;
     using I10 = std::integral_constant<int, 10>; using I0 = std::integral_constant<int, 0>;
     auto rdA = [&](const int ks, const int tt) -> uint4 { return act_rd(ks, tt); };
@@ -1061,33 +1063,46 @@ __global__ __launch_bounds__(256, 1) void chain_cs_c320_kernel(const vv_chain_pa
     }
     add_bias(P_BO2);
 
-    // ---- GEGLU feed-forward, 20 chunks of 64 hidden units (16 per wave): g = W1 LN3(t) (20 fragments), t += W2 GEGLU(g) (10); the chunk's hidden
-    //      activations alternate between the two halves of hbuf: one barrier per chunk
+    // ---- GEGLU feed-forward, 20 chunks of 64 hidden units (16 per wave): g = W1 LN3(t) (20 fragments), t += W2 GEGLU(g) (10).  Software pipelined over the
+    //      chunks (stream order W1 (0) | W1 (1), W2 (0) | W1 (2), W2 (1) | ...): the GEGLU of chunk c -- ~2.6 k cycles of VALU on a wave that has its SIMD to
+    //      itself -- runs tile by tile INSIDE the k steps of W1 (c + 1), under that layer's MFMAs, from a second accumulator set; hidden activations
+    //      alternate between the two halves of hbuf: one barrier per chunk
     layer_norm(P_LN3G, P_LN3B);
     bar();
-#pragma unroll 1
-    for (int c = 0; c < 20; ++c) {
-        f32x4 g[2][8];      // row tiles: value, gate of the wave's 16 units
+    auto zero_g = [&](f32x4 (&g)[2][8]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int tt = 0; tt < 8; ++tt) g[i][tt] = z4;
-        layer(I2{}, I10{}, I0{}, &g[0][0], rdA);
+    };
+    auto geglu_tile = [&](const f32x4 (&g)[2][8], const int tt, const float4 bv, const float4 bg, unsigned char* hb) {
+        const vv_f32x2 g01 = gelu2((vv_f32x2){g[1][tt][0] + bg.x, g[1][tt][1] + bg.y});
+        const vv_f32x2 g23 = gelu2((vv_f32x2){g[1][tt][2] + bg.z, g[1][tt][3] + bg.w});
+        const f32x4 hv = {(g[0][tt][0] + bv.x) * g01.x, (g[0][tt][1] + bv.y) * g01.y, (g[0][tt][2] + bv.z) * g23.x, (g[0][tt][3] + bv.w) * g23.y};
+        const int ch = 16 * wave + 4 * lg;
+        *(uint2*)(hb + (16 * tt + li) * 128 + (((ch >> 3) ^ sA) << 4) + ((ch & 4) << 1)) = pk4(hv);
+    };
+    // chunk c: its W1 result is in `cur`; W1 (c + 1) goes to `nxt` with GEGLU (c) inside, then the barrier, then W2 (c)
+    auto ff_step = [&](const int c, f32x4 (&cur)[2][8], f32x4 (&nxt)[2][8]) {
         unsigned char* hb = hbuf + (c & 1) * 16384;
-        {
-            const int u = 64 * c + 16 * wave + 4 * lg;
-            const float4 bv = *(const float4*)(prm + P_B1V + u), bg = *(const float4*)(prm + P_B1G + u);
+        const int u = 64 * c + 16 * wave + 4 * lg;
+        const float4 bv = *(const float4*)(prm + P_B1V + u), bg = *(const float4*)(prm + P_B1G + u);
+        if (c + 1 < 20) {
+            zero_g(nxt);
+            layer_cb(I2{}, I10{}, I0{}, &nxt[0][0], rdA, [&](const int ks) { if (ks < 8) geglu_tile(cur, ks, bv, bg, hb); });
+        } else {
 #pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
-                const vv_f32x2 g01 = gelu2((vv_f32x2){g[1][tt][0] + bg.x, g[1][tt][1] + bg.y});
-                const vv_f32x2 g23 = gelu2((vv_f32x2){g[1][tt][2] + bg.z, g[1][tt][3] + bg.w});
-                const f32x4 hv = {(g[0][tt][0] + bv.x) * g01.x, (g[0][tt][1] + bv.y) * g01.y, (g[0][tt][2] + bv.z) * g23.x, (g[0][tt][3] + bv.w) * g23.y};
-                const int ch = 16 * wave + 4 * lg;
-                *(uint2*)(hb + (16 * tt + li) * 128 + (((ch >> 3) ^ sA) << 4) + ((ch & 4) << 1)) = pk4(hv);
-            }
+            for (int tt = 0; tt < 8; ++tt) geglu_tile(cur, tt, bv, bg, hb);
         }
         bar();
         layer(I5{}, I2{}, I0{}, &t[0][0], [&](const int ks, const int tt) -> uint4 { return *(const uint4*)(hb + (16 * tt + li) * 128 + (((4 * ks + lg) ^ sA) << 4)); });
+    };
+    {
+        f32x4 gA[2][8], gB[2][8];
+        zero_g(gA);
+        layer(I2{}, I10{}, I0{}, &gA[0][0], rdA);
+#pragma unroll 1
+        for (int c = 0; c < 20; c += 2) { ff_step(c, gA, gB); ff_step(c + 1, gB, gA); }
     }
     add_bias(P_B2);
 

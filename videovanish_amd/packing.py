@@ -207,10 +207,14 @@ def pack_chain_stream_columns(w, h16, heads=8):
             fr += _pad_ring(_frags(_permute_k(vt), [0, 16, 32], 3))
             cols = torch.cat([torch.arange((2 * q + s_) * D, (2 * q + s_ + 1) * D) for q in range(4)])      # O buffer channel order: wave q's head
             fr += _pad_ring(_frags(w["o2.w"][:, cols], own, 5))
-        for c in range(inner // 64):
+        def w1(c):
             u0 = 64 * c + 16 * wv
             rows = torch.cat([torch.arange(u0, u0 + 16), inner + torch.arange(u0, u0 + 16)])
-            fr += _frags(w["ff1.w"][rows], [0, 16], 10)
+            return _frags(w["ff1.w"][rows], [0, 16], 10)
+        fr += w1(0)                                  # software-pipelined consumption order: W1 (c + 1) before W2 (c)
+        for c in range(inner // 64):
+            if c + 1 < inner // 64:
+                fr += w1(c + 1)
             fr += _frags(w["ff2.w"][:, 64 * c:64 * c + 64], own, 2)
         fr += _frags(w["out.w"], own, 10)
         fr += [torch.zeros((64, 8))] * CS_RING
