@@ -65,5 +65,15 @@ def test_power_trace_parses_rocm_smi_and_never_raises(monkeypatch):
 
 def test_bench_flags_of_the_driver_contract():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120).stdout
-    for flag in ("--gpus", "--steps", "--warmup", "--frames", "--denoise-steps", "--no-power-trace", "--lanes"):
+    for flag in ("--gpus", "--steps", "--warmup", "--frames", "--denoise-steps", "--no-power-trace", "--lanes", "--prior", "--dilate", "--reference-defaults", "--dry-run"):
         assert flag in out
+
+
+def test_kernel_table_groups_profile_records():
+    """bench.kernel_table: hip.PROFILE records (key, flops, bytes, event pair) -> launches / seconds / flops / bytes per key (the c5 line's `prior` table)."""
+    class Ev:
+        def __init__(self, t): self.t = t
+        def elapsed_time(self, other): return other.t - self.t
+    prof = [("prior:corr_lookup", 0.0, 100.0, Ev(0.0), Ev(2.0)), ("prior:corr_lookup", 0.0, 100.0, Ev(5.0), Ev(6.0)), ("conv", 8.0, 0.0, Ev(0.0), Ev(4.0))]
+    tab = bench.kernel_table(prof)
+    assert tab["prior:corr_lookup"] == [2, 3.0e-3, 0.0, 200.0] and tab["conv"] == [1, 4.0e-3, 8.0, 0.0]

@@ -567,8 +567,12 @@ class DiffuEraserHIP:
                 alive -= 1
                 continue
             k, out, ev = item
-            main.wait_event(ev)
-            sink(mine[k], out)
+            try:
+                if not errors:
+                    main.wait_event(ev)
+                    sink(mine[k], out)
+            except BaseException as exc:               # a failing blend / send must not strand the lanes: they stop at their next chunk
+                errors.append(exc)
             del out, item
             with lock:
                 finished.add(k)
