@@ -245,8 +245,15 @@ class LayerNorm:
 class ResBlock:
     """ResnetBlock2D: GN+SiLU -> conv3 (+temb) -> GN+SiLU -> conv3 -> + shortcut(x)."""
 
-    def __init__(self, ctx, name, cin, cout, groups, eps, temb_dim=None, precise=False, precise_temb=False):
+    # conv1's output feeds norm2 and nothing else: the UNet / BrushNet blocks store it in h16 (ResBlock.H16_MID; round 5).  conv1 then writes 2 bytes per
+    # element, norm2's statistics and apply passes read 2 instead of 4 -- 6 of the 14 bytes per element this pair of layers moves (GroupNorm is HBM bound:
+    # 6 % of a denoise step).  Cost, predicted on the CPU before the change (tools/parity_h16_conv1.py: the oracle with the product's roundings plus this
+    # one): per-pixel rms 1.103e-4 -> 1.119e-4 (+1.5 %) at full width; measured on the GPU: profiles/r5_parity_gpu.txt.  The VAE's blocks keep fp32.
+    H16_MID = True
+
+    def __init__(self, ctx, name, cin, cout, groups, eps, temb_dim=None, precise=False, precise_temb=False, h16_mid=False):
         self.ctx, self.cin, self.cout = ctx, cin, cout
+        self.h16_mid = bool(h16_mid) and not precise
         self.norm1 = GroupNorm(ctx, name + ".norm1", cin, groups, eps, precise=precise)
         self.conv1 = Conv(ctx, name + ".conv1", cin, cout, precise=precise)
         # precise_temb: the time-embedding projection in split precision -- a one-row GEMM per ResBlock (hoisted out of the denoise loop: free)
@@ -272,7 +279,7 @@ class ResBlock:
                 b1 = silu_temb[id(self)]
             else:
                 b1 = self.temb_bias(silu_temb).view(-1)
-        h, _, _ = self.conv1(h, F, H, W, bias_override=b1)
+        h, _, _ = self.conv1(h, F, H, W, bias_override=b1, out_dtype=self.ctx.h16 if (self.h16_mid and ResBlock.H16_MID) else torch.float32)
         h = self.norm2(h, F, HW, silu=True)
         if self.short is not None:
             xs, _, _ = self.short(x0, F, H, W, x1=x1)

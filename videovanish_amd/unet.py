@@ -50,7 +50,7 @@ class _Backbone:
             return pes[C]
 
         def layer(name_res, name_attn, name_mot, cin, cout, attn):
-            r = ResBlock(ctx, name_res, cin, cout, cfg.groups, 1e-5, td, precise_temb=self.precise_io)
+            r = ResBlock(ctx, name_res, cin, cout, cfg.groups, 1e-5, td, precise_temb=self.precise_io, h16_mid=True)
             a = SpatialTransformer(ctx, name_attn, cout, cfg, text_h16) if attn else None
             m = MotionModule(ctx, name_mot, cout, cfg, pe(cout)) if motion else None
             return r, a, m
@@ -71,10 +71,10 @@ class _Backbone:
                 skip_ch.append(cout)
         self.skip_ch = list(skip_ch)
         C = bo[-1]
-        self.mid_r0 = ResBlock(ctx, f"{pre}.mid_block.resnets.0", C, C, cfg.groups, 1e-5, td, precise_temb=self.precise_io)
+        self.mid_r0 = ResBlock(ctx, f"{pre}.mid_block.resnets.0", C, C, cfg.groups, 1e-5, td, precise_temb=self.precise_io, h16_mid=True)
         self.mid_a = SpatialTransformer(ctx, f"{pre}.mid_block.attentions.0", C, cfg, text_h16)
         self.mid_m = MotionModule(ctx, f"{pre}.mid_block.motion_modules.0", C, cfg, pe(C)) if motion else None
-        self.mid_r1 = ResBlock(ctx, f"{pre}.mid_block.resnets.1", C, C, cfg.groups, 1e-5, td, precise_temb=self.precise_io)
+        self.mid_r1 = ResBlock(ctx, f"{pre}.mid_block.resnets.1", C, C, cfg.groups, 1e-5, td, precise_temb=self.precise_io, h16_mid=True)
         self.up, self.ups, self.up_ch = [], [], []
         rev, rev_attn = list(reversed(bo)), list(reversed(cfg.attn_levels))
         x_ch = C
