@@ -245,11 +245,11 @@ class LayerNorm:
 class ResBlock:
     """ResnetBlock2D: GN+SiLU -> conv3 (+temb) -> GN+SiLU -> conv3 -> + shortcut(x)."""
 
-    # conv1's output feeds norm2 and nothing else: the UNet / BrushNet blocks store it in h16 (ResBlock.H16_MID; round 5).  conv1 then writes 2 bytes per
-    # element, norm2's statistics and apply passes read 2 instead of 4 -- 6 of the 14 bytes per element this pair of layers moves (GroupNorm is HBM bound:
-    # 6 % of a denoise step).  Cost, predicted on the CPU before the change (tools/parity_h16_conv1.py: the oracle with the product's roundings plus this
-    # one): per-pixel rms 1.103e-4 -> 1.119e-4 (+1.5 %) at full width; measured on the GPU: profiles/r5_parity_gpu.txt.  The VAE's blocks keep fp32.
-    H16_MID = True
+    # conv1's output feeds norm2 and nothing else, so it could be stored in h16 (conv1 writes 2 bytes per element, norm2's two passes read 2 instead of 4).
+    # Built and measured in round 5, NOT adopted (H16_MID = False): +0.47 % on the bench line (GroupNorm 1.22 -> 1.14 s per chunk), but the extra rounding costs
+    # parity -- predicted on the CPU (tools/parity_h16_conv1.py: rms +1.5 % at full width), measured on the GPU: rms +1.8 % at c1, +6.7 % at 50 steps full width, and the smoke clip's
+    # per-pixel maximum 8.3e-4 -> 1.015e-3, over the 1e-3 bound (profiles/r5_h16_mid_ab.txt).  The switch stays for the A/B (tools/bench_with.py ResBlock.H16_MID=1).
+    H16_MID = False
 
     def __init__(self, ctx, name, cin, cout, groups, eps, temb_dim=None, precise=False, precise_temb=False, h16_mid=False):
         self.ctx, self.cin, self.cout = ctx, cin, cout
