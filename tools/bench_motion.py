@@ -6,6 +6,9 @@ import torch
 from videovanish_amd import hip, nn as vnn
 if os.environ.get("VV_LIB_PATH"):
     hip._LIB_PATH = os.environ["VV_LIB_PATH"]          # A/B of two builds of the library on one device
+from videovanish_amd import packing
+if os.environ.get("VV_MOTION_LAYOUT"):
+    packing.MOTION_LAYOUT = os.environ["VV_MOTION_LAYOUT"]     # lab build of the rounds 2-4 kernel (-DVV_MOTION_FORM=0) reads the "tokens" stream order
 from videovanish_amd.config import UNetConfig
 from videovanish_amd.unet import sinusoidal_pos_emb
 

@@ -7,12 +7,12 @@ mkdir -p build
 pids=()
 compile() {   # compile <src> <obj> [extra flags]
   local src=$1 obj=$2; shift 2
-  if [ ! -f build/$obj.o ] || [ $src.hip -nt build/$obj.o ] || [ vv_common.h -nt build/$obj.o ] || [ vv_attn_common.h -nt build/$obj.o ] || [ vv_gemm_epilogue.h -nt build/$obj.o ] || [ vv_chain_lab.h -nt build/$obj.o ] || [ ../../include/vvhip.h -nt build/$obj.o ] || [ build.sh -nt build/$obj.o ]; then
+  if [ ! -f build/$obj.o ] || [ $src.hip -nt build/$obj.o ] || [ vv_common.h -nt build/$obj.o ] || [ vv_attn_common.h -nt build/$obj.o ] || [ vv_gemm_epilogue.h -nt build/$obj.o ] || [ vv_chain_lab.h -nt build/$obj.o ] || [ vv_motion_lab.h -nt build/$obj.o ] || [ ../../include/vvhip.h -nt build/$obj.o ] || [ build.sh -nt build/$obj.o ]; then
     hipcc $FLAGS "$@" -c $src.hip -o build/$obj.o &
     pids+=($!)
   fi
 }
-# (vv_chain_lab.h: lab forms of the fused chain tail, compiled only by hand with -DVV_CHAIN_FORM=0 / 2 -- tools/jobs/r5_chain_ab.sh; vv_conv3.hip, vv_attn_lab.hip: VV_AB=1 only)
+# (vv_motion_lab.h: row-split lab form of the motion module, -DVV_MOTION_FORM=1; vv_chain_lab.h: lab forms of the fused chain tail, compiled only by hand with -DVV_CHAIN_FORM=0 / 2 -- tools/jobs/r5_chain_ab.sh; vv_conv3.hip, vv_attn_lab.hip: VV_AB=1 only)
 # VV_AB=1 ./build.sh builds the lab variant: environment-selected A/B kernels + the opt-in vv_conv3 kernel
 AB=""
 SRCS="vv_api vv_motion vv_chain vv_norm vv_elem vv_image vv_flow vv_deform vv_sam2"

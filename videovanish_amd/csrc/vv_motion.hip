@@ -383,6 +383,13 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
     }
 }
 
+#ifndef VV_MOTION_FORM
+#define VV_MOTION_FORM 0      // 0 = 4 waves x 32 tokens (the product form; stream layout "tokens"); 1 = row-split pairs (lab: vv_motion_lab.h, layout "rowsplit")
+#endif
+#if VV_MOTION_FORM == 1
+#include "vv_motion_lab.h"
+#endif
+
 // per-channel GroupNorm affine of a clip-pooled GroupNorm: a[c] = rstd_g * gamma_c, b[c] = beta_c - mean_g * a[c]   ([2][C] floats)
 __global__ void gn_affine_kernel(const float* fin /* [groups][2] */, const float* gamma, const float* beta, int C, int groups, float* out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -411,8 +418,13 @@ extern "C" int vv_motion_module_c320(const vv_motion_params* pp, int dtype, void
     if (p.out_dtype != VV_F32 && p.out_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_motion_module_c320: out_dtype mismatch");
     if (p.n_slabs != N_SLABS || p.n_params != P_TOTAL - 640) VV_FAIL(VV_E_ARG, "vv_motion_module_c320: stream / parameter block size mismatch (%d slabs, %d floats)", p.n_slabs, p.n_params);
     hipStream_t st = (hipStream_t)stream;
+#if VV_MOTION_FORM == 1
+    if (dtype == VV_BF16) hipLaunchKernelGGL(motion_rs_c320_kernel<BF16>, dim3(p.HW / 4), dim3(512), 0, st, p);
+    else if (dtype == VV_F16) hipLaunchKernelGGL(motion_rs_c320_kernel<F16>, dim3(p.HW / 4), dim3(512), 0, st, p);
+#else
     if (dtype == VV_BF16) hipLaunchKernelGGL(motion_c320_kernel<BF16>, dim3(p.HW / 4), dim3(256), 0, st, p);
     else if (dtype == VV_F16) hipLaunchKernelGGL(motion_c320_kernel<F16>, dim3(p.HW / 4), dim3(256), 0, st, p);
+#endif
     else VV_FAIL(VV_E_ARG, "vv_motion_module_c320: bad dtype");
     VV_CHECK_LAUNCH("vv_motion_module_c320");
     return VV_OK;

@@ -99,10 +99,17 @@ def _dense_slabs(wp, h16, rows_per_block):
     return [_slab(wp[r0:r0 + rows_per_block, k0:k0 + 64], h16) for r0 in range(0, N, rows_per_block) for k0 in range(0, K, 64)]
 
 
-def pack_motion_stream(w, h16, heads=8):
+MOTION_LAYOUT = "tokens"      # stream order of vv_motion.hip's product kernel (4 waves x 32 tokens); "rowsplit": the lab kernel motion_rs_c320_kernel (VV_MOTION_FORM = 1)
+
+
+def pack_motion_stream(w, h16, heads=8, layout=None):
     """w: dict of fp32 tensors of one motion module at C = 320 -- proj_in/proj_out (.w [C,C], .b), attn1/attn2 (q, k, v, o weights, o bias),
     ln1..3 (g, b), ff1 (w [8C, C], b), ff2 (w [C, 4C], b), pe [32, C].  Returns (stream [670, 64, 64] h16, params [16320] fp32) in the
-    consumption order of vv_motion.hip."""
+    consumption order of vv_motion.hip.  layout "rowsplit" (lab kernel): per head k | v | q | Wo (the pair of waves that shares a pixel swaps its key
+    tiles while the q slabs stream) and the GEGLU rows of a 64-unit chunk ordered like packing.pack_chain_stream's (row tiles (0, 1) / (2, 3) of the
+    chunk's two slab groups = [value | gate] of hidden units 0..15 / 32..47 and 16..31 / 48..63)."""
+    layout = layout or MOTION_LAYOUT
+    assert layout in ("rowsplit", "tokens")
     if w["proj_in.w"].device.type == "meta":
         return w["proj_in.w"], w["proj_in.b"]
     C = w["proj_in.w"].shape[0]
@@ -111,7 +118,7 @@ def pack_motion_stream(w, h16, heads=8):
     slabs = _dense_slabs(_permute_k(w["proj_in.w"]), h16, 64)
     for a in ("attn1", "attn2"):
         for h in range(heads):
-            for nm in ("q", "k", "v"):
+            for nm in (("k", "v", "q") if layout == "rowsplit" else ("q", "k", "v")):
                 wh = torch.zeros((48, C))
                 wh[:D] = w[f"{a}.{nm}"][h * D:(h + 1) * D]
                 slabs += _dense_slabs(_permute_k(wh), h16, 48)
@@ -128,7 +135,7 @@ def pack_motion_stream(w, h16, heads=8):
     b1 = []
     for c in range(inner // 64):
         rows = []
-        for i in range(4):
+        for i in ((0, 2, 1, 3) if layout == "rowsplit" else (0, 1, 2, 3)):
             rows += list(range(64 * c + 16 * i, 64 * c + 16 * i + 16)) + list(range(inner + 64 * c + 16 * i, inner + 64 * c + 16 * i + 16))
         rows = torch.tensor(rows)
         slabs += _dense_slabs(_permute_k(w["ff1.w"][rows]), h16, 64)
