@@ -47,3 +47,17 @@ for name, fn in (("layer-by-layer", unfused), ("fused", lambda: hip.spatial_chai
     print(f"{dname} spatial chain level 0 ({name}): {s*1e3:7.3f} ms  {fl/s/1e12:7.1f} TFLOP/s = {fl/s/2.5e15*100:5.1f} % of the MFMA peak")
 a, b = hip.spatial_chain_c320(ctx.dt, o, t, x, mod.fused[0], mod.fused[1]), unfused()
 print("fused vs layer-by-layer rel max:", float((a - b).abs().max() / b.abs().max()))
+
+# the block front (GroupNorm statistics + apply, proj_in, LN1, fused q | k | v projection): hip.PROFILE gives the fused kernel's own time
+hip.PROFILE = []
+for _ in range(3):
+    hip.spatial_chain_front_c320(ctx.dt, x, mod.norm.g, mod.norm.b, mod.norm.groups, mod.norm.eps, mod.front[0], mod.front[1], F=Fr, HW=H * W)
+hip.PROFILE = []
+for _ in range(20):
+    hip.spatial_chain_front_c320(ctx.dt, x, mod.norm.g, mod.norm.b, mod.norm.groups, mod.norm.eps, mod.front[0], mod.front[1], F=Fr, HW=H * W)
+torch.cuda.synchronize()
+recs = [r for r in hip.PROFILE if r[0].startswith("spatial_chain_front")]
+hip.PROFILE = None
+sf = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in recs) / len(recs) * 1e-3
+ff = 2.0 * M * C * C * 4
+print(f"{dname} spatial chain front level 0 (front): {sf*1e3:7.3f} ms  {ff/sf/1e12:7.1f} TFLOP/s = {ff/sf/2.5e15*100:5.1f} % of the MFMA peak")

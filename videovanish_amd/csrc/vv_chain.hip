@@ -676,6 +676,238 @@ __global__ __launch_bounds__(256, 1) void chain_front_c320_kernel(const vv_chain
     qkv_block(12, P0O{}, TAIL{}); qkv_block(13, P0E{}, TAIL{}); qkv_block(14, P0O{}, TAIL{});
 }
 
+// ROW-SPLIT pair form of the block front (round 5; design: chain_rs_c320_kernel above).  All 100 slabs are dense layers, so every slab is read as two row
+// tiles per wave (4 fragment reads feed 8 MFMAs) at two waves per SIMD; the partners swap the LayerNorm output once.  Same stream as the 4 x 32 form.
+template <typename T>
+__global__ __launch_bounds__(512, 2) void chain_front_rs_c320_kernel(const vv_chain_front_params p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[RS_NS * SLAB];
+    __shared__ __attribute__((aligned(16))) unsigned char xbuf[RS_XBUF];
+    __shared__ __attribute__((aligned(16))) float sbuf[8 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float prm[F_TOTAL];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int grp = wave & 3, hf = wave >> 2, pw = wave ^ 4;
+    const bool hi = hf != 0;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + grp * 32;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int i = tid * 4; i < F_TOTAL; i += 512 * 4) *(float4*)(prm + i) = *(const float4*)(p.params + i);
+    const unsigned char* sbase = (const unsigned char*)p.stream + wave * 1024 + lane * 16;
+    int issued = 0, islot = 0, cslot = 0;
+    auto issue = [&]() {
+        glds16_asm(sbase + (int64_t)issued * SLAB, ring + islot * SLAB + wave * 1024);
+        ++issued;
+        islot = islot + 1 == RS_NS ? 0 : islot + 1;
+    };
+    using BODY = std::false_type; using TAIL = std::true_type;
+    using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    auto sync = [&](auto ni_tag, auto tail_tag) {
+        constexpr int NI = decltype(ni_tag)::value;
+        if constexpr (decltype(tail_tag)::value) {
+            if (issued + NI <= NF_SLABS) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) issue();
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                while (issued < NF_SLABS) issue();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) issue();
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    };
+    auto slab = [&]() -> const unsigned char* {
+        const unsigned char* s = ring + cslot * SLAB;
+        cslot = cslot + 1 == RS_NS ? 0 : cslot + 1;
+        return s;
+    };
+    auto meet = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+    auto frag = [&](const f32x4& lo, const f32x4& hi_) -> uint4 {
+        return make_uint4(pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]), pack2<T>(hi_[0], hi_[1]), pack2<T>(hi_[2], hi_[3]));
+    };
+    auto sel = [&](const uint4& a_, const uint4& b_) -> uint4 { return hi ? b_ : a_; };
+    struct WF2 { uint4 w[2][2]; };
+    const int rs_off = hf * 4096 + li * 128, sw = li & 7;
+    auto load_rs = [&](const unsigned char* s, WF2& f) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int off = ((kk * 4 + lg) ^ sw) << 4;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) f.w[kk][rt] = *(const uint4*)(s + rs_off + rt * 2048 + off);
+        }
+    };
+    uint4 a0[5][2], a1[5][2];
+    // N slabs (5 k tiles per 64-row block), a step in front of every pair: acc_of(i)[rt][tt] += own row tiles x the full activation row
+    auto group_rs = [&](auto n_tag, auto&& acc_of, auto tail) {
+        constexpr int N = decltype(n_tag)::value;
+        WF2 f[2];
+        if constexpr (N >= 2) sync(I2{}, tail); else sync(I1{}, tail);
+        load_rs(slab(), f[0]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (i + 1 < N) {
+                if (((i + 1) & 1) == 0) { if (i + 2 < N) sync(I2{}, tail); else sync(I1{}, tail); }
+                load_rs(slab(), f[(i + 1) & 1]);
+            }
+            f32x4* acc = acc_of(i);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) acc[rt * 2 + tt] = T::mfma(f[i & 1].w[kk][rt], kk ? a1[i % 5][tt] : a0[i % 5][tt], acc[rt * 2 + tt]);
+            if (i + 1 < N) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+    };
+    using N5 = std::integral_constant<int, 5>; using N25 = std::integral_constant<int, 25>;
+    auto chan = [&](const int j) -> int { return 64 * (j >> 1) + 32 * hf + 16 * (j & 1) + 4 * lg; };
+
+    unsigned char* const xmine = xbuf + wave * 5120 + lane * 16;
+    const unsigned char* const xpart = xbuf + pw * 5120 + lane * 16;
+    // full swap of the partners' halves: a0 / a1 <- (own k steps, partner's) for both token tiles (two rounds through the 40 KB buffer)
+    auto swap_full = [&](const uint4 (&own)[5][2]) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            if (tt) meet();
+#pragma unroll
+            for (int rb = 0; rb < 5; ++rb) *(uint4*)(xmine + rb * 1024) = own[rb][tt];
+            meet();
+#pragma unroll
+            for (int rb = 0; rb < 5; ++rb) {
+                const uint4 o = *(const uint4*)(xpart + rb * 1024);
+                a0[rb][tt] = sel(own[rb][tt], o);
+                a1[rb][tt] = sel(o, own[rb][tt]);
+            }
+        }
+    };
+    // ---- x -> GroupNorm apply (scale / shift of the token's own frame) -> activation fragments.  Each wave converts ITS k steps (2 rb + hf) of both
+    //      token tiles and the partners swap (no duplicate reads of x); the per-frame affine rows the block touches are staged in LDS first
+    int64_t rows[2];
+    {
+        const int64_t r_lo = (int64_t)blockIdx.x * 128, r_hi = (r_lo + 127 < p.M ? r_lo + 127 : p.M - 1);
+        const int f_lo = (int)(r_lo / p.HW), nfr = (int)(r_hi / p.HW) - f_lo + 1;      // <= 16 frames (launcher)
+        float* affs = (float*)xbuf;
+        for (int i = tid * 4; i < nfr * 2 * CC; i += 512 * 4) *(float4*)(affs + i) = *(const float4*)(p.gn_affine + (int64_t)f_lo * (2 * CC) + i);
+        __syncthreads();       // affine rows and parameter block visible
+        uint4 own[5][2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            int64_t row = row0 + tt * 16 + li;
+            if (row >= p.M) row = p.M - 1;
+            rows[tt] = row;
+            const float* xrow = p.x + row * CC;
+            const float* aff = affs + ((int)(row / p.HW) - f_lo) * (2 * CC);
+#pragma unroll
+            for (int rb = 0; rb < 5; ++rb) {
+                const int c0 = 64 * rb + 32 * hf + 4 * lg, c1 = c0 + 16;
+                const float4 x0 = *(const float4*)(xrow + c0), x1 = *(const float4*)(xrow + c1);
+                const float4 g0 = *(const float4*)(aff + c0), b0 = *(const float4*)(aff + CC + c0);
+                const float4 g1 = *(const float4*)(aff + c1), b1 = *(const float4*)(aff + CC + c1);
+                own[rb][tt] = make_uint4(pack2<T>(x0.x * g0.x + b0.x, x0.y * g0.y + b0.y), pack2<T>(x0.z * g0.z + b0.z, x0.w * g0.w + b0.w),
+                                         pack2<T>(x1.x * g1.x + b1.x, x1.y * g1.y + b1.y), pack2<T>(x1.z * g1.z + b1.z, x1.w * g1.w + b1.w));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+        for (int i = 0; i < RS_AH; ++i) issue();
+        meet();                // everybody has read its affine rows: the buffer turns into the exchange buffer
+        swap_full(own);
+    }
+    // ---- proj_in: t = Win a + bin (own channels), stored for the tail kernel and the residual
+    f32x4 t[10][2];
+#pragma unroll
+    for (int j = 0; j < 10; ++j)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) t[j][tt] = z4;
+    group_rs(N25{}, [&](int i) { return &t[(i / 5) * 2][0]; }, BODY{});
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const float4 b = *(const float4*)(prm + F_BIN + chan(j));
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) { t[j][tt][0] += b.x; t[j][tt][1] += b.y; t[j][tt][2] += b.z; t[j][tt][3] += b.w; }
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        if (row0 + tt * 16 + li < p.M) {
+            float* trow = p.t_out + rows[tt] * CC;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) *(float4*)(trow + chan(j)) = make_float4(t[j][tt][0], t[j][tt][1], t[j][tt][2], t[j][tt][3]);
+        }
+    }
+    // ---- LN1 (statistics merged with the partner's) -> own k steps -> swap -> full rows
+    {
+        float mloc[2], m2loc[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) s += (t[j][tt][0] + t[j][tt][1]) + (t[j][tt][2] + t[j][tt][3]);
+            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+            mloc[tt] = s * (1.0f / 160);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 10; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = t[j][tt][r] - mloc[tt]; q += d * d; }
+            q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+            m2loc[tt] = q;
+        }
+        *(float4*)(sbuf + (wave * 64 + lane) * 4) = make_float4(mloc[0], m2loc[0], mloc[1], m2loc[1]);
+        meet();
+        const float4 o4 = *(const float4*)(sbuf + (pw * 64 + lane) * 4);
+        const float om[2] = {o4.x, o4.z}, oq[2] = {o4.y, o4.w};
+        uint4 own[5][2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const float mean = 0.5f * (mloc[tt] + om[tt]), dm = mloc[tt] - om[tt];
+            const float rstd = rsqrtf((m2loc[tt] + oq[tt] + 80.0f * dm * dm) * (1.0f / CC) + 1e-5f);
+#pragma unroll
+            for (int rb = 0; rb < 5; ++rb) {
+                f32x4 y[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = 2 * rb + h, c = chan(j);
+                    const float4 g = *(const float4*)(prm + F_LN1G + c), b = *(const float4*)(prm + F_LN1B + c);
+                    y[h][0] = (t[j][tt][0] - mean) * rstd * g.x + b.x; y[h][1] = (t[j][tt][1] - mean) * rstd * g.y + b.y;
+                    y[h][2] = (t[j][tt][2] - mean) * rstd * g.z + b.z; y[h][3] = (t[j][tt][3] - mean) * rstd * g.w + b.w;
+                }
+                own[rb][tt] = frag(y[0], y[1]);
+            }
+        }
+        swap_full(own);
+    }
+    // ---- fused q | k | v projection: 15 blocks of 64 output channels (this wave: 32 of them), stored head-major
+    unsigned short* qkv = (unsigned short*)p.qkv;
+    int64_t tokbase[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int64_t fr = rows[tt] / p.HW, tk = rows[tt] - fr * p.HW;
+        tokbase[tt] = fr * (3 * (int64_t)p.HW * CC) + tk * CD;
+    }
+    auto qkv_block = [&](const int rb, auto tail) {
+        f32x4 acc[2][2] = {{z4, z4}, {z4, z4}};
+        group_rs(N5{}, [&](int) { return &acc[0][0]; }, tail);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int c = 64 * rb + 32 * hf + 16 * rt + 4 * lg;
+            const int which = c / CC, cc = c - which * CC, head = cc / CD, d = cc - head * CD;
+            const int64_t off = ((int64_t)which * CC + (int64_t)head * CD) * p.HW + d;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+                if (row0 + tt * 16 + li < p.M)
+                    *(uint2*)(qkv + tokbase[tt] + off) = make_uint2(pack2<T>(acc[rt][tt][0], acc[rt][tt][1]), pack2<T>(acc[rt][tt][2], acc[rt][tt][3]));
+        }
+    };
+#pragma unroll 1
+    for (int rb = 0; rb < 12; ++rb) qkv_block(rb, BODY{});
+    qkv_block(12, TAIL{}); qkv_block(13, TAIL{}); qkv_block(14, TAIL{});
+}
+
 // per-frame GroupNorm affine: out[f][0][c] = rstd * gamma[c], out[f][1][c] = beta[c] - mean * rstd * gamma[c]
 __global__ void gn_affine_frames_kernel(const float* fin /* [F][groups][2] */, const float* gamma, const float* beta, int C, int groups, int F, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -742,8 +974,23 @@ extern "C" int vv_spatial_chain_front_c320(const vv_chain_front_params* pp, int 
     const int64_t nblk = (p.M + 127) / 128;
     if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_spatial_chain_front_c320: grid too large");
     hipStream_t st = (hipStream_t)stream;
+#ifndef VV_FRONT_FORM
+#define VV_FRONT_FORM 1      // 1 = row-split pairs (chain_front_rs_c320_kernel); 0 = 4 waves x 32 tokens (round 3; same stream)
+#endif
+#if VV_FRONT_FORM == 1
+    if (127 / p.HW + 2 <= 16) {      // the block's per-frame affine rows fit the staging buffer (always, beyond toy frame sizes)
+        if (dtype == VV_BF16) hipLaunchKernelGGL(chain_front_rs_c320_kernel<BF16>, dim3((unsigned)nblk), dim3(512), 0, st, p);
+        else if (dtype == VV_F16) hipLaunchKernelGGL(chain_front_rs_c320_kernel<F16>, dim3((unsigned)nblk), dim3(512), 0, st, p);
+        else VV_FAIL(VV_E_ARG, "vv_spatial_chain_front_c320: bad dtype");
+        VV_CHECK_LAUNCH("vv_spatial_chain_front_c320");
+        return VV_OK;
+    }
     if (dtype == VV_BF16) hipLaunchKernelGGL(chain_front_c320_kernel<BF16>, dim3((unsigned)nblk), dim3(256), 0, st, p);
     else if (dtype == VV_F16) hipLaunchKernelGGL(chain_front_c320_kernel<F16>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+#else
+    if (dtype == VV_BF16) hipLaunchKernelGGL(chain_front_c320_kernel<BF16>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else if (dtype == VV_F16) hipLaunchKernelGGL(chain_front_c320_kernel<F16>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+#endif
     else VV_FAIL(VV_E_ARG, "vv_spatial_chain_front_c320: bad dtype");
     VV_CHECK_LAUNCH("vv_spatial_chain_front_c320");
     return VV_OK;
