@@ -47,3 +47,27 @@ def test_fused_spatial_chain_vs_oracle_and_unfused(gpu, dname, tol, Fr, H, W):
     assert e_f <= tol and e_f <= 2.0 * e_p + 1e-4
     out16 = mod(xin, Fr, H, W, out_dtype=ctx.h16)
     assert out16.dtype == ctx.h16 and _rel(back(out16), fused) <= (2e-3 if dname == "fp16" else 1.6e-2)
+
+
+def test_fused_chain_kernels_are_run_to_run_deterministic(gpu):
+    """The row-split kernels hand activations between the two waves of a pair through LDS (round 5): an ordering hazard there would show as launches of the
+    same inputs that differ.  30 launches of the front and of the tail at 80 blocks (more blocks than one pass over a slice of the CUs, fewer than the
+    chip: both full and ragged occupancy occur), bit for bit equal; fp16 and bf16."""
+    from videovanish_amd import hip, nn as vnn
+    cfg = UNetConfig()
+    C, Fr, H, W = 320, 4, 40, 64
+    M = Fr * H * W
+    g = torch.Generator().manual_seed(5)
+    for dname in ("fp16", "bf16"):
+        ctx = vnn.Ctx("cuda:0", dname, 0)
+        text = ctx.dev(torch.randn(77, 768, generator=g), ctx.h16)
+        mod = vnn.SpatialTransformer(ctx, "unet.down_blocks.0.attentions.0", C, cfg, text)
+        x = torch.randn(M, C, generator=g).to(gpu)
+        t0, qkv0 = hip.spatial_chain_front_c320(ctx.dt, x, mod.norm.g, mod.norm.b, mod.norm.groups, mod.norm.eps, mod.front[0], mod.front[1], F=Fr, HW=H * W)
+        o = torch.randn(M, C, generator=g).to(gpu).to(ctx.h16)
+        out0 = hip.spatial_chain_c320(ctx.dt, o, t0, x, mod.fused[0], mod.fused[1])
+        for _ in range(30):
+            t1, qkv1 = hip.spatial_chain_front_c320(ctx.dt, x, mod.norm.g, mod.norm.b, mod.norm.groups, mod.norm.eps, mod.front[0], mod.front[1], F=Fr, HW=H * W)
+            out1 = hip.spatial_chain_c320(ctx.dt, o, t0, x, mod.fused[0], mod.fused[1])
+            assert torch.equal(t1, t0) and torch.equal(qkv1, qkv0) and torch.equal(out1, out0)
+        assert torch.isfinite(out0).all()
