@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const vv_conv_params p,
     }
 
     auto row_m = [&](int row, bool& ok) -> int { ok = m0 + row < M; return m0 + row; };
-    gemm_epilogue<T, MT, NT>(p, acc, wr * 128, n0 + wc * NT * 16, lr, lq, HWo, row_m);
+    gemm_epilogue<T, MT, NT, true>(p, acc, wr * 128, n0 + wc * NT * 16, lr, lq, HWo, row_m);      // LEAN: one block per CU, nothing else covers the epilogue
 }
 
 
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const vv_conv_params p
     if (wr == 0) bar();                          // re-align the two groups
 
     auto row_m = [&](int row, bool& ok) -> int { ok = m0 + row < M; return m0 + row; };
-    gemm_epilogue<T, MT, NT>(p, acc, wr * 128, n0 + wc * 64, lr, lq, HWo, row_m);
+    gemm_epilogue<T, MT, NT, true>(p, acc, wr * 128, n0 + wc * 64, lr, lq, HWo, row_m);
 }
 
 template <typename T, int NT, int MODE>

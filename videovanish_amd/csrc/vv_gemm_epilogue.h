@@ -1,10 +1,21 @@
-// Epilogue shared by the MFMA GEMM / convolution kernels (vv_gemm.hip, vv_conv3.hip): accumulators in the swapped-operand layout
+// Epilogue shared by the MFMA GEMM / convolution kernels (vv_gemm.hip, vv_gemm256.hip, vv_conv3.hip): accumulators in the swapped-operand layout
 // (lane (lr, lq) owns output row row0 + i*16 + lr, channels ncol0 + j*16 + 4*lq .. +3) -> bias, out_scale, time-embedding row
 // vector, up to two residuals, ReLU, GEGLU, cast, 16-byte stores.  row_m(tile_row, ok&) maps a tile row to the output row.
+//
+// Two forms of the 16-byte vector path (round 5, second session):
+//   * LEAN = false (the 128-row kernels of vv_gemm.hip): per (strip, column tile) the bias float4 is re-read and waited for with s_waitcnt vmcnt(0) --
+//     which on gfx950 also drains the STORE of the previous tile: MT x NT serialised load -> wait -> store steps per wave.  With 3-4 blocks per CU the
+//     other blocks' MFMAs cover them, and the form holds no operand across tiles: the 128 x 160 kernels fit their 128-VGPR budget exactly.
+//   * LEAN = true (the 256-row kernels of vv_gemm256.hip: ONE block per CU, nothing covers the epilogue -- 40 such steps per wave of a 256 x 320 tile):
+//     the lane's NT bias float4 are read once and folded into the accumulators (same fp32 sum, same order: bit-identical results), the fp32 residual
+//     of a strip is requested in one batch, and the strip's stores issue back to back: MT waits per wave instead of MT x NT.  Measured
+//     (profiles/r5_epilogue_ab.txt): qkv L2 0.329 -> 0.292 ms, ff2 L2 0.389 -> 0.371, 8192^3 1225 -> 1250 TFLOP/s.  The same form on the 128-row
+//     kernels costs the two 128 x 160 / 4-blocks-per-CU loaders 55 spilled registers (-30 %), and a column-by-column order (one bias float4 per
+//     column, no fold) loses 8-12 % on every fp32-residual shape (the 64-byte pieces of an output row are then written microseconds apart).
 #pragma once
 #include "vv_common.h"
 
-template <typename T, int MT, int NT, typename RowMap>
+template <typename T, int MT, int NT, bool LEAN = false, typename RowMap>
 __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&acc)[MT][NT], const int row0, const int ncol0, const int lr,
                                               const int lq, const int HWo, RowMap row_m) {
     // ---- epilogue: lane owns out[m][n .. n+3].  All bias / time-embedding / residual loads of one 16-row strip are issued
@@ -40,6 +51,73 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
                     if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + oc) = make_float4(o[0], o[1], o[2], o[3]);
                     else *(uint2*)((unsigned short*)p.out + oc) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
                 }
+            }
+        }
+        return;
+    }
+    if (LEAN && vec) {
+        int colpart[NT];          // split_heads store: the column's (which, head, d) part of the output index (< 3*C*tokens)
+        const bool split = p.split_heads > 0;
+        const int stok = p.split_tokens < 0 ? -p.split_tokens : p.split_tokens;      // tokens per batch element
+        const int snb = p.split_tokens < 0 ? (p.F * HWo) / stok : 0;                 // token-major rows: number of batch elements
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = ncol0 + j * 16 + 4 * lq;
+            colpart[j] = 0;
+            if (split) {
+                const int wh = n / p.split_dim;                       // which * heads + head
+                colpart[j] = wh * stok * p.split_dim + (n - wh * p.split_dim);
+            }
+        }
+        {      // the lane's NT bias float4 are read ONCE and folded into the accumulators (the sum keeps its order: products first, bias last)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = ncol0 + j * 16 + 4 * lq;
+                const float4 b = (p.bias && n < N) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) { acc[i][j][0] += b.x; acc[i][j][1] += b.y; acc[i][j][2] += b.z; acc[i][j][3] += b.w; }
+            }
+        }
+        const bool pre0 = p.res0 && r0f32;          // the common residual: the loads of one strip are issued back to back before their first use
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            __builtin_amdgcn_sched_barrier(0);      // one strip at a time: hoisting the next strips' address arithmetic over this one's stores costs the 128-VGPR kernels their budget
+            bool mok;
+            const int m = row_m(row0 + i * 16 + lr, mok);
+            float4 ra4[NT];
+            if (pre0) {
+                const float* rp = (const float*)p.res0 + (int64_t)(mok ? m : 0) * N + ncol0 + 4 * lq;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) ra4[j] = (mok && ncol0 + j * 16 + 4 * lq < N) ? *(const float4*)(rp + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (!mok) continue;
+            const int64_t rbase = (int64_t)(mok ? m : 0) * N;
+            const float* rowv = (p.rowvec && mok) ? p.rowvec + (int64_t)(m / HWo) * N : nullptr;
+            int64_t rowpart = 0;
+            if (split) {
+                int b, tok;
+                if (snb) { tok = m / snb; b = m - tok * snb; } else { b = m / stok; tok = m - b * stok; }
+                rowpart = ((int64_t)b * 3 * p.split_heads * stok + tok) * p.split_dim;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = ncol0 + j * 16 + 4 * lq;
+                const bool on = mok && n < N;
+                float v[4] = {acc[i][j][0] * p.out_scale, acc[i][j][1] * p.out_scale, acc[i][j][2] * p.out_scale, acc[i][j][3] * p.out_scale};
+                if (rowv && on) { const float4 t4 = *(const float4*)(rowv + n); v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w; }
+                if (pre0) { v[0] += ra4[j].x; v[1] += ra4[j].y; v[2] += ra4[j].z; v[3] += ra4[j].w; }
+                if (!on) continue;
+                if (p.res0 && !r0f32) { const uint2 r2 = *(const uint2*)((const unsigned short*)p.res0 + rbase + n); v[0] += T::to_f32(r2.x & 0xffff); v[1] += T::to_f32(r2.x >> 16); v[2] += T::to_f32(r2.y & 0xffff); v[3] += T::to_f32(r2.y >> 16); }
+                if (p.res1) {
+                    if (r0f32) { const float4 r4 = *(const float4*)((const float*)p.res1 + rbase + n); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+                    else { const uint2 r2 = *(const uint2*)((const unsigned short*)p.res1 + rbase + n); v[0] += T::to_f32(r2.x & 0xffff); v[1] += T::to_f32(r2.x >> 16); v[2] += T::to_f32(r2.y & 0xffff); v[3] += T::to_f32(r2.y >> 16); }
+                }
+                if (p.act == VV_ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                else if (p.act == VV_ACT_LRELU) { v[0] = v[0] > 0.f ? v[0] : v[0] * p.act_slope; v[1] = v[1] > 0.f ? v[1] : v[1] * p.act_slope; v[2] = v[2] > 0.f ? v[2] : v[2] * p.act_slope; v[3] = v[3] > 0.f ? v[3] : v[3] * p.act_slope; }
+                // head-major QKV store: out[b][which][head][token][d] = row part + column part
+                const int64_t oc = split ? rowpart + colpart[j] : (int64_t)m * p.ldo + n;
+                if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + oc) = make_float4(v[0], v[1], v[2], v[3]);
+                else *(uint2*)((unsigned short*)p.out + oc) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
             }
         }
         return;
