@@ -59,6 +59,9 @@ CASES = [   # name, F, H, W, cin (or (c0,c1)), cout, k, stride, flags, calls per
     ("geglu L2 K1280 N10240", F, 23, 40, 1280, 10240, 1, 1, "geglu", 15),
     ("ff2   L2 K5120 N1280 +res", F, 23, 40, 5120, 1280, 1, 1, "res h16out", 15),
     ("out   L2 K1280 N1280 +res", F, 23, 40, 1280, 1280, 1, 1, "res", 70),
+    ("zero  L0 K320  N320 f32in +res", F, 90, 160, 320, 320, 1, 1, "res f32in", 8),          # BrushNet zero convolutions / conv_shortcuts: fp32 trunk in, fp32 out
+    ("zero  L1 K640  N640 f32in +res", F, 45, 80, 640, 640, 1, 1, "res f32in", 8),
+    ("zero  L2 K1280 N1280 f32in +res", F, 23, 40, 1280, 1280, 1, 1, "res f32in", 8),
     ("conv3 L0 320->320 +res", F, 90, 160, 320, 320, 3, 1, "res", 14),
     ("conv3 L0 640->320 (cat)", F, 90, 160, (320, 320), 320, 3, 1, "", 4),
     ("conv3 L0 960->320 (cat)", F, 90, 160, (640, 320), 320, 3, 1, "", 2),
@@ -91,7 +94,7 @@ def main():
         Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
         M = Fr * Ho * Wo
         g = torch.Generator(device="cpu").manual_seed(1)
-        x0 = torch.randn(Fr * H * W, c0, generator=g).to(td).to(dev)
+        x0 = torch.randn(Fr * H * W, c0, generator=g).to(torch.float32 if "f32in" in flags else td).to(dev)
         x1 = torch.randn(Fr * H * W, c1, generator=g).to(td).to(dev) if c1 else None
         wt = torch.randn(cout, c0 + c1, k, k, generator=g) / ((c0 + c1) * k * k) ** 0.5
         bias = torch.randn(cout, generator=g)

@@ -398,7 +398,10 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
         }
     }
 
-    gemm_epilogue<T, MT, NT>(p, acc, wr * MT * 16, n0 + wc * NT * 16, lr, lq, HWo, row_m);
+    // LEAN epilogue (vv_gemm_epilogue.h) in the halo-tile 3x3 kernels: +1.5-3.4 % on the ResBlock / VAE convolutions with a residual, +0.3-1.1 % on the
+    // others.  NOT in the loaders held to 128 VGPRs for a fourth block per CU (LIN, FAST9: it spills there, -30 %) and not in the fp32-operand loader
+    // (FAST32: level 1 / 2 zero convolutions -8..-10 %): profiles/r5_epilogue_ab.txt
+    gemm_epilogue<T, MT, NT, MODE == MODE_HALO>(p, acc, wr * MT * 16, n0 + wc * NT * 16, lr, lq, HWo, row_m);
 }
 
 template <typename T, int WR, int WC, int MT, int NT, int MODE>

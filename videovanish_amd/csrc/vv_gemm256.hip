@@ -430,10 +430,15 @@ extern "C" int vv_gemm256_try(const vv_conv_params* pp, int dtype, int force, vo
         // 128-row tiles whatever their K (x1.06-1.18), level 2 stays here (x1.12-1.34); the level-2 FF output projection (K = 5120, N = 1280) takes
         // the 2-phase 256x320 form (x1.14 over the 128-row tile, x1.09 over the 8-phase form; the level-1 one, K = 2560, gained x1.05 standalone and lost
         // 2 % in the pipeline: stays on the 128-row tile).
+        // Round 5 (second session): with the lean epilogue (vv_gemm_epilogue.h: the 256-row kernels no longer pay 40 serialised bias-load / store round
+        // trips per wave) the 2-phase form also wins on the level-1 / level-2 linears with K >= 640 the 128-row tiles used to keep -- QKV K 640 N 1920
+        // x1.12, FF output K 2560 N 640 x1.10, attention / block output projections K 640 N 640 x1.04 and K 1280 N 1280 x1.05 -- and on the level-1
+        // GEGLU projection (K 640 N 5120) against the 8-phase form (x1.04); in the pipeline, two chunks in flight, all five together: 19.24 -> 19.06 s per
+        // chunk, bit-identical output (tools/ab_tiles.py, profiles/r5_epilogue_ab.txt).  K = 320 (level 0) stays on the 128-row tiles.
         if (lin) {
             if (p.K >= 5120 && p.Npad % 320 == 0 && p.Npad < 3840 && p.epilogue != VV_EPI_GEGLU) { win = true; form = 1; }
-            else if (n256 && ((p.epilogue == VV_EPI_GEGLU && p.K >= 640) || (p.K >= 1280 && p.Npad >= 3840) || p.K >= 5120)) { win = true; form = 3; }
-            else if (p.K >= 5120) { win = true; form = 1; }
+            else if (n256 && ((p.epilogue == VV_EPI_GEGLU && p.K >= 1280) || (p.K >= 1280 && p.Npad >= 3840) || p.K >= 5120)) { win = true; form = 3; }
+            else if (p.K >= 640) { win = true; form = 1; }
         } else if (p.ksize == 3 && p.stride == 1 && p.K >= 5760 && M64 <= 65536 && BN == 320) { win = true; form = 1; }      // (the 256x256 form lost on every VAE shape)
         const int64_t tiles = ((M64 + 255) / 256) * (p.Npad / (form == 3 ? 256 : BN));
         if (!win || tiles < 400) return -1000;

@@ -2,16 +2,17 @@
 // (lane (lr, lq) owns output row row0 + i*16 + lr, channels ncol0 + j*16 + 4*lq .. +3) -> bias, out_scale, time-embedding row
 // vector, up to two residuals, ReLU, GEGLU, cast, 16-byte stores.  row_m(tile_row, ok&) maps a tile row to the output row.
 //
-// Two forms of the 16-byte vector path (round 5, second session):
-//   * LEAN = false (the 128-row kernels of vv_gemm.hip): per (strip, column tile) the bias float4 is re-read and waited for with s_waitcnt vmcnt(0) --
-//     which on gfx950 also drains the STORE of the previous tile: MT x NT serialised load -> wait -> store steps per wave.  With 3-4 blocks per CU the
-//     other blocks' MFMAs cover them, and the form holds no operand across tiles: the 128 x 160 kernels fit their 128-VGPR budget exactly.
-//   * LEAN = true (the 256-row kernels of vv_gemm256.hip: ONE block per CU, nothing covers the epilogue -- 40 such steps per wave of a 256 x 320 tile):
-//     the lane's NT bias float4 are read once and folded into the accumulators (same fp32 sum, same order: bit-identical results), the fp32 residual
-//     of a strip is requested in one batch, and the strip's stores issue back to back: MT waits per wave instead of MT x NT.  Measured
-//     (profiles/r5_epilogue_ab.txt): qkv L2 0.329 -> 0.292 ms, ff2 L2 0.389 -> 0.371, 8192^3 1225 -> 1250 TFLOP/s.  The same form on the 128-row
-//     kernels costs the two 128 x 160 / 4-blocks-per-CU loaders 55 spilled registers (-30 %), and a column-by-column order (one bias float4 per
-//     column, no fold) loses 8-12 % on every fp32-residual shape (the 64-byte pieces of an output row are then written microseconds apart).
+// Two forms of the 16-byte vector path (round 5, second session; A/B record: profiles/r5_epilogue_ab.txt):
+//   * LEAN = false: per (strip, column tile) the bias float4 is re-read and waited for with s_waitcnt vmcnt(0) -- which on gfx950 also drains the STORE
+//     of the previous tile: MT x NT serialised load -> wait -> store steps per wave.  It holds no operand across tiles, which is what lets the
+//     128 x 160 LIN / FAST9 loaders fit the 128-VGPR budget of a fourth block per CU (whose MFMAs then cover the steps).
+//   * LEAN = true: the lane's NT bias float4 are read once and folded into the accumulators (same fp32 sum, same order: bit-identical results), the
+//     fp32 residual of a strip is requested in one batch, and the strip's stores issue back to back: MT waits per wave instead of MT x NT.  Used by
+//     the 256-row kernels (vv_gemm256.hip: ONE block per CU, nothing else covers the epilogue; qkv L2 0.339 -> 0.303 ms, ff2 L2 0.390 -> 0.376,
+//     8192^3 1225 -> 1250 TFLOP/s -- and the 2-phase form now wins on the level-1 / level-2 linears with K >= 640, vv_gemm256_try) and by the halo-tile
+//     3x3 kernels (MODE_HALO: +1.5..3.4 % with a residual).  Measured losers: the LIN / FAST9 loaders (55 spilled registers, -30 %), the fp32-operand
+//     loader (FAST32, -8..-10 % at levels 1 / 2), and a column-by-column order of the same work (-8..-12 % on every fp32-residual shape: the 64-byte
+//     pieces of an output row are then written microseconds apart).
 #pragma once
 #include "vv_common.h"
 

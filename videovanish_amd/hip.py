@@ -226,9 +226,9 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
             if lin:
                 if K >= 5120 and Npad % 320 == 0 and Npad < 3840 and epilogue != EPI_GEGLU:
                     form = 1
-                elif n256 and ((epilogue == EPI_GEGLU and K >= 640) or (K >= 1280 and Npad >= 3840) or K >= 5120):
+                elif n256 and ((epilogue == EPI_GEGLU and K >= 1280) or (K >= 1280 and Npad >= 3840) or K >= 5120):
                     form = 3
-                elif K >= 5120:
+                elif K >= 640:
                     form = 1
             elif ksize == 3 and stride == 1 and K >= 5760 and M <= 65536 and Npad % 320 == 0:
                 form = 1
