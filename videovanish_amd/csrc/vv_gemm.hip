@@ -80,6 +80,8 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
     __shared__ __attribute__((aligned(16))) unsigned char sB1[SPLIT == 1 ? BN * RP : 16];
     __shared__ __attribute__((aligned(16))) unsigned char sAB[SPLIT == 0 ? 2 * (BM + BN) * RP : 16];
 
+    __shared__ __attribute__((aligned(16))) float sBias[(MODE == MODE_HALO || MODE == MODE_FAST32) ? 4 : BN];      // the block's bias columns: the non-LEAN epilogue reads them from here (vv_gemm_epilogue.h)
+
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave / WC, wc = wave % WC;
 
@@ -92,6 +94,13 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
     }
     const int tile_n = bid % tilesN, tile_m = bid / tilesN;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // (not for the fp32-operand loader: its HBM-bound zero convolutions LOSE 9-14 % when the stores stop waiting for each other, like with the LEAN form --
+    //  profiles/r5_epilogue_ab.txt; the halo-tile kernels run the LEAN form and need no staged copy)
+    const bool stage_bias = MODE != MODE_HALO && MODE != MODE_FAST32 && (p.N & 3) == 0 && p.epilogue != VV_EPI_GEGLU;       // (made visible by the k loop's barriers)
+    if (stage_bias && t < BN / 4) {
+        const int n = n0 + 4 * t;
+        *(float4*)(sBias + 4 * t) = (p.bias && n < p.N) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     // HALO: tile_m -> (frame, patch row, patch column)
     int hf = 0, hy0 = 0, hx0 = 0;
     if (HALO) {
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
     // LEAN epilogue (vv_gemm_epilogue.h) in the halo-tile 3x3 kernels: +1.5-3.4 % on the ResBlock / VAE convolutions with a residual, +0.3-1.1 % on the
     // others.  NOT in the loaders held to 128 VGPRs for a fourth block per CU (LIN, FAST9: it spills there, -30 %) and not in the fp32-operand loader
     // (FAST32: level 1 / 2 zero convolutions -8..-10 %): profiles/r5_epilogue_ab.txt
-    gemm_epilogue<T, MT, NT, MODE == MODE_HALO>(p, acc, wr * MT * 16, n0 + wc * NT * 16, lr, lq, HWo, row_m);
+    gemm_epilogue<T, MT, NT, MODE == MODE_HALO>(p, acc, wr * MT * 16, n0 + wc * NT * 16, lr, lq, HWo, row_m, stage_bias ? sBias + wc * NT * 16 : nullptr);
 }
 
 template <typename T, int WR, int WC, int MT, int NT, int MODE>

@@ -18,7 +18,7 @@
 
 template <typename T, int MT, int NT, bool LEAN = false, typename RowMap>
 __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&acc)[MT][NT], const int row0, const int ncol0, const int lr,
-                                              const int lq, const int HWo, RowMap row_m) {
+                                              const int lq, const int HWo, RowMap row_m, const float* sbias = nullptr) {
     // ---- epilogue: lane owns out[m][n .. n+3].  All bias / time-embedding / residual loads of one 16-row strip are issued
     // back to back into registers BEFORE their first use (one wait per strip instead of one per load).
     const bool geglu = p.epilogue == VV_EPI_GEGLU;
@@ -164,7 +164,8 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
             for (int j = 0; j < NT; ++j) {
                 const int n = ncol0 + j * 16 + 4 * lq;
                 if (n >= N) continue;
-                const float4 bj = p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                // (sbias: the block's bias columns staged in LDS by the kernel -- an LDS read waits on lgkmcnt, not on vmcnt: the previous tile's store stays in flight)
+                const float4 bj = sbias ? *(const float4*)(sbias + j * 16 + 4 * lq) : (p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f));
                 float v[4] = {(acc[i][j][0] + bj.x) * p.out_scale, (acc[i][j][1] + bj.y) * p.out_scale,
                               (acc[i][j][2] + bj.z) * p.out_scale, (acc[i][j][3] + bj.w) * p.out_scale};
                 if (rowv) { const float4 t4 = *(const float4*)(rowv + n); v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w; }
