@@ -468,6 +468,29 @@ __global__ __launch_bounds__(512, 2) void chain_rs_c320_kernel(const vv_chain_pa
 #ifdef VV_PROBE_REGLOAD
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+    // Block residual: ALL 20 float4 of x (and of res1) are requested before the first store.  Read in place -- load, s_waitcnt vmcnt(0), store, per tile --
+    // every wait also drained the previous tile's store: 20 serialised memory round trips at the end of every block (round 5, second session; the same
+    // finding as in vv_gemm_epilogue.h).  The activation row registers are dead here, the 80 extra registers are free.
+    float4 xr[2][10];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int64_t r = row0 + tt * 16 + li;
+        const int64_t row = (r < p.M ? r : 0) * CC;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) xr[tt][j] = r < p.M ? *(const float4*)(p.x + row + chan(j)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (p.res1) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int64_t r = row0 + tt * 16 + li;
+            const int64_t row = (r < p.M ? r : 0) * CC;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const float4 r4 = r < p.M ? *(const float4*)(p.res1 + row + chan(j)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xr[tt][j].x += r4.x; xr[tt][j].y += r4.y; xr[tt][j].z += r4.z; xr[tt][j].w += r4.w;
+            }
+        }
+    }
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
         const int64_t r = row0 + tt * 16 + li;
@@ -477,9 +500,7 @@ __global__ __launch_bounds__(512, 2) void chain_rs_c320_kernel(const vv_chain_pa
             for (int j = 0; j < 10; ++j) {
                 const int c = chan(j);
                 const float4 b = *(const float4*)(prm + Q_BOUT + c);
-                const float4 xr = *(const float4*)(p.x + row + c);
-                float v0 = t[j][tt][0] + b.x + xr.x, v1 = t[j][tt][1] + b.y + xr.y, v2 = t[j][tt][2] + b.z + xr.z, v3 = t[j][tt][3] + b.w + xr.w;
-                if (p.res1) { const float4 r4 = *(const float4*)(p.res1 + row + c); v0 += r4.x; v1 += r4.y; v2 += r4.z; v3 += r4.w; }
+                const float v0 = t[j][tt][0] + b.x + xr[tt][j].x, v1 = t[j][tt][1] + b.y + xr[tt][j].y, v2 = t[j][tt][2] + b.z + xr[tt][j].z, v3 = t[j][tt][3] + b.w + xr[tt][j].w;
                 if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + row + c) = make_float4(v0, v1, v2, v3);
                 else *(uint2*)((unsigned short*)p.out + row + c) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
             }

@@ -366,6 +366,29 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) t[j][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     dense320(P0O{}, t, TAIL{});          // stream slabs 645..669
+    // Block residual: all 40 float4 of x (and of res1) are requested before the first store (read in place, every tile's s_waitcnt vmcnt(0) also drained the
+    // previous tile's store: 40 serialised memory round trips at the end of a block that owns its CU alone -- round 5, second session).  The operand
+    // registers a[][] are dead here.
+    float4 xr[2][20];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const bool on = tt * 16 + li < p.F;
+        const int64_t row = on ? ((int64_t)(tt * 16 + li) * HW + pixel) * MC : 0;
+#pragma unroll
+        for (int j = 0; j < 20; ++j) xr[tt][j] = on ? *(const float4*)(p.x + row + 16 * j + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (p.res1) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const bool on = tt * 16 + li < p.F;
+            const int64_t row = on ? ((int64_t)(tt * 16 + li) * HW + pixel) * MC : 0;
+#pragma unroll
+            for (int j = 0; j < 20; ++j) {
+                const float4 r4 = on ? *(const float4*)(p.res1 + row + 16 * j + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xr[tt][j].x += r4.x; xr[tt][j].y += r4.y; xr[tt][j].z += r4.z; xr[tt][j].w += r4.w;
+            }
+        }
+    }
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
         const int64_t row = ((int64_t)(tt * 16 + li) * HW + pixel) * MC;
@@ -374,9 +397,7 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
         for (int j = 0; j < 20; ++j) {
             const int c = 16 * j + 4 * lg;
             const float4 b = *(const float4*)(prm + P_BOUT + c);
-            const float4 xr = *(const float4*)(p.x + row + c);
-            float v0 = t[j][tt][0] + b.x + xr.x, v1 = t[j][tt][1] + b.y + xr.y, v2 = t[j][tt][2] + b.z + xr.z, v3 = t[j][tt][3] + b.w + xr.w;
-            if (p.res1) { const float4 r4 = *(const float4*)(p.res1 + row + c); v0 += r4.x; v1 += r4.y; v2 += r4.z; v3 += r4.w; }
+            const float v0 = t[j][tt][0] + b.x + xr[tt][j].x, v1 = t[j][tt][1] + b.y + xr[tt][j].y, v2 = t[j][tt][2] + b.z + xr[tt][j].z, v3 = t[j][tt][3] + b.w + xr[tt][j].w;
             if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + row + c) = make_float4(v0, v1, v2, v3);
             else *(uint2*)((unsigned short*)p.out + row + c) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
         }
