@@ -5,6 +5,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from videovanish_amd import hip
+if os.environ.get("VV_LIB_PATH"):
+    hip._LIB_PATH = os.environ["VV_LIB_PATH"]          # A/B of two builds of the library on one device
 
 dt = hip.F16
 for F, HW, C in ((32, 14400, 320), (32, 14400, 640), (32, 3600, 640), (4, 921600, 128)):
@@ -15,7 +17,7 @@ for F, HW, C in ((32, 14400, 320), (32, 14400, 640), (32, 3600, 640), (4, 921600
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    n = 20
+    n = int(os.environ.get("VV_BENCH_N", "20"))
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / n * 1e-3

@@ -171,11 +171,21 @@ __global__ void gn_apply_kernel(const vv_groupnorm_params p, const GNGeom g) {
         }
         else *(uint4*)((unsigned short*)p.out + o) = pack8<T>(v);
     };
+    // Four rows per pass, all loads first: the input and the output may alias as far as the compiler knows, so in a one-row loop the load of row i + 1 follows
+    // the store of row i and its s_waitcnt vmcnt(0) drains that store -- one serialised memory round trip per row and wave (round 5, second session)
     int r = rbeg + r0;
+    const int64_t base = (int64_t)f * p.HW;
+    for (; r + 3 * g.krows < rend; r += 4 * g.krows) {
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gn_load8<T>(p, base + r + u * g.krows, chunk, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) emit(v[u], base + r + u * g.krows);
+    }
     for (; r < rend; r += g.krows) {
         float v[8];
-        gn_load8<T>(p, (int64_t)f * p.HW + r, chunk, v);
-        emit(v, (int64_t)f * p.HW + r);
+        gn_load8<T>(p, base + r, chunk, v);
+        emit(v, base + r);
     }
 }
 
