@@ -475,7 +475,7 @@ int launch_mode(const vv_conv_params& p, int M, hipStream_t st) {
     static const bool nohalo = VV_AB_ENV("VV_GEMM_NO_HALO");
     // (the halo tile maps tile rows to pixels itself: the ABI 9 output scatter lives in the other loaders' row map, so a scattered launch never takes it)
     if (fast && !nohalo && p.sc_oh == 0 && p.in_dtype != VV_F32 && p.ksize == 3 && (p.ksize_w == 0 || p.ksize_w == 3) && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 &&
-        p.Hv == p.Hin && p.Wv == p.Win && p.Hout == p.Hin && p.Wout == p.Win && p.epilogue != VV_EPI_GEGLU && (p.Npad % 160 == 0 || p.Npad % 128 == 0)) {
+        p.Hv == p.Hin && p.Wv == p.Win && p.Hout == p.Hin && p.Wout == p.Win && p.epilogue != VV_EPI_GEGLU && (p.Npad % 160 == 0 || p.Npad % 128 == 0 || (p.Npad % 16 == 0 && p.Npad <= 64))) {      // (the narrow tile: conv_out layers, 4 MFMAs per k tile -- all data movement, the halo saves 3/4 of it)
         // patch grid waste <= 15 % (the halo tile is worth 17-25 %)
         const int64_t cover = (int64_t)((p.Hin + 7) / 8) * 8 * ((p.Win + 15) / 16) * 16;
         if (cover * 100 <= (int64_t)p.Hin * p.Win * 115) return launch_t<T, MODE_HALO>(p, M, st);
