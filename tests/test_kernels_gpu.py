@@ -251,7 +251,9 @@ def test_attention_spatial(gpu, dname, td, ulp, B, heads, Nq, Nkv, D):
                                                            (2, 23, 40, 45, 80, 64, 160, False, False), (1, 6, 7, 11, 13, 64, 64, False, False),
                                                            (2, 8, 14, 15, 27, 64, 64, False, False), (1, 5, 7, 10, 13, 64, 64, True, False),
                                                            (1, 2, 2, 3, 3, 64, 64, False, False), (1, 6, 7, 12, 15, 64, 64, False, False),
-                                                           (1, 7, 9, 14, 18, 64, 32, True, True), (1, 7, 9, 13, 17, 64, 32, True, True)])
+                                                           (1, 7, 9, 14, 18, 64, 32, True, True), (1, 7, 9, 13, 17, 64, 32, True, True),
+                                                           (1, 16, 32, 32, 64, 64, 128, False, False), (2, 15, 32, 30, 64, 128, 160, False, False),      # patch grids the halo loader takes (round 5: 2x2 taps + scatter)
+                                                           (1, 16, 16, 32, 32, 64, 128, True, True), (1, 8, 16, 16, 32, 64, 64, False, False)])
 def test_upconv2x_parity_phases(gpu, dname, td, ulp, Fr, H, W, Hv, Wv, C, N, f32in, precise):
     """nn.UpConv2x: the 3x3 convolution of an Upsample2D layer as four 2x2 convolutions over the SOURCE image (taps on the same source pixel summed,
     scattered store, ABI 9) against torch's interpolate(nearest) + conv2d with exact weights -- even sizes, Hv = 2 H - 1 and / or Wv = 2 W - 1 (the

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
         if (HALO) {
             const int y = hy0 + (row >> 4), x = hx0 + (row & 15);
             ok = y < p.Hin && x < p.Win;
+            if (p.sc_oh > 0) return (hf * p.sc_oh + y * p.sc_sy + p.sc_oy) * p.sc_ow + x * p.sc_sx + p.sc_ox;      // output scatter (nn.UpConv2x parity launches)
             return (hf * p.Hin + y) * p.Win + x;
         }
         ok = m0 + row < M;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
 #pragma unroll
         for (int i = 0; i < HP; ++i) {
             const int idx = i * 256 + t, hp = idx >> 3;
-            const int y = hy0 - 1 + hp / 18, x = hx0 - 1 + hp % 18;
+            const int y = hy0 - p.pad_t + hp / 18, x = hx0 - p.pad_l + hp % 18;      // (3x3: pad 1; the 2x2 parity convolutions of nn.UpConv2x: pad 0 or 1 per axis)
             hok[i] = hp < 180 && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
             hpix[i] = (hf * p.Hin + y) * p.Win + x;
             if (idx < HALO_PX * 8) *(uint4*)(sA0 + idx * 16) = make_uint4(0, 0, 0, 0);     // out-of-image halo stays zero (those lanes are masked in the DMA)
@@ -373,11 +374,11 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
         const int nchunks = Cin >> 6;
         for (int c = 0; c < nchunks; ++c) {
 #pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {
+            for (int tap = 0; tap < p.ksize * KW; ++tap) {
                 if (tap == 0) dma_halo(c);
                 dma_b(tap * Cin + c * 64, sB0);
                 __syncthreads();
-                k_step(nk, sA0, sB0, sA0, sB0, (tap / 3) * 18 + tap % 3);
+                k_step(nk, sA0, sB0, sA0, sB0, (tap / KW) * 18 + tap % KW);
             }
         }
     } else if (SPLIT == 2) {
@@ -473,8 +474,11 @@ int launch_mode(const vv_conv_params& p, int M, hipStream_t st) {
     }
 #endif
     static const bool nohalo = VV_AB_ENV("VV_GEMM_NO_HALO");
-    // (the halo tile maps tile rows to pixels itself: the ABI 9 output scatter lives in the other loaders' row map, so a scattered launch never takes it)
-    if (fast && !nohalo && p.sc_oh == 0 && p.in_dtype != VV_F32 && p.ksize == 3 && (p.ksize_w == 0 || p.ksize_w == 3) && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 &&
+    // 3x3 / pad 1, and (round 5) the 2x2 / pad 0 or 1 parity convolutions of nn.UpConv2x with their scattered store: the 10 x 18 halo of an 8 x 16 patch starts
+    // at (y0 - pad_t, x0 - pad_l) and holds every tap of both kernel sizes
+    const bool halo3 = p.ksize == 3 && (p.ksize_w == 0 || p.ksize_w == 3) && p.pad_t == 1 && p.pad_l == 1 && p.sc_oh == 0;
+    const bool halo2 = p.ksize == 2 && (p.ksize_w == 0 || p.ksize_w == 2) && p.pad_t >= 0 && p.pad_t <= 1 && p.pad_l >= 0 && p.pad_l <= 1;
+    if (fast && !nohalo && p.in_dtype != VV_F32 && (halo3 || halo2) && p.stride == 1 &&
         p.Hv == p.Hin && p.Wv == p.Win && p.Hout == p.Hin && p.Wout == p.Win && p.epilogue != VV_EPI_GEGLU && (p.Npad % 160 == 0 || p.Npad % 128 == 0 || (p.Npad % 16 == 0 && p.Npad <= 64))) {      // (the narrow tile: conv_out layers, 4 MFMAs per k tile -- all data movement, the halo saves 3/4 of it)
         // patch grid waste <= 15 % (the halo tile is worth 17-25 %)
         const int64_t cover = (int64_t)((p.Hin + 7) / 8) * 8 * ((p.Win + 15) / 16) * 16;
