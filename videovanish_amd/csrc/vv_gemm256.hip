@@ -162,7 +162,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const vv_conv_params p,
     }
 
     auto row_m = [&](int row, bool& ok) -> int { ok = m0 + row < M; return m0 + row; };
-    gemm_epilogue<T, MT, NT, true>(p, acc, wr * 128, n0 + wc * NT * 16, lr, lq, HWo, row_m);      // LEAN: one block per CU, nothing else covers the epilogue
+    // LEAN: one block per CU, nothing else covers the epilogue; the operand stages are dead (the k loop ended with a barrier): a wave-private strip tile in sB0 / sB1
+    gemm_epilogue<T, MT, NT, true, true>(p, acc, wr * 128, n0 + wc * NT * 16, lr, lq, HWo, row_m, nullptr, (float*)(wr ? sB1 : sB0) + wc * (16 * (NT * 16 + 4)));
 }
 
 

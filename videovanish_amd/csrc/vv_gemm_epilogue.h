@@ -13,12 +13,15 @@
 //     3x3 kernels (MODE_HALO: +1.5..3.4 % with a residual).  Measured losers: the LIN / FAST9 loaders (55 spilled registers, -30 %), the fp32-operand
 //     loader (FAST32, -8..-10 % at levels 1 / 2), and a column-by-column order of the same work (-8..-12 % on every fp32-residual shape: the 64-byte
 //     pieces of an output row are then written microseconds apart).
+//   * STAGED (with LEAN; the 2-phase 256-row kernel and the 128 x 160 halo-tile kernel, fp32 output with at most the fp32 residual): in the accumulator layout a wave
+//     instruction touches 16 rows x 64 bytes -- half a cache line per row and request.  A strip goes through a wave-private LDS tile (the operand stages are dead) and
+//     comes back row-major: 256 / W rows x W * 4 contiguous bytes per instruction.  out-proj L1 0.210 -> 0.189 ms, L2 0.146 -> 0.134; 3x3 + residual +1.1 %.
 #pragma once
 #include "vv_common.h"
 
-template <typename T, int MT, int NT, bool LEAN = false, typename RowMap>
+template <typename T, int MT, int NT, bool LEAN = false, bool STAGED = false, typename RowMap>
 __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&acc)[MT][NT], const int row0, const int ncol0, const int lr,
-                                              const int lq, const int HWo, RowMap row_m, const float* sbias = nullptr) {
+                                              const int lq, const int HWo, RowMap row_m, const float* sbias = nullptr, float* stage = nullptr) {
     // ---- epilogue: lane owns out[m][n .. n+3].  All bias / time-embedding / residual loads of one 16-row strip are issued
     // back to back into registers BEFORE their first use (one wait per strip instead of one per load).
     const bool geglu = p.epilogue == VV_EPI_GEGLU;
@@ -53,6 +56,45 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
                     else *(uint2*)((unsigned short*)p.out + oc) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
                 }
             }
+        }
+        return;
+    }
+    if (LEAN && STAGED && vec && stage && p.out_dtype == VV_F32 && p.split_heads <= 0 && !p.rowvec && !p.res1 && p.act == VV_ACT_NONE && (!p.res0 || r0f32)) {
+        // STAGED form of the lean path (fp32 trunk out, at most the fp32 residual: the out-projections and FF outputs of levels 1 / 2 -- streaming kernels, 60 % of
+        // their time in this epilogue).  In the accumulator layout a wave instruction touches 16 rows x 64 bytes: half a cache line per row and request.  A strip
+        // (16 rows x W columns) goes through a wave-private LDS tile instead and comes back row-major: each instruction then covers 256 / W rows x W * 4 contiguous bytes
+        // (320 bytes per row for the 80-column wave tile), residual read and store alike.  Same arithmetic, same order: bit-identical.
+        constexpr int W = NT * 16, PITCH = W + 4;
+        const int lane = lq * 16 + lr;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = ncol0 + j * 16 + 4 * lq;
+            const float4 b = (p.bias && n < N) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) { acc[i][j][0] += b.x; acc[i][j][1] += b.y; acc[i][j][2] += b.z; acc[i][j][3] += b.w; }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                *(float4*)(stage + lr * PITCH + j * 16 + 4 * lq) = make_float4(acc[i][j][0] * p.out_scale, acc[i][j][1] * p.out_scale, acc[i][j][2] * p.out_scale, acc[i][j][3] * p.out_scale);
+            float4 v[NT], r4[NT];
+            int64_t off[NT];
+            bool on[NT];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                const int idx = (q * 64 + lane) * 4, rr = idx / W, cc = idx - rr * W;
+                bool mok;
+                const int m = row_m(row0 + i * 16 + rr, mok);
+                on[q] = mok && ncol0 + cc < N;
+                off[q] = (int64_t)(mok ? m : 0);
+                r4[q] = (p.res0 && on[q]) ? *(const float4*)((const float*)p.res0 + off[q] * N + ncol0 + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                off[q] = off[q] * p.ldo + ncol0 + cc;
+                v[q] = *(const float4*)(stage + rr * PITCH + cc);
+            }
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+                if (on[q]) *(float4*)((float*)p.out + off[q]) = make_float4(v[q].x + r4[q].x, v[q].y + r4[q].y, v[q].z + r4[q].z, v[q].w + r4[q].w);
         }
         return;
     }
