@@ -409,8 +409,9 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
     }
 
     // LEAN epilogue (vv_gemm_epilogue.h) in the halo-tile 3x3 kernels: +1.5-3.4 % on the ResBlock / VAE convolutions with a residual, +0.3-1.1 % on the
-    // others.  NOT in the loaders held to 128 VGPRs for a fourth block per CU (LIN, FAST9: it spills there, -30 %) and not in the fp32-operand loader
-    // (FAST32: level 1 / 2 zero convolutions -8..-10 %): profiles/r5_epilogue_ab.txt
+    // others.  NOT in the loaders held to 128 VGPRs for a fourth block per CU (LIN, FAST9: it spills there, -30 %).  The fp32-operand loader (FAST32: zero
+    // convolutions, conv_shortcuts -- HBM-bound fp32-in / fp32-out layers) loses 8-10 % with the lean form alone and GAINS 9-15 % with lean + STAGED (row-major
+    // residual reads / stores through a wave-private LDS tile): profiles/r5_epilogue_ab.txt
     gemm_epilogue<T, MT, NT, MODE == MODE_HALO || (MODE == MODE_FAST32 && NT == 5), (MODE == MODE_HALO || MODE == MODE_FAST32) && NT == 5>(p, acc, wr * MT * 16, n0 + wc * NT * 16, lr, lq, HWo, row_m, stage_bias ? sBias + wc * NT * 16 : nullptr,
                                                 ((HALO || A32) && NT == 5) ? (float*)sA0 + wave * (16 * (NT * 16 + 4)) : nullptr);      // (halo tiles: a strip = 16 consecutive pixels of one image row; the halo buffer is dead after the k loop's last barrier)
 }
