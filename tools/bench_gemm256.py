@@ -79,6 +79,8 @@ CASES = [   # name, F, H, W, cin (or (c0,c1)), cout, k, stride, flags, calls per
     ("vae conv3 512->512 180x320 x4f", 4, 180, 320, 512, 512, 3, 1, "res", 0),
     ("vae conv3 256->256 360x640 x4f", 4, 360, 640, 256, 256, 3, 1, "res", 0),
     ("vae conv3 512->512 90x160 x4f", 4, 90, 160, 512, 512, 3, 1, "res", 0),
+    ("vae conv3 128->128 720x1280 x4f", 4, 720, 1280, 128, 128, 3, 1, "res", 0),
+    ("vae conv3 256->128 720x1280 x4f", 4, 720, 1280, 256, 128, 3, 1, "", 0),
     ("unet conv_out 320->4 90x160", F, 90, 160, 320, 4, 3, 1, "", 1),
     ("vae conv_out 128->3 720x1280 x4f", 4, 720, 1280, 128, 3, 3, 1, "", 0),
     ("big   K4096 N4096 M8192", 1, 8192, 1, 4096, 4096, 1, 1, "", 0),
