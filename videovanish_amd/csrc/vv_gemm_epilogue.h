@@ -11,11 +11,12 @@
 //     the 256-row kernels (vv_gemm256.hip: ONE block per CU, nothing else covers the epilogue; qkv L2 0.339 -> 0.303 ms, ff2 L2 0.390 -> 0.376,
 //     8192^3 1225 -> 1250 TFLOP/s -- and the 2-phase form now wins on the level-1 / level-2 linears with K >= 640, vv_gemm256_try) and by the halo-tile
 //     3x3 kernels (MODE_HALO: +1.5..3.4 % with a residual).  Measured losers: the LIN / FAST9 loaders (55 spilled registers, -30 %), the fp32-operand
-//     loader (FAST32, -8..-10 % at levels 1 / 2), and a column-by-column order of the same work (-8..-12 % on every fp32-residual shape: the 64-byte
+//     loader with the lean form ALONE (FAST32, -8..-10 % at levels 1 / 2; it gains with STAGED on top), and a column-by-column order of the same work (-8..-12 % on every fp32-residual shape: the 64-byte
 //     pieces of an output row are then written microseconds apart).
-//   * STAGED (with LEAN; the 2-phase 256-row kernel and the 128 x 160 halo-tile kernel, fp32 output with at most the fp32 residual): in the accumulator layout a wave
+//   * STAGED (with LEAN; the 2-phase 256-row kernel, the 128 x 160 halo-tile kernel and the fp32-operand loader; fp32 output with at most the fp32 residual): in the accumulator layout a wave
 //     instruction touches 16 rows x 64 bytes -- half a cache line per row and request.  A strip goes through a wave-private LDS tile (the operand stages are dead) and
-//     comes back row-major: 256 / W rows x W * 4 contiguous bytes per instruction.  out-proj L1 0.210 -> 0.189 ms, L2 0.146 -> 0.134; 3x3 + residual +1.1 %.
+//     comes back row-major: 256 / W rows x W * 4 contiguous bytes per instruction.  out-proj L1 0.210 -> 0.189 ms, L2 0.146 -> 0.134; zero convolutions (fp32 operand) +9..15 %;
+//     3x3 + residual +1.1 %.
 #pragma once
 #include "vv_common.h"
 
