@@ -246,6 +246,49 @@ def test_attention_spatial(gpu, dname, td, ulp, B, heads, Nq, Nkv, D):
 
 
 @pytest.mark.parametrize("dname,td,ulp", DT)
+@pytest.mark.parametrize("M,K,N,flags", [(3000, 640, 640, "res f32out"), (2900, 640, 640, "f32out"), (1000, 1280, 1280, "res f32out p8"), (2600, 640, 1920, "split80"),
+                                         (777, 640, 640, "h16out"), (2048, 640, 1280, "geglu"), (1500, 2560, 640, "res f32out scale")])
+def test_gemm_tile_forms_agree_on_every_epilogue(gpu, dname, td, ulp, M, K, N, flags):
+    """The epilogue forms of vv_gemm_epilogue.h (round 5: lean -- bias folded into the accumulators --, staged -- fp32 strips through a wave-private LDS tile, read /
+    written row-major --, and the old tile-by-tile form of the 128-row loaders) compute the same arithmetic in the same order: a linear layer run on the 128-row tile
+    (tile_hint 1), the 2-phase 256-row kernel (tile_hint 2: lean + staged) and the 8-phase one (tile_hint 3: lean; N % 256 == 0) gives the same bits, ragged last
+    row tile included, and matches fp32 torch on the rounded operands."""
+    from videovanish_amd import hip, packing
+    dt = hip.dtype_id(dname)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    geglu, res = "geglu" in flags, "res" in flags
+    f32out = "f32out" in flags
+    scale = 0.5 if "scale" in flags else 1.0
+    if geglu:
+        wi, bi = packing.geglu_interleave(w, b)
+        wp, bias = packing.pack_matrix(wi, td, geglu=True).to(gpu), bi.to(gpu)
+    else:
+        wp, bias = packing.pack_matrix(w, td).to(gpu), b.to(gpu)
+    r = torch.randn(M, N, generator=g) if res else None
+    kw = dict(F=1, Hin=M, Win=1, bias=bias, res0=r.to(gpu) if res else None, epilogue=hip.EPI_GEGLU if geglu else hip.EPI_NONE, out_scale=scale)
+    if "split80" in flags:
+        kw.update(split_heads=N // 3 // 80, split_dim=80, split_tokens=M // 2)      # two batch elements
+    xg = x.to(td).to(gpu)
+    outs = {}
+    for hint in (1, 2) + ((3,) if (N % 256 == 0 and ("p8" in flags or geglu)) else ()):
+        out = torch.zeros(M, N // 2 if geglu else N, dtype=torch.float32 if f32out else td, device=gpu)
+        hip.conv_gemm(dt, xg, wp, N, K, out=out, tile_hint=hint, **kw)
+        outs[hint] = out.float().cpu()
+    for hint, o in outs.items():
+        assert torch.equal(o, outs[1]), f"tile_hint {hint} differs from the 128-row tile"
+    if "split80" not in flags:
+        y = _r(x, td) @ _r(w, td).t() + b
+        if geglu:
+            y = y[:, : N // 2] * F.gelu(y[:, N // 2:])
+        ref = y * scale + (r if res else 0.0)
+        tol = (3e-4 if f32out else 2 * ulp) * max(1.0, ref.abs().max().item())
+        assert (outs[1] - ref).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("dname,td,ulp", DT)
 @pytest.mark.parametrize("Fr,H,W,Hv,Wv,C,N,f32in,precise", [(2, 9, 12, 18, 24, 64, 64, False, False), (2, 9, 12, 17, 24, 64, 96, False, False),
                                                            (1, 5, 8, 10, 16, 128, 64, True, False), (3, 2, 4, 3, 8, 64, 64, False, False),
                                                            (2, 23, 40, 45, 80, 64, 160, False, False), (1, 6, 7, 11, 13, 64, 64, False, False),
