@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
     }
     const int tile_n = bid % tilesN, tile_m = bid / tilesN;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    // (not for the fp32-operand loader: its HBM-bound zero convolutions LOSE 9-14 % when the stores stop waiting for each other, like with the LEAN form --
-    //  profiles/r5_epilogue_ab.txt; the halo-tile kernels run the LEAN form and need no staged copy)
+    // (not for the fp32-operand loader: with this alone its HBM-bound zero convolutions LOSE 9-14 % -- profiles/r5_epilogue_ab.txt; at 128 x 160 it runs the LEAN + STAGED
+    //  form instead, like the halo-tile kernels, which need no staged copy)
     const bool stage_bias = MODE != MODE_HALO && MODE != MODE_FAST32 && (p.N & 3) == 0 && p.epilogue != VV_EPI_GEGLU;       // (made visible by the k loop's barriers)
     if (stage_bias && t < BN / 4) {
         const int n = n0 + 4 * t;
