@@ -99,6 +99,63 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
         }
         return;
     }
+#ifdef VV_STAGE_H16
+    // LAB, opt-in (-DVV_STAGE_H16; written at the end of round 5 when the GPU budget was spent: it compiles, it has NOT run -- tests/test_kernels_gpu.py::
+    // test_gemm_tile_forms_agree_on_every_epilogue is the check, tools/jobs/r5_epilogue_ab.sh the A/B): the STAGED form for h16 outputs (QKV with the head-major store when a
+    // wave tile is exactly one head, proj_in, FF outputs stored h16).  In the accumulator layout a wave instruction writes 16 rows x 32 bytes; through the same fp32 LDS tile a
+    // lane takes 8 consecutive columns of a row instead (two ds_read_b128, at most two residual float4, one 16-byte store): W * 2 contiguous bytes per row.
+    if (LEAN && STAGED && vec && stage && p.out_dtype != VV_F32 && !p.rowvec && !p.res1 && p.act == VV_ACT_NONE && (!p.res0 || r0f32) && (N & 7) == 0 && (p.ldo & 7) == 0 &&
+        (p.split_heads <= 0 || p.split_dim == NT * 16)) {
+        constexpr int W = NT * 16, PITCH = W + 4, NQ = (16 * W + 511) / 512;
+        const int lane = lq * 16 + lr;
+        const bool split = p.split_heads > 0;
+        const int stok = p.split_tokens < 0 ? -p.split_tokens : p.split_tokens;
+        const int snb = p.split_tokens < 0 ? (p.F * HWo) / stok : 0;
+        const int64_t colpart0 = split ? (int64_t)(ncol0 / p.split_dim) * stok * p.split_dim : 0;      // the wave tile is one (which, head) block
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = ncol0 + j * 16 + 4 * lq;
+            const float4 b = (p.bias && n < N) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) { acc[i][j][0] += b.x; acc[i][j][1] += b.y; acc[i][j][2] += b.z; acc[i][j][3] += b.w; }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                *(float4*)(stage + lr * PITCH + j * 16 + 4 * lq) = make_float4(acc[i][j][0] * p.out_scale, acc[i][j][1] * p.out_scale, acc[i][j][2] * p.out_scale, acc[i][j][3] * p.out_scale);
+            float v[NQ][8];
+            int64_t off[NQ];
+            bool on[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int idx = (q * 64 + lane) * 8;
+                const bool valid = idx < 16 * W;
+                const int rr = valid ? idx / W : 0, cc = valid ? idx - rr * W : 0;
+                bool mok;
+                const int m = row_m(row0 + i * 16 + rr, mok);
+                on[q] = valid && mok && ncol0 + cc < N;
+                const int64_t mm = mok ? m : 0;
+                *(float4*)&v[q][0] = *(const float4*)(stage + rr * PITCH + cc);
+                *(float4*)&v[q][4] = *(const float4*)(stage + rr * PITCH + cc + 4);
+                if (p.res0 && on[q]) {
+                    const float* rp = (const float*)p.res0 + mm * N + ncol0 + cc;
+                    const float4 a4 = *(const float4*)rp, b4 = *(const float4*)(rp + 4);
+                    v[q][0] += a4.x; v[q][1] += a4.y; v[q][2] += a4.z; v[q][3] += a4.w; v[q][4] += b4.x; v[q][5] += b4.y; v[q][6] += b4.z; v[q][7] += b4.w;
+                }
+                if (split) {
+                    int64_t b, tok;
+                    if (snb) { tok = mm / snb; b = mm - tok * snb; } else { b = mm / stok; tok = mm - b * stok; }
+                    off[q] = (b * 3 * p.split_heads * stok + tok) * p.split_dim + colpart0 + cc;
+                } else off[q] = mm * p.ldo + ncol0 + cc;
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (on[q]) *(uint4*)((unsigned short*)p.out + off[q]) = pack8<T>(v[q]);
+        }
+        return;
+    }
+#endif
     if (LEAN && vec) {
         int colpart[NT];          // split_heads store: the column's (which, head, d) part of the output index (< 3*C*tokens)
         const bool split = p.split_heads > 0;
