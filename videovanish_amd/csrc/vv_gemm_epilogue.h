@@ -100,8 +100,8 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
         return;
     }
 #ifdef VV_STAGE_H16
-    // LAB, opt-in (-DVV_STAGE_H16; written at the end of round 5 when the GPU budget was spent: it compiles, it has NOT run -- tests/test_kernels_gpu.py::
-    // test_gemm_tile_forms_agree_on_every_epilogue is the check, tools/jobs/r5_epilogue_ab.sh the A/B): the STAGED form for h16 outputs (QKV with the head-major store when a
+    // LAB, opt-in (-DVV_STAGE_H16; written at the end of round 5: bit-equal to the other forms -- tools/pytest_with_lib.py on a lab build, tests/test_kernels_gpu.py::
+    // test_gemm_tile_forms_agree_on_every_epilogue + split-heads + UpConv2x cases: 48 passed -- but NOT TIMED yet, tools/jobs/r5_epilogue_ab.sh is the A/B): the STAGED form for h16 outputs (QKV with the head-major store when a
     // wave tile is exactly one head, proj_in, FF outputs stored h16).  In the accumulator layout a wave instruction writes 16 rows x 32 bytes; through the same fp32 LDS tile a
     // lane takes 8 consecutive columns of a row instead (two ds_read_b128, at most two residual float4, one 16-byte store): W * 2 contiguous bytes per row.
     if (LEAN && STAGED && vec && stage && p.out_dtype != VV_F32 && !p.rowvec && !p.res1 && p.act == VV_ACT_NONE && (!p.res0 || r0f32) && (N & 7) == 0 && (p.ldo & 7) == 0 &&
