@@ -83,6 +83,20 @@ def attn40q2_report():
     return tot, tot - ideal
 
 
+# ---- round 5, second session: the wave-private fp32 strip tile of the STAGED GEMM epilogue (vv_gemm_epilogue.h): ds_write_b128 in the accumulator layout
+#      (lane (lr, lq) -> row lr, columns 16 j + 4 lq), ds_read_b128 row-major (flat index 4 (64 q + lane) -> row, column)
+def staged_tile_report():
+    for W in (80, 64):
+        for pad in (0, 4, 8):
+            P = W + pad
+            wc = [cycles([((l & 15) * P + j * 16 + 4 * (l >> 4)) * 4 for l in range(64)], G128, 16) for j in range(W // 16)]
+            rc = [cycles([(((q * 64 + l) * 4 // W) * P + (q * 64 + l) * 4 % W) * 4 for l in range(64)], G128, 16) for q in range(W // 16)]
+            print(f"  W = {W}, pitch W + {pad}: write {wc[0]} cycles per instruction, read {max(rc)} (conflict-free: 4 each)")
+    print("  (the kernels use W + 4: 2-way on both sides = 80 LDS cycles per 16 x 80 strip against 60 with W + 8 or W + 0; the strip's residual read and store are ~1000x that)")
+
+
 if __name__ == "__main__":
     print("attn40q2_kernel, per 64-key tile and wave:")
     attn40q2_report()
+    print("staged GEMM epilogue tile:")
+    staged_tile_report()
