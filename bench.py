@@ -363,6 +363,67 @@ def cpu_baseline(H, W, steps, chunk, overlap, sample_hw=(256, 384), vae_hw=(192,
                       f"x{chunk / float(chunk - overlap):.2f} chunk overlap"}
 
 
+def self_launch(n, argv, dry_run=False):
+    """`python bench.py --gpus N ...` started WITHOUT a launcher (no WORLD_SIZE in the environment): start N fresh child processes of this script,
+    one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, the contract torch.distributed.run gives its
+    children), pass rank 0's stdout (the JSON line) through, forward the other ranks' stdout to stderr, and return the children's worst exit code.
+    The parent makes NO GPU call before or after (importing torch and counting devices do not initialise HIP); nothing is ever exec'd over a
+    process that has touched the GPU.  If a rank dies the others are ended by their exact PIDs (they would wait in a collective forever)."""
+    import socket
+    import subprocess
+    import threading
+    if not dry_run:
+        have = torch.cuda.device_count()      # (counting devices does not initialise the GPU on this image)
+        if have < n:
+            print(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node", file=sys.stderr)
+            return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if dry_run:
+            env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=subprocess.PIPE, text=True))
+
+    def pump(p, sink):
+        for line in p.stdout:
+            sink.write(line)
+            sink.flush()
+
+    pumps = [threading.Thread(target=pump, args=(p, sys.stdout if r == 0 else sys.stderr), daemon=True) for r, p in enumerate(procs)]
+    for t in pumps:
+        t.start()
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for r, p in enumerate(procs):      # a rank failed: end the rest (exact PIDs), they would hang in the next collective
+                if codes[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(timeout=30)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+            break
+        time.sleep(0.2)
+    for t in pumps:
+        t.join(timeout=10)
+    bad = [c for c in codes if c != 0]
+    if bad:
+        print(f"bench.py --gpus {n}: rank exit codes {codes}", file=sys.stderr)
+        return max(abs(c) for c in bad) or 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -404,12 +465,15 @@ def main():
         _unet.Denoiser.OVERLAP = False
         args.lanes = 1
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher (it has made no GPU call and makes none)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], dry_run=args.dry_run))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: one rank per GPU (launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}, or start it without WORLD_SIZE in the environment and it spawns its own ranks)")
     if not args.dry_run:
         torch.cuda.set_device(local_rank)
     dist = None
@@ -420,6 +484,8 @@ def main():
         else:
             td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = (rank, world)
+        if args.dry_run and os.environ.get("VV_DRYRUN_FAIL_RANK") == str(rank):      # tests/test_dist_cpu.py: one rank dies after the rendezvous
+            raise RuntimeError(f"dry run: rank {rank} told to fail (VV_DRYRUN_FAIL_RANK)")
 
     from videovanish_amd import hip
     hip.PROFILE_SHAPES = bool(args.profile_shapes)
@@ -439,9 +505,8 @@ def main():
     t_build = time.time()
     if args.dry_run:
         from videovanish_amd.pipeline import DryRunEraser
-        if args.frames <= 0:
-            raise SystemExit("bench.py --dry-run needs --frames T (the fixed-clip form)")
         model = DryRunEraser(run, "cpu")
+        args.no_kernel_events = args.no_cpu_baseline = args.no_power_trace = True      # no kernels run: nothing to price, nothing to compare
     else:
         model = DiffuEraserHIP(run, f"cuda:{local_rank}")
         torch.cuda.synchronize()
@@ -468,16 +533,19 @@ def main():
         assert len(plan) == n_chunks_per_rank * world
         mine = shard_chunks(len(plan), world)[rank]
         base, end = plan[mine[0]][0], plan[mine[-1]][1]
-        fr, mk, pr = synth_clip(end - base, H, W, seed=1234 + rank, t0=base)
+        # seeded per FRAME INDEX (synth_frame), so the video -- and with it every output frame -- does not depend on how many ranks share it
+        trip = [synth_frame(t, H, W) for t in range(base, end)]
+        fr, mk, pr = (np.stack([x[i] for x in trip]) for i in range(3))
+        del trip
         host_inputs[:] = [fr, pr, mk]
         return T, base, torch.from_numpy(fr).to(dev), torch.from_numpy(pr).to(dev), torch.from_numpy(mk).to(dev)
 
     def barrier():
-        torch.cuda.synchronize()
+        model._sync()
         if world > 1:
             import torch.distributed as td
             td.barrier()
-            torch.cuda.synchronize()
+            model._sync()
 
     if args.warmup > 0:
         T, base, fr, pr, mk = resident_inputs(args.warmup)
@@ -489,24 +557,44 @@ def main():
     t0 = time.time()
     if power is not None:
         power.__enter__()
-    out, (lo, hi) = model.forward_device(fr, pr, mk, T, base, steps=args.denoise_steps, scheduler="ddim", dist=dist)
+    tm = {} if world > 1 else None      # (N > 1 only: one device sync either side of the blend-time exchange, to report its seconds per rank)
+    out, (lo, hi) = model.forward_device(fr, pr, mk, T, base, steps=args.denoise_steps, scheduler="ddim", dist=dist, timings=tm)
+    model._sync()
+    dt_mine = time.time() - t0           # this rank's own seconds (before it waits for the slowest rank in the barrier)
     barrier()
     dt = time.time() - t0
     if power is not None:
         power.__exit__()
+    # what the collective layer itself reports: a launcher that silently started fewer ranks, or a backend that is not RCCL, shows up in the line
+    backend, ranks_seen, per_rank = "none", 1, [{"rank": 0, "seconds": round(dt_mine, 3), "chunks": args.steps, "owned_frames": hi - lo}]
     if world > 1:
         import torch.distributed as td
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         dt = float(tt.item())
+        backend, ranks_seen = td.get_backend(), td.get_world_size()
+        per_rank = [None] * world
+        sent = model.last_blend.sent_bytes if model.last_blend is not None else 0
+        td.all_gather_object(per_rank, {"rank": rank, "seconds": round(dt_mine, 3), "chunks": args.steps, "owned_frames": hi - lo,
+                                        "exchange_blend_s": round(tm.get("exchange_blend_s", 0.0), 4), "overlap_bytes_sent": int(sent)})
+    frame_sha = None
+    if args.dry_run:      # per-frame fingerprints of what every rank owns (dry run only): the N-rank weak line computes the frames of the one-rank line
+        import hashlib
+        mine_sha = {lo + j: hashlib.sha256(out[j].numpy().tobytes()).hexdigest()[:16] for j in range(hi - lo)}
+        alls = [mine_sha]
+        if world > 1:
+            alls = [None] * world
+            td.all_gather_object(alls, mine_sha)
+        frame_sha = [v for _, v in sorted((k, v) for d in alls for k, v in d.items())]
+        assert len(frame_sha) == T, "dry run: the ranks' owned frames do not tile the video"
     distinct = stride * args.steps * world          # credited frames: every chunk contributes (chunk - overlap) new frames
     assert out is not None and out.dtype == torch.uint8 and out.shape[1:] == (H, W, 3)
     # SURVEY 8(d) defines the metric host memory -> host memory; `value` keeps the inputs resident (the driver contract), the copies this rank would add
     # are measured right here on the same tensors and reported beside it (`host_to_host`)
-    torch.cuda.synchronize()
+    model._sync()
     t_up = time.time()
     ups = [torch.from_numpy(a).to(dev) for a in host_inputs]
-    torch.cuda.synchronize()
+    model._sync()
     t_up = time.time() - t_up
     del ups
     t_down = time.time()
@@ -571,9 +659,11 @@ def main():
         "metric": f"inpainted frames/sec at {H}p, {args.denoise_steps} denoise steps", "value": round(distinct / dt, 5), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "ranks_seen": ranks_seen, "collective_backend": backend, "per_rank": per_rank,
+        **({"dry_run": True, "frame_sha256_16": frame_sha} if args.dry_run else {}),
         "config": {"workload": f"{ {480: 'c2', 720: 'c3', 1080: 'c4'}.get(H, 'custom') } chunk: {args.chunk}-frame {W}x{H} chunk, {args.denoise_steps} DDIM steps, {args.chunk}/{args.overlap} chunk/overlap, "
                                f"{args.arch} SD-1.5 UNet+BrushNet+motion / SD-VAE, random-init weights",
-                   "frames_per_step": args.chunk, "credited_frames_per_step": stride, "chunks_per_rank": args.steps,
+                   "frames_per_step": args.chunk, "credited_frames_per_step": stride, "chunks_per_rank": args.steps, "chunks_total": args.steps * world,
                    "parallelism": f"chunk-dp{world}", "model_build_s": round(t_build, 1), "precise_decoder": bool(args.precise_decoder),
                    "concurrent_chunks": min(model.run.concurrent_chunks, args.steps),
                    "streams_per_chunk": 2 if (min(model.run.concurrent_chunks, args.steps) == 1 and __import__("videovanish_amd.unet", fromlist=["x"]).Denoiser.OVERLAP) else 1,

@@ -181,3 +181,164 @@ def test_bench_dry_run_multi_rank_equals_one_rank(world, T, shards):
     assert f"sharded {shards}" in many["config"]["workload"] and many["config"]["chunks"] == sum(shards)
     assert many["output_sha256"] == one["output_sha256"]
     assert all("exchange_blend_s" in t and "upload_s" in t for t in many["per_rank_seconds"])
+
+
+# ---- round 6: the exchange under RENDEZVOUS semantics (RCCL point-to-point), and bench.py without a launcher ----------------------------------
+class _RendezvousFabric:
+    """An in-process stand-in for RCCL's point-to-point semantics, which gloo does not have: a send COMPLETES only once the matching receive has
+    been posted (gloo buffers eagerly, so an early send costs nothing there and the gloo tests cannot see it).  Ranks are threads; every rank keeps a
+    logical clock (chunks computed so far); for every transfer the fabric records the clock of each side when its half was posted and the wall time
+    between the first and the second half."""
+
+    def __init__(self, world):
+        import threading
+        self.cv = threading.Condition()
+        self.clock = [0] * world
+        self.open = {}           # (src, dst) -> list of half-posted transfers in posting order
+        self.log = []            # (src, dst, clock at send post, clock at recv post, seconds the first half waited for the second)
+
+    def comm(self, rank):
+        return _RendezvousComm(self, rank)
+
+    def tick(self, rank):
+        with self.cv:
+            self.clock[rank] += 1
+
+    def _post(self, kind, rank, tensor, peer):
+        import time
+        key = (rank, peer) if kind == "send" else (peer, rank)
+        with self.cv:
+            q = self.open.setdefault(key, [])
+            other = "recv" if kind == "send" else "send"
+            half = next((h for h in q if other in h and kind not in h), None)
+            if half is None:
+                half = {}
+                q.append(half)
+            half[kind] = (tensor, self.clock[rank], time.time())
+            if "send" in half and "recv" in half:
+                half["recv"][0].copy_(half["send"][0])
+                half["done"] = True
+                q.remove(half)
+                self.log.append((key[0], key[1], half["send"][1], half["recv"][1], abs(half["send"][2] - half["recv"][2])))
+                self.cv.notify_all()
+        return half
+
+    def _wait(self, half):
+        with self.cv:
+            assert self.cv.wait_for(lambda: half.get("done"), timeout=60), "rendezvous never completed: a send or a receive has no partner"
+
+
+class _RendezvousComm:
+    def __init__(self, fabric, rank):
+        self.f, self.rank = fabric, rank
+
+    def post(self, ops):
+        import types
+        halves = [self.f._post(kind, self.rank, t, peer) for kind, t, peer in ops]
+        return [types.SimpleNamespace(wait=lambda h=h: self.f._wait(h)) for h in halves]
+
+
+@pytest.mark.parametrize("world,T", [(4, 256), (8, 1024), (3, 40), (2, 33)])
+def test_overlap_exchange_under_rendezvous_semantics(world, T):
+    """with a backend whose send blocks until the peer's receive is posted, (i) the exchange completes (no deadlock: a rank's sends
+    and receives are posted as one group), (ii) NO transfer is posted before its rank has computed all its chunks -- so nothing sits on a GPU waiting
+    for a peer that is still denoising; the wait is bounded by the rank skew (block sizes differ by at most one chunk), which the recorded clocks show,
+    (iii) the result is bit for bit the single-process blend."""
+    import threading
+    import time
+    chunk, overlap, H, W = 32, 8, 3, 4
+    plan = PL.chunk_plan(T, chunk, overlap)
+    wts = PL.blend_weights(plan)
+    shards = PL.shard_chunks(len(plan), world)
+    owner, chunk_rank = PL.frame_owner(plan, shards)
+    ref, _, _ = _run_rank(0, 1, T, chunk, overlap, H, W)
+    fabric = _RendezvousFabric(world)
+    results, errors = {}, []
+    chunk_s = 0.01
+
+    def rank_main(r):
+        try:
+            sb = PL.StreamingBlend(plan, wts, owner, chunk_rank, r, world, shards[r], (H, W), torch.device("cpu"), blend_fn=_cpu_blend, comm=fabric.comm(r))
+            for ci in shards[r]:
+                time.sleep(chunk_s)                                   # "denoise + decode" of one chunk
+                fabric.tick(r)
+                sb.add(ci, _fake_decoded(ci, plan[ci][1] - plan[ci][0], H, W))
+                assert not any("send" in h for h in fabric.open.get((r, r - 1), [])), "a send was posted before the rank had finished its chunks"
+            results[r] = sb.finish()
+        except BaseException as exc:
+            errors.append(exc)
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    out = np.zeros_like(ref.numpy())
+    for r, (acc, (lo, hi)) in results.items():
+        if acc is not None:
+            out[lo:hi] = acc.numpy()
+    assert np.array_equal(out, ref.numpy())
+    n_boundaries = sum(1 for r in range(1, world) if shards[r] and shards[r - 1])
+    assert len(fabric.log) >= n_boundaries and not any(fabric.open.values())
+    for src, dst, c_send, c_recv, waited in fabric.log:
+        assert c_send == len(shards[src]) and c_recv == len(shards[dst])      # both halves posted in finish(), after the rank's last chunk
+        assert waited < (abs(len(shards[src]) - len(shards[dst])) + 1) * chunk_s + 0.5      # outstanding for the rank skew only (<= one chunk) + thread jitter
+
+
+def _bench_no_launcher(argv, **extra_env):
+    """`python bench.py --gpus N ...` exactly as the driver types it for N = 1: NO torch.distributed.run, no RANK / WORLD_SIZE in the environment."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=900)
+    return p, [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher():
+    """bench.py --gpus 4 --dry-run --frames 256 with no launcher starts its own 4 ranks (fresh child processes), prints exactly
+    ONE JSON line (rank 0's) and exits 0; the frames are those of the one-rank run."""
+    p, lines = _bench_no_launcher(["--gpus", "4", "--dry-run", "--frames", "256", "--height", "16", "--width", "24", "--steps", "1", "--warmup", "1"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    many = lines[0]
+    assert many["n_gpus"] == 4 and many["ranks_seen"] == 4 and many["collective_backend"] == "gloo" and "sharded [3, 3, 3, 2]" in many["config"]["workload"]
+    assert many["output_sha256"] == _bench_dry_run(1, 256)["output_sha256"]
+
+
+def test_bench_default_weak_line_reports_the_ranks_it_saw():
+    """the DEFAULT line (weak scaling: every rank runs K chunks of one long video, the form the driver's SCALE run uses) carries
+    ranks_seen / collective_backend / chunks_per_rank / per-rank seconds, and -- dry run -- the frames of the 2-rank x 3-chunk job are bit for bit those
+    of the 1-rank x 6-chunk job (the overlap behind the rank boundary crossed the backend: overlap_bytes_sent)."""
+    p2, l2 = _bench_no_launcher(["--gpus", "2", "--dry-run", "--height", "16", "--width", "24", "--steps", "3", "--warmup", "1"])
+    p1, l1 = _bench_no_launcher(["--gpus", "1", "--dry-run", "--height", "16", "--width", "24", "--steps", "6", "--warmup", "1"])
+    assert p2.returncode == 0 and p1.returncode == 0, (p2.stderr[-1500:], p1.stderr[-1500:])
+    two, one = l2[-1], l1[-1]
+    assert len(l2) == 1 and two["scaling"] == "weak" and two["n_gpus"] == 2 and two["ranks_seen"] == 2 and two["collective_backend"] == "gloo"
+    assert two["config"]["chunks_per_rank"] == 3 and two["config"]["chunks_total"] == 6 and one["ranks_seen"] == 1
+    assert [r["rank"] for r in two["per_rank"]] == [0, 1] and all(r["chunks"] == 3 and r["seconds"] >= 0 for r in two["per_rank"])
+    assert two["per_rank"][0]["owned_frames"] + two["per_rank"][1]["owned_frames"] == 24 * 6 + 8
+    assert two["per_rank"][1]["overlap_bytes_sent"] == 8 * 16 * 24 * 3 * 4 and two["per_rank"][0]["overlap_bytes_sent"] == 0
+    assert two["frame_sha256_16"] == one["frame_sha256_16"] and len(one["frame_sha256_16"]) == 152
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    """A rank that dies after the rendezvous must not leave the launcher (or the ranks waiting for it in a collective) hanging: the launcher ends the
+    survivors by PID, prints no result line and exits non-zero -- within seconds, not at a watchdog's timeout."""
+    import time
+    t0 = time.time()
+    p, lines = _bench_no_launcher(["--gpus", "3", "--dry-run", "--frames", "100", "--height", "16", "--width", "24"], VV_DRYRUN_FAIL_RANK="1")
+    assert p.returncode != 0 and not lines and "rank exit codes" in p.stderr
+    assert time.time() - t0 < 120
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--frames", "64"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
