@@ -477,7 +477,10 @@ def main():
     if not args.dry_run:
         torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # VV_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, barriers, all_reduce / all_gather_object of the records) even at world 1 --
+    # the RCCL first-contact test that one GPU allows (tests/test_fullsize_gpu.py::test_bench_line_with_rccl_initialised)
+    multi = world > 1 or os.environ.get("VV_BENCH_FORCE_DIST") == "1"
+    if multi:
         import torch.distributed as td
         if args.dry_run:
             td.init_process_group("gloo")
@@ -498,7 +501,7 @@ def main():
         res = full_pipeline_c5(args, run, rank, world, dist, args.height, args.width, ucfg, vcfg)
         if rank == 0:
             print(json.dumps(res))
-        if world > 1:
+        if multi:
             import torch.distributed as td
             td.destroy_process_group()
         return
@@ -519,7 +522,7 @@ def main():
         if rank == 0:
             res["config"]["model_build_s"] = round(t_build, 1)
             print(json.dumps(res))
-        if world > 1:
+        if multi:
             import torch.distributed as td
             td.destroy_process_group()
         return
@@ -542,7 +545,7 @@ def main():
 
     def barrier():
         model._sync()
-        if world > 1:
+        if multi:
             import torch.distributed as td
             td.barrier()
             model._sync()
@@ -557,7 +560,7 @@ def main():
     t0 = time.time()
     if power is not None:
         power.__enter__()
-    tm = {} if world > 1 else None      # (N > 1 only: one device sync either side of the blend-time exchange, to report its seconds per rank)
+    tm = {} if multi else None      # (N > 1 only: one device sync either side of the blend-time exchange, to report its seconds per rank)
     out, (lo, hi) = model.forward_device(fr, pr, mk, T, base, steps=args.denoise_steps, scheduler="ddim", dist=dist, timings=tm)
     model._sync()
     dt_mine = time.time() - t0           # this rank's own seconds (before it waits for the slowest rank in the barrier)
@@ -567,7 +570,7 @@ def main():
         power.__exit__()
     # what the collective layer itself reports: a launcher that silently started fewer ranks, or a backend that is not RCCL, shows up in the line
     backend, ranks_seen, per_rank = "none", 1, [{"rank": 0, "seconds": round(dt_mine, 3), "chunks": args.steps, "owned_frames": hi - lo}]
-    if world > 1:
+    if multi:
         import torch.distributed as td
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
@@ -582,7 +585,7 @@ def main():
         import hashlib
         mine_sha = {lo + j: hashlib.sha256(out[j].numpy().tobytes()).hexdigest()[:16] for j in range(hi - lo)}
         alls = [mine_sha]
-        if world > 1:
+        if multi:
             alls = [None] * world
             td.all_gather_object(alls, mine_sha)
         frame_sha = [v for _, v in sorted((k, v) for d in alls for k, v in d.items())]
@@ -603,7 +606,7 @@ def main():
     del out_host
 
     if rank != 0:
-        if world > 1:
+        if multi:
             import torch.distributed as td
             td.destroy_process_group()
         return
@@ -684,7 +687,7 @@ def main():
     if args.dump_kernels:      # raw per-key table (launches, seconds, flops, algorithmic bytes); with --profile-shapes the GEMM keys carry M,N,K
         json.dump(kernels, open(args.dump_kernels, "w"))
     print(json.dumps(res))
-    if world > 1:
+    if multi:
         import torch.distributed as td
         td.destroy_process_group()
 

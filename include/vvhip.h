@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VV_ABI_VERSION 9
+#define VV_ABI_VERSION 10
 
 enum { VV_BF16 = 0, VV_F16 = 1, VV_F32 = 2, VV_U8 = 3,
        VV_SPLIT3 = 16 /* vv_groupnorm out_dtype only: the K-concatenated split-precision operand [rows][3C] of vv_split3, in the operand dtype */ };
@@ -161,7 +161,21 @@ int vv_motion_module_c320(const vv_motion_params* host_p, int dtype, void* strea
  * replaces 9 launches of vv_conv_gemm / vv_layernorm / vv_attention and their intermediates in HBM.  o: h16 [M][320] (the self-attention core's
  * output), t_in: fp32 [M][320] (proj_in output = the block's residual stream), x: fp32 [M][320] (the Transformer2D input), res1: optional fp32.
  * stream / params: packing.pack_chain_stream (462 slabs of [64][64] h16 incl. the per-head text K and V^T; 5120 floats).
+ * ABI 10 -- `layout` names the ORDER of the slabs inside the stream; it must be the one the library's kernel consumes (VV_CHAIN_LAYOUT_ROWSPLIT for
+ * the product build), else VV_E_ARG: the three orders have the same slab and parameter counts, so a size check cannot tell them apart (a stream packed
+ * the pre-round-5 way would compute wrong activations silently).  Order of VV_CHAIN_LAYOUT_ROWSPLIT, every slab [64 rows][64 k] h16, k pre-permuted
+ * (packing._permute_k) and pre-swizzled for the LDS ring:
+ *   25 slabs  Wo1 (5 row blocks x 5 k tiles)
+ *   4 x head pair (h, h+1):  for each of the two heads: 5 slabs Wq2[head] (40 -> 48 rows) | 2 slabs text K_h (77 keys -> 64 + 16 rows) | 2 slabs text
+ *             V_h^T (40 -> 48 rows x 128 keys);  then 5 slabs Wo2[:, head h] and 5 slabs Wo2[:, head h+1] (k = the head's 40 channels -> 64)
+ *   20 x 64-unit GEGLU chunk c:  10 slabs W1 rows [value | gate] of the chunk's hidden-unit row tiles in the order (0, 2, 1, 3) (row tile i = units
+ *             64 c + 16 i .. + 16: 16 value rows then their 16 gate rows), then 5 slabs W2[:, 64 c .. 64 c + 64]
+ *   25 slabs  Wout (proj_out)
+ * params (fp32): bo1 | ln2.g | ln2.b | bo2 | ln3.g | ln3.b | b1 in the W1 row order above (2560) | b2 | bout.
  * ------------------------------------------------------------------------------------------------------------ */
+#define VV_CHAIN_LAYOUT_TOKENS   0   /* lab kernels only (-DVV_CHAIN_FORM=0): per head q K V^T Wo, GEGLU row tiles (0, 1, 2, 3) -- the order of ABI <= 9 before round 5 */
+#define VV_CHAIN_LAYOUT_ROWSPLIT 1   /* the product kernel */
+#define VV_CHAIN_LAYOUT_COLUMNS  2   /* lab kernel only (-DVV_CHAIN_FORM=2): per-wave fragment streams, 3480 slabs */
 typedef struct {
     const void* o; const float* t_in; const float* x; const float* res1;
     void* out; int32_t out_dtype;
@@ -169,6 +183,7 @@ typedef struct {
     int64_t M;
     int32_t C, heads, text_len;
     int32_t n_slabs, n_params;
+    int32_t layout;                   /* VV_CHAIN_LAYOUT_* of `stream` (ABI 10) */
 } vv_chain_params;
 int vv_spatial_chain_c320(const vv_chain_params* host_p, int dtype, void* stream);
 

@@ -78,8 +78,19 @@ def attention(q, k, v, heads):
     q = q.view(B, Nq, heads, d).transpose(1, 2)
     k = k.view(B, -1, heads, d).transpose(1, 2)
     v = v.view(B, -1, heads, d).transpose(1, 2)
-    s = (q @ k.transpose(-1, -2)) * (d ** -0.5)
-    o = torch.softmax(s, dim=-1) @ v
+    Nk = k.shape[2]
+    if B * heads * Nq * Nk <= (1 << 28):
+        s = (q @ k.transpose(-1, -2)) * (d ** -0.5)
+        o = torch.softmax(s, dim=-1) @ v
+        return o.transpose(1, 2).reshape(B, Nq, C)
+    # the benchmarked geometries (N = 14400 at 720p, 32400 at 1080p: 13 / 34 GB of scores for 2 / 1 frames): the same arithmetic over blocks of query
+    # rows -- every softmax row is complete inside its block, so only the memory changes (tests/test_oracle_cpu.py pins the two forms against each other)
+    o = torch.empty((B, heads, Nq, d), dtype=q.dtype)
+    rows = max(1, (1 << 28) // (B * heads * Nk))
+    kt = k.transpose(-1, -2)
+    for a in range(0, Nq, rows):
+        s = (q[:, :, a:a + rows] @ kt) * (d ** -0.5)
+        o[:, :, a:a + rows] = torch.softmax(s, dim=-1) @ v
     return o.transpose(1, 2).reshape(B, Nq, C)
 
 
@@ -176,6 +187,13 @@ def _backbone(P, pre, x, temb, text, cfg, motion, add_down=None, add_mid=None, a
     """Shared down/mid/up traversal.  Returns (x, down_skips, mid, up_outputs)."""
     L = len(cfg.block_out)
     skips = [x]
+    # the ONE switch for the BrushNet down-residual site (config.UNetConfig.brushnet_add, [UNVERIFIED-3P]): "hidden" = into the running hidden state
+    # (the skip taken after a layer then carries it; the conv_in skip is taken before), "skip" = onto the skip copies after the down path
+    into_hidden = add_down is not None and cfg.brushnet_add == "hidden"
+    assert cfg.brushnet_add in ("skip", "hidden")
+    hid = list(add_down) if into_hidden else None
+    if into_hidden:
+        x = x + hid.pop(0)
     cin = cfg.block_out[0]
     for i, cout in enumerate(cfg.block_out):
         for j in range(cfg.layers_per_block):
@@ -184,13 +202,17 @@ def _backbone(P, pre, x, temb, text, cfg, motion, add_down=None, add_mid=None, a
                 x = spatial_transformer(P, f"{pre}.down_blocks.{i}.attentions.{j}", x, text, cfg)
             if motion:
                 x = motion_module(P, f"{pre}.down_blocks.{i}.motion_modules.{j}", x, cfg)
+            if into_hidden:
+                x = x + hid.pop(0)
             skips.append(x)
             cin = cout
         if i < L - 1:
             x = conv2d(P, f"{pre}.down_blocks.{i}.downsamplers.0.conv", x, cout, stride=2)
+            if into_hidden:
+                x = x + hid.pop(0)
             skips.append(x)
     down_skips = list(skips)
-    if add_down is not None:
+    if add_down is not None and not into_hidden:
         skips = [s + a for s, a in zip(skips, add_down)]
     C = cfg.block_out[-1]
     x = resnet_block(P, f"{pre}.mid_block.resnets.0", x, temb, C, cfg.groups)

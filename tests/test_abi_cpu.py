@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_binding_lists_match_header(lib):
     from videovanish_amd import hip
     assert sorted(hip.EXPORTS) == _declared()
-    assert lib.vv_abi_version() == hip.ABI_VERSION == 9
+    assert lib.vv_abi_version() == hip.ABI_VERSION == 10
 
 
 def test_integration_md_binding_snippet_version_check(lib):
@@ -97,6 +97,38 @@ def test_product_path_has_no_cpu_fallback():
     assert "oracle" not in txt
 
 
+def test_chain_stream_layout_is_part_of_the_abi(lib):
+    """ABI 10: vv_spatial_chain_c320 refuses a weight stream whose `layout` is not the order its kernel consumes -- the orders have equal slab
+    and parameter counts, so only the id can tell a stream packed the pre-round-5 way from the current one.  Checked before anything touches a device."""
+    from videovanish_amd import hip, packing
+    lib.vv_last_error.restype = ctypes.c_char_p
+    assert hip.CHAIN_LAYOUT_IDS[packing.CHAIN_LAYOUT] == 1
+    hdr = open(os.path.join(ROOT, "include", "vvhip.h")).read()
+    for name, val in (("TOKENS", 0), ("ROWSPLIT", 1), ("COLUMNS", 2)):
+        assert re.search(rf"#define VV_CHAIN_LAYOUT_{name}\s+{val}\b", hdr)
+    buf = (ctypes.c_char * 64)()
+    addr = ctypes.addressof(buf)
+    base = dict(o=addr, t_in=addr, x=addr, res1=0, out=addr, out_dtype=hip.F32, stream=addr, params=addr, M=128, C=320, heads=8, text_len=77, n_slabs=462, n_params=5120)
+    for stale in (0, 2, 7):
+        cp = hip.ChainParams(layout=stale, **base)
+        assert lib.vv_spatial_chain_c320(ctypes.byref(cp), hip.F16, None) == -1
+        msg = lib.vv_last_error()
+        assert b"layout" in msg and str(stale).encode() in msg, msg
+
+
+def test_product_sources_carry_no_timing_probes():
+    """VERDICT r5 hygiene 10: switches that make a kernel compute wrong results (timing probes) live in lab headers / tools/lab/*.patch, never in a
+    translation unit of the product library."""
+    csrc = os.path.join(ROOT, "videovanish_amd", "csrc")
+    product = [f for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".c")) and "_lab" not in f and f != "vv_conv3.hip"]
+    assert "vv_chain.hip" in product and "vv_motion.hip" in product
+    for f in product:
+        txt = open(os.path.join(csrc, f)).read()
+        for tok in ("VV_PROBE_", "VV_CHAIN_PROBE_", "VV_MOTION_NO_PIN"):
+            assert tok not in txt, (f, tok)
+    assert os.path.isfile(os.path.join(ROOT, "tools", "lab", "r5_chain_probes.patch"))
+
+
 def test_struct_layouts_match_header(tmp_path):
     """sizeof / offsetof of the three parameter structs as gcc compiles include/vvhip.h == the ctypes mirrors in hip.py."""
     import subprocess
@@ -104,7 +136,8 @@ def test_struct_layouts_match_header(tmp_path):
     probes = {"vv_conv_params": (hip.ConvParams, ["weight", "bias", "out", "ldo", "act", "split_heads", "split_tokens", "tile_hint", "act_slope"]),
               "vv_deform_params": (hip.DeformParams, ["x_dtype", "offset", "flow", "max_residue", "col", "B", "deform_groups", "Wo"]),
               "vv_attn_params": (hip.AttnParams, ["o", "q_rs", "D", "scale", "q_hs", "v_hs", "q_prescaled"]),
-              "vv_groupnorm_params": (hip.GroupNormParams, ["groups", "eps", "gamma", "stats_ws", "out_dtype"])}
+              "vv_groupnorm_params": (hip.GroupNormParams, ["groups", "eps", "gamma", "stats_ws", "out_dtype"]),
+              "vv_chain_params": (hip.ChainParams, ["out_dtype", "stream", "M", "text_len", "n_params", "layout"])}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "vvhip.h"', "int main(void) {"]
     for name, (_, fields) in probes.items():
         src.append(f'  printf("{name} %zu", sizeof({name}));')

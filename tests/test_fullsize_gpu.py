@@ -231,6 +231,23 @@ def test_bench_contract_line(gpu):
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
 
 
+def test_bench_line_with_rccl_initialised(gpu):
+    """First contact with RCCL that one GPU allows: bench.py as a launcher starts it for --nproc-per-node 1 with the multi-rank code path FORCED
+    (VV_BENCH_FORCE_DIST=1: init_process_group("nccl"), barriers, the max-over-ranks all_reduce, all_gather_object of the per-rank records on the GPU,
+    destroy) -- the library loads, the communicator comes up under HSA_ENABLE_IPC_MODE_LEGACY=0, the collectives the N-GPU line uses run, and the line
+    says which backend it saw.  The overlap exchange itself needs a second GPU (gloo / rendezvous-fabric tests in tests/test_dist_cpu.py)."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VV_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--arch", "tiny", "--height", "128", "--width", "192", "--denoise-steps", "2",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-events", "--no-power-trace"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["collective_backend"] == "nccl" and d["ranks_seen"] == 1 and d["n_gpus"] == 1
+    assert d["per_rank"][0]["rank"] == 0 and d["per_rank"][0]["chunks"] == 2 and d["per_rank"][0]["owned_frames"] == 56 and d["value"] > 0
+
+
 def test_fused_kernels_full_size_vs_layer_by_layer(gpu):
     """The fused level-0 kernels (spatial chain front + tail, motion module) launch 3600 blocks over 460 800 tokens at 720p but were compared with
     the oracle at <= 384 tokens only (tests/test_chain_gpu.py, tests/test_motion_gpu.py).  Here: the full size (32 frames of 90 x 160, C = 320,

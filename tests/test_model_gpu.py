@@ -253,6 +253,70 @@ def test_full_architecture_one_step(gpu):
     assert zmax <= 4e-3 and dmax <= 4e-3
 
 
+def _one_step_vs_oracle(gpu, ucfg, Fr, h, w, t=441, seed=13, dname="fp16"):
+    """one denoiser evaluation eps = UNet(lat | BrushNet(lat, cond, mask)) on seeded inputs: HIP path vs oracle/model_ref.py -> (rel max, rel rms, got, ref)"""
+    from oracle import model_ref as M
+    from videovanish_amd.nn import Ctx
+    from videovanish_amd.unet import Denoiser
+    P = M.Params(0)
+    g = torch.Generator().manual_seed(seed)
+    lat = torch.randn(Fr, 4, h, w, generator=g)
+    cond = torch.randn(Fr, 4, h, w, generator=g)
+    mask = (torch.rand(Fr, h * 8, w * 8, generator=g) > 0.6).to(torch.uint8) * 255
+    m_lat = torch.nn.functional.interpolate((mask > 0).float()[:, None], size=(h, w), mode="nearest")
+    text = M.text_states(P, ucfg)
+    with torch.no_grad():
+        ref = M.unet_forward(P, lat, t, text, ucfg, M.brushnet_forward(P, torch.cat([lat, cond, m_lat], 1), t, text, ucfg))
+    P.cache.clear()
+    ctx = Ctx("cuda:0", dname, 0)
+    den = Denoiser(ctx, ucfg, ctx.src.normal("text_states", (1, ucfg.text_len, ucfg.cross_dim)))
+    eps = den(_nhwc(lat).to(gpu), _nhwc(cond).to(gpu), mask.to(gpu), t, Fr, h, w, h * 8, w * 8)
+    got = eps.cpu().permute(0, 3, 1, 2)
+    del den, eps
+    torch.cuda.empty_cache()
+    emax, erms = _rel(got, ref)
+    return emax, erms, got, ref
+
+
+@pytest.mark.parametrize("cname,ucfg,Fr,h,w", [("tiny", TINY_UNET, 5, 6, 7), ("small", SMALL_UNET, 4, 9, 6)])
+def test_brushnet_residual_site_modes(gpu, cname, ucfg, Fr, h, w):
+    """UNetConfig.brushnet_add ([UNVERIFIED-3P], VERDICT r5 missing 3): the BrushNet down residuals onto the skip copies ("skip", the default) or into the
+    running hidden state ("hidden", the public BrushNet blocks' way).  The HIP path follows the oracle in BOTH modes, and the modes are really
+    different networks (so a wrong site could not hide inside the tolerance)."""
+    import dataclasses
+    out = {}
+    for mode in ("skip", "hidden"):
+        cfg = dataclasses.replace(ucfg, brushnet_add=mode)
+        emax, erms, got, ref = _one_step_vs_oracle(gpu, cfg, Fr, h, w, t=621, seed=11)
+        _log(f"brushnet_add[{cname},{mode}]", rel_max=emax, rel_rms=erms)
+        assert torch.isfinite(got).all() and emax <= 4e-3 and erms <= 3e-3
+        out[mode] = ref
+    d = (out["skip"] - out["hidden"]).abs().max().item() / out["skip"].abs().max().item()
+    _log(f"brushnet_add[{cname}] skip-vs-hidden", rel_max=d)
+    assert d > 2e-2
+
+
+# latent grids of the BENCHMARKED geometries (SURVEY 8: c2 848x480 -> 60x106, c3 / c5 1280x720 -> 90x160, c4 1920x1080 -> 135x240): the
+# 90 -> 45 -> 23 -> 12 / 60 -> 30 -> 15 -> 8 / 135 -> 68 -> 34 -> 17 pyramids with their odd sizes (UpConv2x edge launches, "resize to the skip"),
+# N = 14400 / 3600 / 920 / 240 attention lengths and the 720p / 1080p tile heuristics (vv_gemm256_try) -- none of which the 8 x 10 case reaches
+@pytest.mark.parametrize("cname,Fr,h,w", [("c2", 2, 60, 106), ("c3", 2, 90, 160), ("c4", 1, 135, 240)])
+def test_full_architecture_one_step_at_benchmarked_geometry(gpu, cname, Fr, h, w):
+    """one evaluation of the FULL-width UNet + BrushNet + motion modules, fp16 operands (the bench line's arithmetic), at the
+    latent grid of BASELINE configs 2 / 3 / 4 against the fp32 oracle (oracle/model_ref.py::unet_forward, brushnet_forward) with the same seeded
+    weights: F = 2 frames (1 at 1080p) keep the CPU side to ~3 / 9 / 29 TFLOP per frame.  Same bound as the 8 x 10 case: rel max <= 4e-3."""
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(64, os.cpu_count() or 1))      # big convolutions: the oracle scales here (the conftest's 16 are for small tensors)
+    try:
+        import time
+        t0 = time.time()
+        emax, erms, got, ref = _one_step_vs_oracle(gpu, UNetConfig(), Fr, h, w, t=441, seed=17)
+        _log(f"denoiser[FULL,fp16,{cname} latent {h}x{w},F={Fr}]", rel_max=emax, rel_rms=erms, seconds=time.time() - t0)
+    finally:
+        torch.set_num_threads(nthreads)
+    assert torch.isfinite(got).all()
+    assert emax <= 4e-3 and erms <= 3e-3
+
+
 def test_reference_default_two_step_tcd(gpu):
     """The reference's own default (diffuerase.py:37: ckpt forced to "2-Step" => 2 TCD steps, gamma 0.3, seeded re-noising)."""
     import diffuerase
@@ -443,6 +507,33 @@ def test_cli_main_on_the_hip_path(gpu, tmp_path, monkeypatch):
         assert len(part) == 2
     finally:
         diffuerase.configure(None)
+
+
+def test_fp16_operand_overflow_fails_loudly(gpu):
+    """VERDICT r5 hygiene 8: F16::from_f32 does not saturate, so a trained checkpoint's outlier beyond 65504 becomes inf in an h16 operand and NaN in every
+    pixel of its frame.  The pipeline must FAIL BY NAME (FloatingPointError naming the chunk and the remedy), never blend NaN pixels into a result; the same
+    weights run finite with bf16 operands (fp32's range)."""
+    from videovanish_amd.pipeline import DiffuEraserHIP
+    from videovanish_amd.weights import SyntheticWeights
+
+    class Outlier(SyntheticWeights):
+        def conv(self, name, cin, cout, k, gain=1.0):
+            w, b = super().conv(name, cin, cout, k, gain)
+            if name == "unet.down_blocks.0.resnets.0.conv1":
+                w = w.clone()
+                w[3, 5, 1, 1] = 3.0e5           # one weight beyond the fp16 range
+            return w, b
+
+    T, H, W = 6, 32, 48
+    frames, masks, prior = _clip(T, H, W, seed=21)
+    run = RunConfig(steps=2, chunk=4, overlap=2, seed=1, dtype="fp16", unet=TINY_UNET, vae=TINY_VAE)
+    model = DiffuEraserHIP(run, "cuda:0", weights=Outlier(0))
+    with pytest.raises(FloatingPointError, match="65504"):
+        model.forward(list(frames), [m[..., 0] for m in masks], list(prior), max_img_size=64)
+    import dataclasses
+    model = DiffuEraserHIP(dataclasses.replace(run, dtype="bf16"), "cuda:0", weights=Outlier(0))
+    out = model.forward(list(frames), [m[..., 0] for m in masks], list(prior), max_img_size=64)
+    assert len(out) == T and all(o.dtype == np.uint8 for o in out)
 
 
 def test_two_stream_schedule_is_bit_identical(gpu):

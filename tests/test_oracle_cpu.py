@@ -276,3 +276,18 @@ def test_cv2_restatements_against_independent_implementations():
     edt = ndimage.distance_transform_edt(src)
     inner = (edt > 0)
     assert (np.abs(got - edt)[inner] / edt[inner]).max() <= 0.045
+
+
+def test_blocked_attention_equals_the_direct_form(monkeypatch):
+    """oracle/model_ref.py::attention switches to blocks of query rows above 2^28 score elements (the benchmarked 720p / 1080p grids): same arithmetic,
+    softmax rows complete inside a block.  Pinned here against the direct form on a size just above the switch."""
+    import torch
+    from oracle import model_ref as M
+    g = torch.Generator().manual_seed(3)
+    B, N, C, heads = 1, 5800, 64, 8                      # 8 * 5800^2 = 2.69e8 > 2^28: the blocked branch (4 blocks of 5785 + 15 rows)
+    q, k, v = (torch.randn(B, N, C, generator=g) for _ in range(3))
+    got = M.attention(q, k, v, heads)
+    d = C // heads
+    qh, kh, vh = (t.view(B, N, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax((qh @ kh.transpose(-1, -2)) * d ** -0.5, dim=-1) @ vh).transpose(1, 2).reshape(B, N, C)
+    assert (got - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()

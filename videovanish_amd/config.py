@@ -18,6 +18,14 @@ class UNetConfig:
     brush_in_ch: int = 9          # 4 noisy latents + 4 masked-image latents + 1 mask
     motion_max_seq: int = 32
     zero_conv_gain: float = 0.5
+    # WHERE the BrushNet down residuals enter the UNet ([UNVERIFIED-3P]: the fork's model code is not in the image; VERDICT r5 missing 3).
+    #   "skip"   -- added to the skip copies only, after the down path (SURVEY App. D.3's wording; the build's default since round 1);
+    #   "hidden" -- added into the running hidden state after conv_in, after every resnet / attention / motion layer and after every downsampler,
+    #               so the skip taken there already carries it (how the public BrushNet blocks do it: `hidden_states = hidden_states +
+    #               down_block_add_samples.pop(0)` before `output_states += (hidden_states,)`; the conv_in skip is taken BEFORE its residual).
+    # One switch, honoured by oracle/model_ref.py::_backbone and unet._Backbone.run_down alike; parity is asserted in both modes
+    # (tests/test_model_gpu.py::test_brushnet_residual_site_modes).  The mid and up residuals enter the hidden state in both.
+    brushnet_add: str = "skip"
 
     @property
     def temb_dim(self):

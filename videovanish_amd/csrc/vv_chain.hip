@@ -30,9 +30,6 @@ __device__ __forceinline__ void glds16_asm(const void* gptr, void* lds_wave_base
 
 // two GELUs at once on packed fp32 math (exact erf GELU through Abramowitz-Stegun 7.1.26; see vv_motion.hip)
 __device__ __forceinline__ vv_f32x2 gelu2(vv_f32x2 x) {
-#ifdef VV_CHAIN_PROBE_NOGELU      // timing probe only (wrong results): what the activation's VALU work costs
-    return x;
-#endif
     const vv_f32x2 ax = {fabsf(x.x), fabsf(x.y)};
     const vv_f32x2 z = ax * 0.70710678118654752f;
     const vv_f32x2 d = __builtin_elementwise_fma(z, (vv_f32x2){0.3275911f, 0.3275911f}, (vv_f32x2){1.0f, 1.0f});
@@ -71,11 +68,7 @@ __device__ __forceinline__ vv_f32x2 gelu2(vv_f32x2 x) {
 // head's 14 slabs), the head's O goes through LDS and its output projection is row-split again; stream order per head pair: q K V^T | q K V^T | Wo | Wo.
 // Synchronisation: explicit steps (LDS-DMA issue of the slabs about to be consumed + counted vmcnt + one barrier) in front of every slab pair of a group.
 constexpr int RS_NS = 10, RS_AH = 6, RS_XBUF = 40960;
-#ifdef VV_PROBE_NOVMWAIT
-#define VV_WAIT6 do {} while (0)
-#else
 #define VV_WAIT6 asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
-#endif
 
 template <typename T>
 __global__ __launch_bounds__(512, 2) void chain_rs_c320_kernel(const vv_chain_params p) {
@@ -95,13 +88,7 @@ __global__ __launch_bounds__(512, 2) void chain_rs_c320_kernel(const vv_chain_pa
     const unsigned char* sbase = (const unsigned char*)p.stream + wave * 1024 + lane * 16;
     int issued = 0, islot = 0, cslot = 0;
     auto issue = [&]() {
-#if defined(VV_PROBE_REGLOAD)       // timing probe (wrong results): the same VMEM instruction count and bytes as the DMA, into a sink register set instead of LDS
-        asm volatile("global_load_dwordx4 a[0:3], %0, off" :: "v"(sbase + (int64_t)issued * SLAB) : "memory", "a0", "a1", "a2", "a3");
-#elif defined(VV_PROBE_SAMESLAB)      // timing probe (wrong results): every DMA reads slab (issued & 7) -- the issue cost without the stream's memory side
-        glds16_asm(sbase + (int64_t)(issued & 7) * SLAB, ring + islot * SLAB + wave * 1024);
-#elif !defined(VV_PROBE_NODMA)
         glds16_asm(sbase + (int64_t)issued * SLAB, ring + islot * SLAB + wave * 1024);
-#endif
         ++issued;
         islot = islot + 1 == RS_NS ? 0 : islot + 1;
     };
@@ -127,9 +114,6 @@ __global__ __launch_bounds__(512, 2) void chain_rs_c320_kernel(const vv_chain_pa
             VV_WAIT6;
         }
         if constexpr (decltype(xch_tag)::value) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef VV_PROBE_NOBARRIER
-        if constexpr (decltype(xch_tag)::value)
-#endif
         __builtin_amdgcn_s_barrier();
     };
     using NOX = std::false_type; using XCH = std::true_type;
@@ -465,9 +449,6 @@ __global__ __launch_bounds__(512, 2) void chain_rs_c320_kernel(const vv_chain_pa
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) t[j][tt] = z4;
     dense320(t, TAIL{});          // stream slabs 437..461
-#ifdef VV_PROBE_REGLOAD
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     // Block residual: ALL 20 float4 of x (and of res1) are requested before the first store.  Read in place -- load, s_waitcnt vmcnt(0), store, per tile --
     // every wait also drained the previous tile's store: 20 serialised memory round trips at the end of every block (round 5, second session; the same
     // finding as in vv_gemm_epilogue.h).  The activation row registers are dead here, the 80 extra registers are free.
@@ -949,6 +930,7 @@ extern "C" int vv_spatial_chain_c320(const vv_chain_params* pp, int dtype, void*
     if (p.M <= 0) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: empty input");
     if (p.out_dtype != VV_F32 && p.out_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: out_dtype mismatch");
     const int want_slabs = VV_CHAIN_FORM == 2 ? 4 * 870 : N_SLABS;
+    if (p.layout != VV_CHAIN_FORM) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: weight stream packed in layout %d, this library's kernel consumes layout %d (VV_CHAIN_LAYOUT_*)", p.layout, (int)VV_CHAIN_FORM);
     if (p.n_slabs != want_slabs || p.n_params != Q_TOTAL) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: stream / parameter block size mismatch (%d slabs, %d floats)", p.n_slabs, p.n_params);
     const int64_t nblk = (p.M + 127) / 128;
     if (nblk > 0x7fffffff) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: grid too large");

@@ -20,6 +20,15 @@
 #pragma once
 #include "vv_common.h"
 
+// Order pin for the wave-private LDS exchange of the STAGED forms: lanes write the strip in the accumulator layout and read it back row-major --
+// OTHER lanes' data -- so the reads must stay behind the writes, and the next strip's writes behind this strip's reads.  The hardware keeps a wave's LDS
+// operations in order; this keeps the COMPILER from reordering may-alias LDS accesses it could one day prove independent per lane.  No instruction is emitted.
+__device__ __forceinline__ void stage_order_pin() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename T, int MT, int NT, bool LEAN = false, bool STAGED = false, typename RowMap>
 __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&acc)[MT][NT], const int row0, const int ncol0, const int lr,
                                               const int lq, const int HWo, RowMap row_m, const float* sbias = nullptr, float* stage = nullptr) {
@@ -79,6 +88,7 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 *(float4*)(stage + lr * PITCH + j * 16 + 4 * lq) = make_float4(acc[i][j][0] * p.out_scale, acc[i][j][1] * p.out_scale, acc[i][j][2] * p.out_scale, acc[i][j][3] * p.out_scale);
+            stage_order_pin();
             float4 v[NT], r4[NT];
             int64_t off[NT];
             bool on[NT];
@@ -93,6 +103,7 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
                 off[q] = off[q] * p.ldo + ncol0 + cc;
                 v[q] = *(const float4*)(stage + rr * PITCH + cc);
             }
+            stage_order_pin();
 #pragma unroll
             for (int q = 0; q < NT; ++q)
                 if (on[q]) *(float4*)((float*)p.out + off[q]) = make_float4(v[q].x + r4[q].x, v[q].y + r4[q].y, v[q].z + r4[q].z, v[q].w + r4[q].w);
@@ -124,6 +135,7 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 *(float4*)(stage + lr * PITCH + j * 16 + 4 * lq) = make_float4(acc[i][j][0] * p.out_scale, acc[i][j][1] * p.out_scale, acc[i][j][2] * p.out_scale, acc[i][j][3] * p.out_scale);
+            stage_order_pin();
             float v[NQ][8];
             int64_t off[NQ];
             bool on[NQ];
@@ -149,6 +161,7 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
                     off[q] = (b * 3 * p.split_heads * stok + tok) * p.split_dim + colpart0 + cc;
                 } else off[q] = mm * p.ldo + ncol0 + cc;
             }
+            stage_order_pin();
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
                 if (on[q]) *(uint4*)((unsigned short*)p.out + off[q]) = pack8<T>(v[q]);

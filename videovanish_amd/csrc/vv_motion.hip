@@ -175,12 +175,11 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
             slab_fma(f[i & 1], rt_tag, tr_tag, acc_of(i), x0_of(i), x1_of(i));
             if (i + 1 < N) __builtin_amdgcn_sched_group_barrier(0x100, 2 * RT, 0);      // next slab's reads first ...
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * RT, 0);                     // ... then this slab's MFMAs
-#ifndef VV_MOTION_NO_PIN      // (3.08 -> 3.025 ms at level 0, profiles/r5_chain_forms.txt section 5)
+            // (3.08 -> 3.025 ms at level 0, profiles/r5_chain_forms.txt section 5)
             // nothing crosses into the next slab's region (round 5): without this fence hipcc fills the MFMA group with the MFMAs of the slab whose reads
             // it has just issued -- the group barriers order instruction types, not instances -- and the fragment double buffer collapses into one
             // register set (profiles/r5_chain_forms.txt, section 1)
             __builtin_amdgcn_sched_barrier(0);
-#endif
         }
     };
     using P0E = std::integral_constant<int, 0>; using P0O = std::integral_constant<int, 1>;

@@ -12,7 +12,7 @@ BF16, F16, F32, U8 = 0, 1, 2, 3
 SPLIT3 = 16      # vv_groupnorm out_dtype: the K-concatenated split-precision operand (see split3)
 EPI_NONE, EPI_GEGLU = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 9
+ABI_VERSION = 10
 _DT = {"bf16": BF16, "fp16": F16}
 _TORCH_H16 = {BF16: torch.bfloat16, F16: torch.float16}
 
@@ -83,7 +83,10 @@ class MotionParams(C.Structure):
 class ChainParams(C.Structure):
     _fields_ = [("o", C.c_void_p), ("t_in", C.c_void_p), ("x", C.c_void_p), ("res1", C.c_void_p), ("out", C.c_void_p), ("out_dtype", C.c_int32),
                 ("stream", C.c_void_p), ("params", C.c_void_p), ("M", C.c_int64), ("C", C.c_int32), ("heads", C.c_int32), ("text_len", C.c_int32),
-                ("n_slabs", C.c_int32), ("n_params", C.c_int32)]
+                ("n_slabs", C.c_int32), ("n_params", C.c_int32), ("layout", C.c_int32)]
+
+
+CHAIN_LAYOUT_IDS = {"tokens": 0, "rowsplit": 1, "columns": 2}      # VV_CHAIN_LAYOUT_* (vvhip.h)
 
 
 class ChainFrontParams(C.Structure):
@@ -533,7 +536,12 @@ def split_f32(dtype, x, lo_scale):
     return hi, lo
 
 
-def spatial_chain_c320(dtype, o, t_in, x, stream_w, params, *, res1=None, out_dtype=torch.float32):
+def _packing():
+    from . import packing
+    return packing
+
+
+def spatial_chain_c320(dtype, o, t_in, x, stream_w, params, *, res1=None, out_dtype=torch.float32, layout=None):
     """The fused tail of a level-0 spatial transformer block (vv_chain.hip): attn1 out-proj + residual, cross-attention to the text tokens,
     GEGLU feed-forward, proj_out + block residual in ONE kernel.  o: h16 [M,320]; t_in, x (, res1): fp32 [M,320]."""
     _need_cuda(o, t_in, x, stream_w, params, res1)
@@ -542,7 +550,7 @@ def spatial_chain_c320(dtype, o, t_in, x, stream_w, params, *, res1=None, out_dt
     out = torch.empty((M, Cc), dtype=out_dtype, device=x.device)
     cp = ChainParams(o=o.data_ptr(), t_in=t_in.data_ptr(), x=x.data_ptr(), res1=res1.data_ptr() if res1 is not None else 0, out=out.data_ptr(),
                      out_dtype=dt_of(out), stream=stream_w.data_ptr(), params=params.data_ptr(), M=M, C=Cc, heads=8, text_len=77,
-                     n_slabs=stream_w.shape[0], n_params=params.numel())
+                     n_slabs=stream_w.shape[0], n_params=params.numel(), layout=CHAIN_LAYOUT_IDS[layout or _packing().CHAIN_LAYOUT])
     flops = 2.0 * M * Cc * Cc * (1 + 1 + 1 + 12 + 1) + 4.0 * M * 77 * Cc
     with _Prof("spatial_chain_fused[c320]", flops, M * Cc * (2 + 4 + 4 + out.element_size())):
         _check(lib().vv_spatial_chain_c320(C.byref(cp), dtype, _stream()), "vv_spatial_chain_c320")

@@ -293,6 +293,19 @@ class DiffuEraserHIP:
     def _compose(self, acc, fr, mk):
         return hip.blur_compose(acc, fr, mk, self.taps)
 
+    @staticmethod
+    def _finite_flag(dec):
+        """one-element device tensor: every sampled value of a decoded chunk [F,H,W,3] is finite (no host sync here)"""
+        return torch.isfinite(dec[:, ::16, ::16]).all()
+
+    def _raise_if_not_finite(self, flags):
+        bad = sorted(ci for ci, f in flags if not bool(f.item()))
+        if bad:
+            raise FloatingPointError(
+                f"non-finite pixels in decoded chunk(s) {bad}: an activation or weight left the {self.run.dtype} operand range "
+                + ("(|x| > 65504: fp16 operands do not saturate, they become inf) -- run with RunConfig(dtype='bf16'), whose range is fp32's" if self.run.dtype == "fp16"
+                   else "or the inputs / weights already held inf / NaN"))
+
     # -- one clip -------------------------------------------------------------------------------------------------
     def encode(self, img8, F, H, W):
         f = self.vae.factor
@@ -515,7 +528,9 @@ class DiffuEraserHIP:
         noise = noise_pre.repeat(reps, 1, 1, 1)[:T].contiguous()
         lat = hip.axpby(prior_lat.contiguous(), noise, a0 ** 0.5, (1 - a0) ** 0.5)
         lat = self._denoise_windows(lat, cond_lat.contiguous(), mk, ts, steps, H, W, nframes, overlap, progress=progress, scheduler=scheduler, tcd_noise=z_all)
-        pix = self._to_pix01(self.decode(lat, T, h, w))
+        dec = self.decode(lat, T, h, w)
+        self._raise_if_not_finite([(0, self._finite_flag(dec))])
+        pix = self._to_pix01(dec)
         if return_float:
             return pix.cpu().numpy()
         out = hip.blur_compose(pix, fr_orig, mk_orig, self.taps)
@@ -630,6 +645,20 @@ class DiffuEraserHIP:
             return self.denoise_chunk(fr[s - base:e - base], pr[s - base:e - base], mk[s - base:e - base], noise, steps=steps,
                                       scheduler=scheduler, tcd_noise=tcd_noise, progress=cb)
 
+        # A trained checkpoint's outliers can leave the fp16 range (65504) in an h16 operand: F16::from_f32 does not saturate (vv_common.h), the value becomes
+        # inf and every GroupNorm / softmax downstream turns the whole frame into NaN.  Nothing is clamped silently: each decoded chunk leaves a one-element
+        # device flag (a strided sample -- a non-finite latent poisons every pixel of its frame through the decoder's normalisations), read after the rank's
+        # last chunk, and the call FAILS by name instead of handing NaN pixels to the blend (VERDICT r5 hygiene 8).
+        finite_flags, flags_lock = [], __import__("threading").Lock()
+        inner_run_chunk = run_chunk
+
+        def run_chunk(k, ci, cb):
+            dec = inner_run_chunk(k, ci, cb)
+            flag = self._finite_flag(dec)
+            with flags_lock:
+                finite_flags.append((ci, flag))
+            return dec
+
         lanes = max(1, min(int(run.concurrent_chunks), n_my))
         if hip.PROFILE is not None or not self._lanes_ok:
             lanes = 1              # per-kernel HIP events only mean something on one stream
@@ -649,6 +678,7 @@ class DiffuEraserHIP:
         if timings is not None:
             self._sync()
             timings["exchange_blend_s"] = time.time() - t_x
+        self._raise_if_not_finite(finite_flags)
         if accT is None:
             return None, (0, 0)
         if return_float:

@@ -124,11 +124,17 @@ class _Backbone:
         rows = {id(r): r.temb_bias(st) for r in self.resblocks()}
         tables[key] = {t: {rid: b[i] for rid, b in rows.items()} for i, t in enumerate(ts)}      # another schedule on this stream: the old rows go
 
-    def run_down(self, x_in, F, h, w, st):
-        """x_in: h16 [F*h*w, in_pad].  Returns (x, skips=[(tensor,H,W)...], (H,W))."""
+    def run_down(self, x_in, F, h, w, st, into_hidden=None):
+        """x_in: h16 [F*h*w, in_pad].  Returns (x, skips=[(tensor,H,W)...], (H,W)).
+        into_hidden (UNetConfig.brushnet_add == "hidden"): one callable per skip position, x -> x + BrushNet residual of that position (the zero
+        convolution with the UNet state as its fused residual: BrushNet.hidden_adders) -- applied to the running hidden state after conv_in (whose
+        skip is taken BEFORE), after every layer and after every downsampler, so the skips taken there carry the residual."""
         x, _, _ = self.conv_in(x_in, F, h, w)
         H, W = h, w
         skips = [(x, H, W)]
+        hid = list(into_hidden) if into_hidden is not None else None
+        if hid is not None:
+            x = hid.pop(0)(x)
         L = len(self.cfg.block_out)
         for i, layers in enumerate(self.down):
             for (r, a, m) in layers:
@@ -137,9 +143,13 @@ class _Backbone:
                     x = a(x, F, H, W)
                 if m is not None:
                     x = m(x, F, H, W)
+                if hid is not None:
+                    x = hid.pop(0)(x)
                 skips.append((x, H, W))
             if i < L - 1:
                 x, H, W = self.downs[i](x, F, H, W, stride=2)
+                if hid is not None:
+                    x = hid.pop(0)(x)
                 skips.append((x, H, W))
         return x, skips, (H, W)
 
@@ -200,6 +210,19 @@ class BrushNet(_Backbone):
         _, ups, _ = self.run_up(mid, F, H, W, skips, st, collect=True)
         return down_raw, mid, ups, (H, W)
 
+    def hidden_adders(self, pre, F, scale=1.0):
+        """UNetConfig.brushnet_add == "hidden": the down residuals as callables x -> zero_conv(BrushNet skip) + x, one per skip position, for
+        _Backbone.run_down(into_hidden=...) -- the same fused kernel as the "skip" site (residual in the GEMM epilogue), launched inside the UNet's
+        down path instead of after it."""
+        down_raw = pre[0]
+        return [(lambda x, z=z, s=s, sh=sh, sw=sw: z(s, F, sh, sw, res0=x, scale=scale)[0]) for z, (s, sh, sw) in zip(self.zd, down_raw)]
+
+    def mid_up(self, pre, F, unet_mid, scale=1.0):
+        """mid + up residuals only (the down residuals already went in through hidden_adders)."""
+        _, mid, ups, (H, W) = pre
+        new_mid, _, _ = self.zm(mid, F, H, W, res0=unet_mid, scale=scale)
+        return new_mid, [z(s, F, sh, sw, scale=scale)[0] for z, (s, sh, sw) in zip(self.zu, ups)]
+
     def __call__(self, x16, t, F, h, w, unet_skips, unet_mid, scale=1.0, pre=None):
         """x16: h16 [F*h*w,16] BrushNet input.  unet_skips / unet_mid: the UNet's own down skips and mid output;
         the zero-conv GEMMs add them in their epilogue, so the returned tensors are already (skip + residual).
@@ -220,9 +243,9 @@ class UNetMotion(_Backbone):
         self.norm_out = GroupNorm(ctx, "unet.conv_norm_out", cfg.block_out[0], cfg.groups, 1e-5, precise=self.precise_io)      # emits the split operand itself
         self.conv_out = Conv(ctx, "unet.conv_out", cfg.block_out[0], cfg.out_ch, precise=self.precise_io)
 
-    def down_mid(self, lat8, t, F, h, w):
+    def down_mid(self, lat8, t, F, h, w, into_hidden=None):
         st = self.temb(t)
-        x, skips, (H, W) = self.run_down(lat8, F, h, w, st)
+        x, skips, (H, W) = self.run_down(lat8, F, h, w, st, into_hidden=into_hidden)
         mid = self.run_mid(x, F, H, W, st)
         return st, skips, mid, (H, W)
 
@@ -271,6 +294,12 @@ class Denoiser:
         # (precise_io: conv_in takes the fp32 latents and splits them itself -- no rounding of the network input to h16)
         lat8 = (hip.pad_channels_f32(lat, 8) if self.unet.precise_io else hip.pad_channels(ctx.dt, lat, 8)).view(F * h * w, 8)
         x16 = hip.brushnet_input(ctx.dt, lat, cond, mask2d, H, W).view(F * h * w, 16)
+        if self.cfg.brushnet_add == "hidden":      # the UNet's down path consumes a BrushNet residual after every layer: the branch runs first
+            pre = self.brush.backbone(x16, t, F, h, w)
+            st, skips, mid, (Hm, Wm) = self.unet.down_mid(lat8, t, F, h, w, into_hidden=self.brush.hidden_adders(pre, F))
+            new_mid, add_up = self.brush.mid_up(pre, F, mid)
+            return self.unet.up_out(st, skips, new_mid, F, Hm, Wm, add_up).view(F, h, w, 4)
+        assert self.cfg.brushnet_add == "skip", self.cfg.brushnet_add
         pre = None
         if Denoiser.OVERLAP and hip.PROFILE is None and not getattr(Denoiser.lane, "concurrent", False):
             main = torch.cuda.current_stream()
