@@ -210,34 +210,37 @@ def test_drop_in_with_the_full_propainter_prior(gpu):
     diffuerase.configure(None)
 
 
-def test_full_architecture_one_step(gpu):
+@pytest.fixture(scope="module")
+def full_width(gpu):
+    """The FULL-width models ONCE for every test of this module that needs them: the 2.3 B seeded UNet + BrushNet + motion weights take ~35 s to draw for
+    the oracle (fp32, ~9 GB of host memory) and ~45 s to draw, pack and upload for the HIP path -- per test, that was most of each test's time."""
+    from oracle import model_ref as M
+    from videovanish_amd.nn import Ctx
+    from videovanish_amd.unet import Denoiser
+    ucfg = UNetConfig()
+    P = M.Params(0)
+    ctx = Ctx("cuda:0", "fp16", 0)
+    den = Denoiser(ctx, ucfg, ctx.src.normal("text_states", (1, ucfg.text_len, ucfg.cross_dim)))
+    yield P, ctx, den
+    P.cache.clear()
+    del den
+    torch.cuda.empty_cache()
+
+
+def test_full_architecture_one_step(gpu, full_width):
     """The FULL SD-1.5 UNet + BrushNet + motion modules (320/640/1280/1280, 8 heads, d = 40/80/160) and the full SD-VAE
     (128/256/512/512, mid attention d = 512) at a small spatial size, fp16 operands, against the fp32 oracle with the same
     2.4 B seeded weights: this is the architecture bench.py times, only the image is smaller."""
     from oracle import model_ref as M
     from videovanish_amd import hip
-    from videovanish_amd.nn import Ctx
-    from videovanish_amd.unet import Denoiser
     from videovanish_amd.vae import VAE
     ucfg, vcfg = UNetConfig(), VAEConfig()
-    P = M.Params(0)
-    g = torch.Generator().manual_seed(13)
-    Fr, h, w = 3, 8, 10
-    lat = torch.randn(Fr, 4, h, w, generator=g)
-    cond = torch.randn(Fr, 4, h, w, generator=g)
-    mask = (torch.rand(Fr, h * 8, w * 8, generator=g) > 0.6).to(torch.uint8) * 255
-    m_lat = torch.nn.functional.interpolate((mask > 0).float()[:, None], size=(h, w), mode="nearest")
-    text = M.text_states(P, ucfg)
-    with torch.no_grad():
-        ref = M.unet_forward(P, lat, 441, text, ucfg, M.brushnet_forward(P, torch.cat([lat, cond, m_lat], 1), 441, text, ucfg))
-    ctx = Ctx("cuda:0", "fp16", 0)
-    den = Denoiser(ctx, ucfg, ctx.src.normal("text_states", (1, ucfg.text_len, ucfg.cross_dim)))
-    eps = den(_nhwc(lat).to(gpu), _nhwc(cond).to(gpu), mask.to(gpu), 441, Fr, h, w, h * 8, w * 8)
-    emax, erms = _rel(eps.cpu().permute(0, 3, 1, 2), ref)
+    emax, erms, _, _ = _one_step_vs_oracle(gpu, ucfg, 3, 8, 10, t=441, seed=13, shared=full_width)
     _log("denoiser[FULL,fp16]", rel_max=emax, rel_rms=erms)
     assert emax <= 4e-3 and erms <= 3e-3
-    del den
-    P.cache.clear()
+    ctx = full_width[1]
+    P = M.Params(0)                                   # (the VAE's 84 M weights; the shared cache keeps the UNet's)
+    g = torch.Generator().manual_seed(13)
     fr = torch.randint(0, 256, (1, 64, 64, 3), generator=g, dtype=torch.uint8)
     img = fr.float().permute(0, 3, 1, 2) / 127.5 - 1.0
     with torch.no_grad():
@@ -253,12 +256,13 @@ def test_full_architecture_one_step(gpu):
     assert zmax <= 4e-3 and dmax <= 4e-3
 
 
-def _one_step_vs_oracle(gpu, ucfg, Fr, h, w, t=441, seed=13, dname="fp16"):
-    """one denoiser evaluation eps = UNet(lat | BrushNet(lat, cond, mask)) on seeded inputs: HIP path vs oracle/model_ref.py -> (rel max, rel rms, got, ref)"""
+def _one_step_vs_oracle(gpu, ucfg, Fr, h, w, t=441, seed=13, dname="fp16", shared=None):
+    """one denoiser evaluation eps = UNet(lat | BrushNet(lat, cond, mask)) on seeded inputs: HIP path vs oracle/model_ref.py -> (rel max, rel rms, got, ref)
+    shared: (oracle Params, Ctx, Denoiser) built once by the `full_width` fixture (same config, fp16)."""
     from oracle import model_ref as M
     from videovanish_amd.nn import Ctx
     from videovanish_amd.unet import Denoiser
-    P = M.Params(0)
+    P = shared[0] if shared is not None else M.Params(0)
     g = torch.Generator().manual_seed(seed)
     lat = torch.randn(Fr, 4, h, w, generator=g)
     cond = torch.randn(Fr, 4, h, w, generator=g)
@@ -267,9 +271,12 @@ def _one_step_vs_oracle(gpu, ucfg, Fr, h, w, t=441, seed=13, dname="fp16"):
     text = M.text_states(P, ucfg)
     with torch.no_grad():
         ref = M.unet_forward(P, lat, t, text, ucfg, M.brushnet_forward(P, torch.cat([lat, cond, m_lat], 1), t, text, ucfg))
-    P.cache.clear()
-    ctx = Ctx("cuda:0", dname, 0)
-    den = Denoiser(ctx, ucfg, ctx.src.normal("text_states", (1, ucfg.text_len, ucfg.cross_dim)))
+    if shared is None:
+        P.cache.clear()
+        ctx = Ctx("cuda:0", dname, 0)
+        den = Denoiser(ctx, ucfg, ctx.src.normal("text_states", (1, ucfg.text_len, ucfg.cross_dim)))
+    else:
+        den = shared[2]
     eps = den(_nhwc(lat).to(gpu), _nhwc(cond).to(gpu), mask.to(gpu), t, Fr, h, w, h * 8, w * 8)
     got = eps.cpu().permute(0, 3, 1, 2)
     del den, eps
@@ -300,7 +307,7 @@ def test_brushnet_residual_site_modes(gpu, cname, ucfg, Fr, h, w):
 # 90 -> 45 -> 23 -> 12 / 60 -> 30 -> 15 -> 8 / 135 -> 68 -> 34 -> 17 pyramids with their odd sizes (UpConv2x edge launches, "resize to the skip"),
 # N = 14400 / 3600 / 920 / 240 attention lengths and the 720p / 1080p tile heuristics (vv_gemm256_try) -- none of which the 8 x 10 case reaches
 @pytest.mark.parametrize("cname,Fr,h,w", [("c2", 2, 60, 106), ("c3", 2, 90, 160), ("c4", 1, 135, 240)])
-def test_full_architecture_one_step_at_benchmarked_geometry(gpu, cname, Fr, h, w):
+def test_full_architecture_one_step_at_benchmarked_geometry(gpu, full_width, cname, Fr, h, w):
     """one evaluation of the FULL-width UNet + BrushNet + motion modules, fp16 operands (the bench line's arithmetic), at the
     latent grid of BASELINE configs 2 / 3 / 4 against the fp32 oracle (oracle/model_ref.py::unet_forward, brushnet_forward) with the same seeded
     weights: F = 2 frames (1 at 1080p) keep the CPU side to ~3 / 9 / 29 TFLOP per frame.  Same bound as the 8 x 10 case: rel max <= 4e-3."""
@@ -309,7 +316,7 @@ def test_full_architecture_one_step_at_benchmarked_geometry(gpu, cname, Fr, h, w
     try:
         import time
         t0 = time.time()
-        emax, erms, got, ref = _one_step_vs_oracle(gpu, UNetConfig(), Fr, h, w, t=441, seed=17)
+        emax, erms, got, ref = _one_step_vs_oracle(gpu, UNetConfig(), Fr, h, w, t=441, seed=17, shared=full_width)
         _log(f"denoiser[FULL,fp16,{cname} latent {h}x{w},F={Fr}]", rel_max=emax, rel_rms=erms, seconds=time.time() - t0)
     finally:
         torch.set_num_threads(nthreads)

@@ -279,12 +279,12 @@ def test_cv2_restatements_against_independent_implementations():
 
 
 def test_blocked_attention_equals_the_direct_form(monkeypatch):
-    """oracle/model_ref.py::attention switches to blocks of query rows above 2^28 score elements (the benchmarked 720p / 1080p grids): same arithmetic,
-    softmax rows complete inside a block.  Pinned here against the direct form on a size just above the switch."""
+    """oracle/model_ref.py::attention switches to torch's fused fp32 CPU kernel above 2^28 score elements (the benchmarked 720p / 1080p grids, where the
+    score matrix would take 13 - 34 GB): same expression.  Pinned here against the direct form on a size just above the switch."""
     import torch
     from oracle import model_ref as M
     g = torch.Generator().manual_seed(3)
-    B, N, C, heads = 1, 5800, 64, 8                      # 8 * 5800^2 = 2.69e8 > 2^28: the blocked branch (4 blocks of 5785 + 15 rows)
+    B, N, C, heads = 1, 5800, 64, 8                      # 8 * 5800^2 = 2.69e8 > 2^28: the fused branch
     q, k, v = (torch.randn(B, N, C, generator=g) for _ in range(3))
     got = M.attention(q, k, v, heads)
     d = C // heads
