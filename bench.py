@@ -485,7 +485,9 @@ def main():
         if args.dry_run:
             td.init_process_group("gloo")
         else:
-            td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            import datetime
+            # (the default collective watchdog is 10 minutes; a rank's block of 50-step chunks between two collectives can be longer at 1080p: one hour)
+            td.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=60))
         dist = (rank, world)
         if args.dry_run and os.environ.get("VV_DRYRUN_FAIL_RANK") == str(rank):      # tests/test_dist_cpu.py: one rank dies after the rendezvous
             raise RuntimeError(f"dry run: rank {rank} told to fail (VV_DRYRUN_FAIL_RANK)")

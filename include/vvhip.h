@@ -184,6 +184,8 @@ typedef struct {
     int32_t C, heads, text_len;
     int32_t n_slabs, n_params;
     int32_t layout;                   /* VV_CHAIN_LAYOUT_* of `stream` (ABI 10) */
+    int32_t o_hw;                     /* ABI 10: 0 = o is row-major [M][320]; > 0 = o is HEAD-MAJOR [M / o_hw][8][o_hw][40] (tokens per frame = o_hw;
+                                         what vv_attention writes with o_hs = o_hw * 40) */
 } vv_chain_params;
 int vv_spatial_chain_c320(const vv_chain_params* host_p, int dtype, void* stream);
 
@@ -235,6 +237,11 @@ typedef struct {
                                          long key sequence is split over the batch index (q_bs = 0, k_bs = v_bs = chunk * row stride) and the
                                          partial outputs are merged by vv_attention_merge: more blocks for one long head (SAM 2 memory attention:
                                          4096 queries x 28736 keys, one head of 256).  Generic kernel only (not the d = 40 spatial form). */
+    int64_t o_hs;                     /* ABI 10: head stride (elements) of o; 0 = D (heads side by side inside a row of o_rs elements: o[b*o_bs + i*o_rs + h*D + c]).
+                                         HEAD-MAJOR output o[b][head][token][D] (o_hs = Nq*D, o_rs = D, o_bs = heads*Nq*D): every wave stores whole
+                                         contiguous 2*D-byte records, 64 tokens = 64 * 2*D contiguous bytes -- in the row layout a head's 80-byte (D = 40)
+                                         slice of a 640-byte row is a partial 64-byte HBM burst on both sides (measured 1.6x write traffic).  The
+                                         level-0 spatial blocks use it: vv_spatial_chain_c320 reads that layout with vv_chain_params.o_hw > 0. */
 } vv_attn_params;
 int vv_attention(const vv_attn_params* host_p, int dtype, void* stream);
 /* out[q][h*D + c] = sum_s w_s o_parts[s][q][h*D + c] / sum_s w_s, w_s = 2^(lse[s][h][q] - max_s lse): merges S partial attention results

@@ -191,7 +191,7 @@ def _denoise_windows(P, lat, cond, m_lat, steps, ucfg, nframes, overlap, schedul
 
 
 def diffueraser_forward_reference_windows(frames, masks2d, priori, max_img_size=960, steps=50, seed=42, weight_seed=0, ucfg=None, vcfg=None,
-                                          nframes=22, overlap=4, P=None, return_float=False, scheduler="ddim"):
+                                          nframes=22, overlap=4, P=None, return_float=False, scheduler="ddim", trace=None):
     """DiffuEraser.forward with the third-party pipeline's own temporal scheme: windows of `nframes` shifted by half a window on
     odd steps, noise prediction averaged over the covering windows, key-frame pre-inference when T > 2 * nframes."""
     from videovanish_amd.config import UNetConfig, VAEConfig
@@ -226,11 +226,15 @@ def diffueraser_forward_reference_windows(frames, masks2d, priori, max_img_size=
             lat_pre = M.add_noise(prior_lat[idx], noise_pre, t0, ac)
             out_pre = _denoise_windows(P, lat_pre, cond_lat[idx], m_lat, steps, ucfg, nframes, overlap, scheduler, z_pre)
             pix = (M.vae_decode(P, out_pre, vcfg) / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
+            keys = []
             for j, i in enumerate(idx):
                 key = I.blur_compose(pix[j], fr[i], np.full((H, W), 255, np.uint8))
+                keys.append(key)
                 fr[i], mk[i] = key, np.zeros((H, W), np.uint8)
                 prior_lat[i] = out_pre[j]
                 cond_lat[i] = M.vae_encode(P, to_model_tensor([key]), vcfg)[0]
+            if trace is not None:      # the quantised key frames (the path's one discontinuity): tests hand them to the HIP path to separate float error from flips
+                trace.update(key_u8=np.stack(keys), key_idx=list(idx))
         noise = noise_pre.repeat(reps, 1, 1, 1)[:T]
         m_lat = torch.nn.functional.interpolate(mt(mk), size=(h, w), mode="nearest")
         lat = _denoise_windows(P, M.add_noise(prior_lat, noise, t0, ac), cond_lat, m_lat, steps, ucfg, nframes, overlap, scheduler, z_all)

@@ -71,3 +71,38 @@ def test_fused_chain_kernels_are_run_to_run_deterministic(gpu):
             out1 = hip.spatial_chain_c320(ctx.dt, o, t0, x, mod.fused[0], mod.fused[1])
             assert torch.equal(t1, t0) and torch.equal(qkv1, qkv0) and torch.equal(out1, out0)
         assert torch.isfinite(out0).all()
+
+
+def test_head_major_attention_output_is_bit_identical(gpu):
+    """Round 6: between the self-attention core and the fused tail the O tensor is head-major [frame][head][token][40]
+    (vv_attn_params.o_hs / vv_chain_params.o_hw): the attention kernels store whole contiguous 80-byte records instead of an 80-byte slice of a 640-byte
+    row.  Same values at other addresses: the attention output permuted back equals the row-major output bit for bit (d = 40 spatial kernels incl. a ragged
+    token count, and the generic kernel at d = 64), and the block's result is bit-identical with either layout -- also when a 128-token block of the tail
+    straddles two frames (HW = 1000) and at the bench geometry's frame size."""
+    from videovanish_amd import hip, nn as vnn
+    cfg = UNetConfig()
+    g = torch.Generator().manual_seed(9)
+    ctx = vnn.Ctx("cuda:0", "fp16", 0)
+    for (B, heads, N, D) in ((2, 8, 1000, 40), (1, 8, 4096, 40), (3, 4, 200, 64), (2, 8, 900, 80)):
+        C = heads * D
+        qkv = (torch.randn(B, 3, heads, N, D, generator=g) * 0.5).to(gpu).to(ctx.h16)
+        outs = []
+        for hm in (False, True):
+            o = torch.zeros((B, heads, N, D) if hm else (B * N, C), dtype=ctx.h16, device=gpu)
+            hip.attention(ctx.dt, qkv, qkv, qkv, o, B=B, heads=heads, Nq=N, Nkv=N, D=D, q_bs=N * 3 * C, k_bs=N * 3 * C, v_bs=N * 3 * C, o_bs=N * C,
+                          q_rs=D, k_rs=D, v_rs=D, o_rs=D if hm else C, k_off=N * C, v_off=2 * N * C, q_hs=N * D, k_hs=N * D, v_hs=N * D,
+                          o_hs=N * D if hm else 0)
+            outs.append(o.permute(0, 2, 1, 3).reshape(B * N, C) if hm else o)
+        assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1]), (B, heads, N, D)
+    text = ctx.dev(torch.randn(77, 768, generator=g), ctx.h16)
+    mod = vnn.SpatialTransformer(ctx, "unet.down_blocks.0.attentions.0", 320, cfg, text)
+    for (Fr, H, W) in ((3, 25, 40), (2, 90, 160)):
+        x = torch.randn(Fr * H * W, 320, generator=g).to(gpu)
+        res = []
+        try:
+            for hm in (True, False):
+                vnn.SpatialTransformer.HEAD_MAJOR_O = hm
+                res.append(mod(x, Fr, H, W))
+        finally:
+            vnn.SpatialTransformer.HEAD_MAJOR_O = True
+        assert torch.isfinite(res[0]).all() and torch.equal(res[0], res[1]), (Fr, H, W)

@@ -275,8 +275,17 @@ def test_reference_windowing_vs_oracle(gpu):
     du = np.abs(np.stack(out).astype(int) - np.stack(refu).astype(int))
     assert len(out) == T and du.max() <= 2
     # the reference's own regime (round 5): the same windows under the 2-step TCD schedule of its "2-Step" checkpoint
-    ref2 = R.diffueraser_forward_reference_windows(frames, m2d, prior, steps=2, seed=7, ucfg=TINY_UNET, vcfg=TINY_VAE, return_float=True, scheduler="tcd")
-    got2, _ = model.forward(frames, m2d, prior, steps=2, return_float=True, scheduler="tcd")
+    tr_ref, tr_got = {}, {}
+    ref2 = R.diffueraser_forward_reference_windows(frames, m2d, prior, steps=2, seed=7, ucfg=TINY_UNET, vcfg=TINY_VAE, return_float=True, scheduler="tcd", trace=tr_ref)
+    got2 = model.forward_reference_windows(frames, m2d, prior, steps=2, return_float=True, scheduler="tcd", trace=tr_got)
     e2 = np.abs(got2 - ref2)
-    _log(f"reference_windowing[tiny,fp16,precise,T=46,2-step TCD] pixel max_abs={e2.max():.3e} mean_abs={e2.mean():.3e}")
-    assert e2.max() <= 6e-3
+    # the ONE discontinuity of this regime is the uint8 hand-off of the 22 key frames: count the levels that flipped, then repeat the run with
+    # the oracle's key frames handed in -- what remains is the float error of the path itself, and THAT is held to the north-star bound
+    kd = np.abs(tr_got["key_u8"].astype(int) - tr_ref["key_u8"].astype(int))
+    assert tr_got["key_idx"] == list(tr_ref["key_idx"]) and kd.max() <= 1
+    got3 = model.forward_reference_windows(frames, m2d, prior, steps=2, return_float=True, scheduler="tcd", key_override=tr_ref["key_u8"])
+    e3 = np.abs(got3 - ref2)
+    _log(f"reference_windowing[tiny,fp16,precise,T=46,2-step TCD] pixel max_abs={e2.max():.3e} mean_abs={e2.mean():.3e} | key-frame uint8 levels flipped: "
+         f"{int(kd.sum())} of {kd.size} | with the oracle's key frames handed in (float error only): max_abs={e3.max():.3e} mean_abs={e3.mean():.3e}")
+    assert e3.max() <= 1.0e-3                                   # float error of the reference-default regime: the north-star bound
+    assert e2.max() <= (1.0e-3 if kd.sum() == 0 else 6e-3)      # a flipped key level is 3.9e-3 on its own pixel (and is what the GUI user's path contains)

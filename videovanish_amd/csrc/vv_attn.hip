@@ -60,7 +60,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const vv_attn_params
     const unsigned short* Q = (const unsigned short*)p.q + (int64_t)b * p.q_bs + (int64_t)h * (p.q_hs ? p.q_hs : D);
     const unsigned short* Kp = (const unsigned short*)p.k + (int64_t)b * p.k_bs + (int64_t)h * (p.k_hs ? p.k_hs : D);
     const unsigned short* Vp = (const unsigned short*)p.v + (int64_t)b * p.v_bs + (int64_t)h * (p.v_hs ? p.v_hs : D);
-    unsigned short* O = (unsigned short*)p.o + (int64_t)b * p.o_bs + (int64_t)h * D;
+    unsigned short* O = (unsigned short*)p.o + (int64_t)b * p.o_bs + (int64_t)h * (p.o_hs ? p.o_hs : D);
 
     const int q0 = qt * BQ + wave * QT * 16;
     // ---- Q fragments (B operand of S^T): lane holds Q[q0 + j*16 + li][s*32 + lg*8 .. +7]
@@ -436,6 +436,7 @@ extern "C" int vv_attention(const vv_attn_params* pp, int dtype, void* stream) {
     if (p.B <= 0 || p.heads <= 0 || p.Nq <= 0 || p.Nkv <= 0) VV_FAIL(VV_E_ARG, "vv_attention: empty problem");
     if ((p.q_rs | p.k_rs | p.v_rs | p.o_rs | p.q_bs | p.k_bs | p.v_bs | p.o_bs) & 3) VV_FAIL(VV_E_ARG, "vv_attention: strides must be multiples of 4 elements (q/k/v: 8)");
     if ((p.q_rs | p.k_rs | p.v_rs | p.q_bs | p.k_bs | p.v_bs | p.q_hs | p.k_hs | p.v_hs) & 7) VV_FAIL(VV_E_ARG, "vv_attention: q/k/v strides must be multiples of 8 elements");
+    if (p.o_hs & 3) VV_FAIL(VV_E_ARG, "vv_attention: o_hs must be a multiple of 4 elements");
     if (dtype != VV_BF16 && dtype != VV_F16) VV_FAIL(VV_E_ARG, "vv_attention: bad dtype");
     if (p.lse && p.D == 40) VV_FAIL(VV_E_UNSUPPORTED, "vv_attention: lse output is not available at D = 40");
 #ifdef VV_AB

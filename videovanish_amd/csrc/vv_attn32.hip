@@ -106,7 +106,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
     const unsigned short* Q = (const unsigned short*)p.q + (int64_t)b * p.q_bs + (int64_t)hd * (p.q_hs ? p.q_hs : D);
     const unsigned char* Kp = (const unsigned char*)((const unsigned short*)p.k + (int64_t)b * p.k_bs + (int64_t)hd * (p.k_hs ? p.k_hs : D));
     const unsigned char* Vp = (const unsigned char*)((const unsigned short*)p.v + (int64_t)b * p.v_bs + (int64_t)hd * (p.v_hs ? p.v_hs : D));
-    unsigned short* O = (unsigned short*)p.o + (int64_t)b * p.o_bs + (int64_t)hd * D;
+    unsigned short* O = (unsigned short*)p.o + (int64_t)b * p.o_bs + (int64_t)hd * (p.o_hs ? p.o_hs : D);
 
     // ---- Q fragments: lane (r, h) holds Q[q0 + r][16 s + 8 h .. +7]; chunk 5 (s = 2, h = 1) is the pad chunk: slots 40, 41 = -m (hi, lo)
     const int q0 = qt * BQ + wave * 32;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
     const unsigned short* Q = (const unsigned short*)p.q + (int64_t)b * p.q_bs + (int64_t)hd * (p.q_hs ? p.q_hs : D);
     const unsigned char* Kp = (const unsigned char*)((const unsigned short*)p.k + (int64_t)b * p.k_bs + (int64_t)hd * (p.k_hs ? p.k_hs : D));
     const unsigned char* Vp = (const unsigned char*)((const unsigned short*)p.v + (int64_t)b * p.v_bs + (int64_t)hd * (p.v_hs ? p.v_hs : D));
-    unsigned short* O = (unsigned short*)p.o + (int64_t)b * p.o_bs + (int64_t)hd * D;
+    unsigned short* O = (unsigned short*)p.o + (int64_t)b * p.o_bs + (int64_t)hd * (p.o_hs ? p.o_hs : D);
 
     // ---- Q fragments: lane (r, h) holds Q[q0 + r][16 s + 8 h .. +7]; chunk 5 (s = 2, h = 1) is the pad chunk: slots 40, 41 = -m (hi, lo)
     const int q0 = qt * BQ + wave * 32 * QB;
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn80_kernel(const vv_attn_para
     const unsigned short* Q = (const unsigned short*)p.q + (int64_t)b * p.q_bs + (int64_t)hd * (p.q_hs ? p.q_hs : D);
     const unsigned char* Kp = (const unsigned char*)((const unsigned short*)p.k + (int64_t)b * p.k_bs + (int64_t)hd * (p.k_hs ? p.k_hs : D));
     const unsigned char* Vp = (const unsigned char*)((const unsigned short*)p.v + (int64_t)b * p.v_bs + (int64_t)hd * (p.v_hs ? p.v_hs : D));
-    unsigned short* O = (unsigned short*)p.o + (int64_t)b * p.o_bs + (int64_t)hd * D;
+    unsigned short* O = (unsigned short*)p.o + (int64_t)b * p.o_bs + (int64_t)hd * (p.o_hs ? p.o_hs : D);
 
     // ---- Q fragments: lane (r, h) holds Q[q0 + 32 x + r][16 s + 8 h .. +7], s = 0..4
     const int q0 = qt * BQ + wave * 32 * QB;

@@ -181,12 +181,21 @@ __global__ __launch_bounds__(512, 2) void chain_rs_c320_kernel(const vv_chain_pa
         for (int tt = 0; tt < 2; ++tt) {
             int64_t row = row0 + tt * 16 + li;
             if (row >= p.M) row = p.M - 1;
-            const unsigned short* orow = (const unsigned short*)p.o + row * CC;
             const float* trow = p.t_in + row * CC;
+            // o: row-major [M][320], or head-major [frame][head][token][40] (o_hw tokens per frame; what vv_attention stores as whole contiguous
+            // 80-byte records): channel c of the row = head c / 40, d = c % 40 -- every 4-channel piece lies inside one head
+            const unsigned short* obase = (const unsigned short*)p.o;
+            int64_t ofr = row * CC, otk = 0;
+            if (p.o_hw > 0) { const int64_t fr = row / p.o_hw; ofr = fr * p.o_hw * CC; otk = (row - fr * p.o_hw) * CD; }
+            auto opiece = [&](const int c0) -> uint2 {      // channels c0 + 4 lg .. + 3
+                const int c = c0 + 4 * lg;
+                if (p.o_hw > 0) { const int hd = c / CD; return *(const uint2*)(obase + ofr + (int64_t)hd * p.o_hw * CD + otk + (c - hd * CD)); }
+                return *(const uint2*)(obase + ofr + c);
+            };
 #pragma unroll
             for (int kt = 0; kt < 5; ++kt) {
-                const uint2 l0 = *(const uint2*)(orow + 64 * kt + 4 * lg), h0 = *(const uint2*)(orow + 64 * kt + 16 + 4 * lg);
-                const uint2 l1 = *(const uint2*)(orow + 64 * kt + 32 + 4 * lg), h1 = *(const uint2*)(orow + 64 * kt + 48 + 4 * lg);
+                const uint2 l0 = opiece(64 * kt), h0 = opiece(64 * kt + 16);
+                const uint2 l1 = opiece(64 * kt + 32), h1 = opiece(64 * kt + 48);
                 a0[kt][tt] = make_uint4(l0.x, l0.y, h0.x, h0.y);
                 a1[kt][tt] = make_uint4(l1.x, l1.y, h1.x, h1.y);
             }
@@ -891,6 +900,41 @@ __global__ __launch_bounds__(512, 2) void chain_front_rs_c320_kernel(const vv_ch
         const int64_t fr = rows[tt] / p.HW, tk = rows[tt] - fr * p.HW;
         tokbase[tt] = fr * (3 * (int64_t)p.HW * CC) + tk * CD;
     }
+    // Stores of the QKV phase: block by block (4 stores per wave and 64-channel block).  The 80-byte record of a (token, head) -- 40 channels that straddle row
+    // blocks and the two waves of a pair -- therefore reaches L2 in 32-byte pieces microseconds apart and leaves as partial 64-byte bursts: 1.574 GB written for
+    // 0.885 GB of QKV (profiles/r5_final_pmc_traffic.json).  Round 6 built the remedy -- one `which` (q, k or v = 320 channels = 5 blocks) held packed in 40
+    // registers and stored in ONE burst (lab form, -DVV_FRONT_BURST) -- and measured it SLOWER (0.767 against 0.747 ms, three interleaved rounds, with plain
+    // vmcnt(6) waits and with waits that leave the stores in flight alike: profiles/r6_front_store_ab.txt): the kernel is not waiting for its stores, and the
+    // burst costs more issue slots than the wasted bytes cost time.  The product keeps the block-by-block form.
+#ifdef VV_FRONT_BURST
+    auto qkv_which = [&](const int which, auto tail) {
+        uint2 hold[5][2][2];
+#pragma unroll
+        for (int b5 = 0; b5 < 5; ++b5) {
+            f32x4 acc[2][2] = {{z4, z4}, {z4, z4}};
+            if (b5 < 2) group_rs(N5{}, [&](int) { return &acc[0][0]; }, BODY{});      // (the stream's last 3 blocks are the only ones that can run out of slabs)
+            else group_rs(N5{}, [&](int) { return &acc[0][0]; }, tail);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) hold[b5][rt][tt] = make_uint2(pack2<T>(acc[rt][tt][0], acc[rt][tt][1]), pack2<T>(acc[rt][tt][2], acc[rt][tt][3]));
+        }
+        const int64_t wbase = (int64_t)which * CC * p.HW;
+#pragma unroll
+        for (int b5 = 0; b5 < 5; ++b5)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int cc = 64 * b5 + 32 * hf + 16 * rt + 4 * lg, head = cc / CD, d = cc - head * CD;
+                const int64_t off = wbase + (int64_t)head * CD * p.HW + d;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    if (row0 + tt * 16 + li < p.M) *(uint2*)(qkv + tokbase[tt] + off) = hold[b5][rt][tt];
+            }
+    };
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) qkv_which(which, BODY{});
+    qkv_which(2, TAIL{});
+#else
     auto qkv_block = [&](const int rb, auto tail) {
         f32x4 acc[2][2] = {{z4, z4}, {z4, z4}};
         group_rs(N5{}, [&](int) { return &acc[0][0]; }, tail);
@@ -908,6 +952,7 @@ __global__ __launch_bounds__(512, 2) void chain_front_rs_c320_kernel(const vv_ch
 #pragma unroll 1
     for (int rb = 0; rb < 12; ++rb) qkv_block(rb, BODY{});
     qkv_block(12, TAIL{}); qkv_block(13, TAIL{}); qkv_block(14, TAIL{});
+#endif
 }
 
 // per-frame GroupNorm affine: out[f][0][c] = rstd * gamma[c], out[f][1][c] = beta[c] - mean * rstd * gamma[c]
@@ -930,6 +975,8 @@ extern "C" int vv_spatial_chain_c320(const vv_chain_params* pp, int dtype, void*
     if (p.M <= 0) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: empty input");
     if (p.out_dtype != VV_F32 && p.out_dtype != dtype) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: out_dtype mismatch");
     const int want_slabs = VV_CHAIN_FORM == 2 ? 4 * 870 : N_SLABS;
+    if (VV_CHAIN_FORM != 1 && p.o_hw) VV_FAIL(VV_E_UNSUPPORTED, "vv_spatial_chain_c320: the lab forms read o row-major only");
+    if (p.o_hw < 0 || (p.o_hw > 0 && p.M % p.o_hw)) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: o_hw must be 0 (row-major o) or divide M (head-major o)");
     if (p.layout != VV_CHAIN_FORM) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: weight stream packed in layout %d, this library's kernel consumes layout %d (VV_CHAIN_LAYOUT_*)", p.layout, (int)VV_CHAIN_FORM);
     if (p.n_slabs != want_slabs || p.n_params != Q_TOTAL) VV_FAIL(VV_E_ARG, "vv_spatial_chain_c320: stream / parameter block size mismatch (%d slabs, %d floats)", p.n_slabs, p.n_params);
     const int64_t nblk = (p.M + 127) / 128;

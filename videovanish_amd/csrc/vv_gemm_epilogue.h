@@ -16,7 +16,7 @@
 //   * STAGED (with LEAN; the 2-phase 256-row kernel, the 128 x 160 halo-tile kernel and the fp32-operand loader; fp32 output with at most the fp32 residual): in the accumulator layout a wave
 //     instruction touches 16 rows x 64 bytes -- half a cache line per row and request.  A strip goes through a wave-private LDS tile (the operand stages are dead) and
 //     comes back row-major: 256 / W rows x W * 4 contiguous bytes per instruction.  out-proj L1 0.210 -> 0.189 ms, L2 0.146 -> 0.134; zero convolutions (fp32 operand) +9..15 %;
-//     3x3 + residual +1.1 %.
+//     3x3 + residual +1.1 %.  Since round 6 also for h16 outputs (second branch below).
 #pragma once
 #include "vv_common.h"
 
@@ -110,11 +110,10 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
         }
         return;
     }
-#ifdef VV_STAGE_H16
-    // LAB, opt-in (-DVV_STAGE_H16; written at the end of round 5: bit-equal to the other forms -- tools/pytest_with_lib.py on a lab build, tests/test_kernels_gpu.py::
-    // test_gemm_tile_forms_agree_on_every_epilogue + split-heads + UpConv2x cases: 48 passed -- but NOT TIMED yet, tools/jobs/r5_epilogue_ab.sh is the A/B): the STAGED form for h16 outputs (QKV with the head-major store when a
-    // wave tile is exactly one head, proj_in, FF outputs stored h16).  In the accumulator layout a wave instruction writes 16 rows x 32 bytes; through the same fp32 LDS tile a
-    // lane takes 8 consecutive columns of a row instead (two ds_read_b128, at most two residual float4, one 16-byte store): W * 2 contiguous bytes per row.
+    // STAGED form for h16 outputs (written at the end of round 5, timed and adopted in round 6: +0.13 % on the bench line in an interleaved in-pipeline A/B, bit-equal
+    // outputs -- profiles/r6_stage_h16_pipeline_ab.txt): QKV with the head-major store when a wave tile is exactly one head, proj_in, FF outputs stored h16.  In the
+    // accumulator layout a wave instruction writes 16 rows x 32 bytes; through the same fp32 LDS tile a lane takes 8 consecutive columns of a row instead (two
+    // ds_read_b128, at most two residual float4, one 16-byte store): W * 2 contiguous bytes per row.
     if (LEAN && STAGED && vec && stage && p.out_dtype != VV_F32 && !p.rowvec && !p.res1 && p.act == VV_ACT_NONE && (!p.res0 || r0f32) && (N & 7) == 0 && (p.ldo & 7) == 0 &&
         (p.split_heads <= 0 || p.split_dim == NT * 16)) {
         constexpr int W = NT * 16, PITCH = W + 4, NQ = (16 * W + 511) / 512;
@@ -168,7 +167,6 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
         }
         return;
     }
-#endif
     if (LEAN && vec) {
         int colpart[NT];          // split_heads store: the column's (which, head, d) part of the output index (< 3*C*tokens)
         const bool split = p.split_heads > 0;

@@ -25,21 +25,6 @@ __host__ __device__ inline GNGeom gn_geom(int HW, int C) {
     return g;
 }
 
-template <typename T>
-__device__ __forceinline__ void gn_load8(const vv_groupnorm_params& p, int64_t pix, int chunk, float* v) {
-    int c = chunk * 8;
-    const unsigned char* src = (const unsigned char*)p.in0;
-    int Cs = p.C0;
-    if (c >= p.C0) { src = (const unsigned char*)p.in1; c -= p.C0; Cs = p.C1; }
-    const int64_t off = pix * Cs + c;
-    if (p.in_dtype == VV_F32) {
-        const float4* g = (const float4*)(src + off * 4);
-        *(float4*)&v[0] = g[0]; *(float4*)&v[4] = g[1];
-    } else {
-        unpack8<T>(*(const uint4*)(src + off * 2), v);
-    }
-}
-
 // Partial statistics of one (frame, row-split): DETERMINISTIC reduction (no float atomics): every thread parks its 8
 // per-channel sums in LDS, then one thread per group adds the group's channels over the block's row lanes in a fixed
 // order.  (The multi-GPU path promises bit-identical output for every world size: nothing may depend on arrival order.)
@@ -58,11 +43,46 @@ __global__ void gn_stats_kernel(const vv_groupnorm_params p, const GNGeom g) {
         const int rbeg = split * g.rows_per_split;
         const int rend = min(rbeg + g.rows_per_split, p.HW);
         int r = rbeg + r0;
-        for (; r < rend; r += g.krows) {
-            float v[8];
-            gn_load8<T>(p, (int64_t)f * p.HW + r, chunk, v);
+        // Four rows per pass, all loads first (round 6).  The one-row loop kept ONE 32-byte load per thread in flight (load, s_waitcnt vmcnt(0), accumulate: ~64 KB
+        // per CU, what Little's law asks for at HBM latency with nothing to spare), and gn_load8's source / type branches sit between the loads of an unrolled
+        // loop -- so the thread's source, row stride and element type are resolved ONCE, outside the loop.  The order of the additions per thread is unchanged
+        // (row r, r + krows, ...): bit-identical statistics.
+        const unsigned char* src = (const unsigned char*)p.in0;
+        int Cs = p.C0, c = chunk * 8;
+        if (c >= p.C0) { src = (const unsigned char*)p.in1; c -= p.C0; Cs = p.C1; }
+        const int64_t pix0 = (int64_t)f * p.HW;
+        auto acc8 = [&](const float* v) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+        };
+        if (p.in_dtype == VV_F32) {
+            const float* b32 = (const float*)src + c;
+            for (; r + 3 * g.krows < rend; r += 4 * g.krows) {
+                float4 v[4][2];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const float4* gp = (const float4*)(b32 + (pix0 + r + u * g.krows) * Cs); v[u][0] = gp[0]; v[u][1] = gp[1]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc8((const float*)&v[u][0]);
+            }
+            for (; r < rend; r += g.krows) {
+                const float4* gp = (const float4*)(b32 + (pix0 + r) * Cs);
+                float4 v[2] = {gp[0], gp[1]};
+                acc8((const float*)&v[0]);
+            }
+        } else {
+            const unsigned short* b16 = (const unsigned short*)src + c;
+            for (; r + 3 * g.krows < rend; r += 4 * g.krows) {
+                uint4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *(const uint4*)(b16 + (pix0 + r + u * g.krows) * Cs);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { float w[8]; unpack8<T>(v[u], w); acc8(w); }
+            }
+            for (; r < rend; r += g.krows) {
+                float w[8];
+                unpack8<T>(*(const uint4*)(b16 + (pix0 + r) * Cs), w);
+                acc8(w);
+            }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ps[r0 * C + chunk * 8 + e] = s[e]; pq[r0 * C + chunk * 8 + e] = q[e]; }
@@ -173,19 +193,41 @@ __global__ void gn_apply_kernel(const vv_groupnorm_params p, const GNGeom g) {
     };
     // Four rows per pass, all loads first: the input and the output may alias as far as the compiler knows, so in a one-row loop the load of row i + 1 follows
     // the store of row i and its s_waitcnt vmcnt(0) drains that store -- one serialised memory round trip per row and wave (round 5, second session)
+    // (round 6) ... and the thread's source, row stride and element type are resolved ONCE, outside the loop: gn_load8's source / type branches sat between the
+    // four loads of a pass, each in its own basic block behind an s_waitcnt vmcnt(0) -- the four loads were never in flight together
     int r = rbeg + r0;
     const int64_t base = (int64_t)f * p.HW;
-    for (; r + 3 * g.krows < rend; r += 4 * g.krows) {
-        float v[4][8];
+    const unsigned char* src = (const unsigned char*)p.in0;
+    int Cs = p.C0, c = chunk * 8;
+    if (c >= p.C0) { src = (const unsigned char*)p.in1; c -= p.C0; Cs = p.C1; }
+    if (p.in_dtype == VV_F32) {
+        const float* b32 = (const float*)src + c;
+        for (; r + 3 * g.krows < rend; r += 4 * g.krows) {
+            float4 v[4][2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) gn_load8<T>(p, base + r + u * g.krows, chunk, v[u]);
+            for (int u = 0; u < 4; ++u) { const float4* gp = (const float4*)(b32 + (base + r + u * g.krows) * Cs); v[u][0] = gp[0]; v[u][1] = gp[1]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) emit(v[u], base + r + u * g.krows);
-    }
-    for (; r < rend; r += g.krows) {
-        float v[8];
-        gn_load8<T>(p, base + r, chunk, v);
-        emit(v, base + r);
+            for (int u = 0; u < 4; ++u) emit((float*)&v[u][0], base + r + u * g.krows);
+        }
+        for (; r < rend; r += g.krows) {
+            const float4* gp = (const float4*)(b32 + (base + r) * Cs);
+            float4 v[2] = {gp[0], gp[1]};
+            emit((float*)&v[0], base + r);
+        }
+    } else {
+        const unsigned short* b16 = (const unsigned short*)src + c;
+        for (; r + 3 * g.krows < rend; r += 4 * g.krows) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const uint4*)(b16 + (base + r + u * g.krows) * Cs);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { float w[8]; unpack8<T>(v[u], w); emit(w, base + r + u * g.krows); }
+        }
+        for (; r < rend; r += g.krows) {
+            float w[8];
+            unpack8<T>(*(const uint4*)(b16 + (base + r) * Cs), w);
+            emit(w, base + r);
+        }
     }
 }
 

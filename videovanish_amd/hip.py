@@ -83,7 +83,7 @@ class MotionParams(C.Structure):
 class ChainParams(C.Structure):
     _fields_ = [("o", C.c_void_p), ("t_in", C.c_void_p), ("x", C.c_void_p), ("res1", C.c_void_p), ("out", C.c_void_p), ("out_dtype", C.c_int32),
                 ("stream", C.c_void_p), ("params", C.c_void_p), ("M", C.c_int64), ("C", C.c_int32), ("heads", C.c_int32), ("text_len", C.c_int32),
-                ("n_slabs", C.c_int32), ("n_params", C.c_int32), ("layout", C.c_int32)]
+                ("n_slabs", C.c_int32), ("n_params", C.c_int32), ("layout", C.c_int32), ("o_hw", C.c_int32)]
 
 
 CHAIN_LAYOUT_IDS = {"tokens": 0, "rowsplit": 1, "columns": 2}      # VV_CHAIN_LAYOUT_* (vvhip.h)
@@ -99,7 +99,7 @@ class AttnParams(C.Structure):
                 ("q_bs", C.c_int64), ("k_bs", C.c_int64), ("v_bs", C.c_int64), ("o_bs", C.c_int64),
                 ("q_rs", C.c_int64), ("k_rs", C.c_int64), ("v_rs", C.c_int64), ("o_rs", C.c_int64),
                 ("B", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nkv", C.c_int32), ("D", C.c_int32),
-                ("scale", C.c_float), ("q_hs", C.c_int64), ("k_hs", C.c_int64), ("v_hs", C.c_int64), ("q_prescaled", C.c_int32), ("lse", C.c_void_p)]
+                ("scale", C.c_float), ("q_hs", C.c_int64), ("k_hs", C.c_int64), ("v_hs", C.c_int64), ("q_prescaled", C.c_int32), ("lse", C.c_void_p), ("o_hs", C.c_int64)]
 
 
 EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name", "vv_conv_gemm", "vv_groupnorm_nsplit",
@@ -309,14 +309,14 @@ def attention_q_scale(D):
 
 
 def attention(dtype, q, k, v, out, *, B, heads, Nq, Nkv, D, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, q_off=0, k_off=0, v_off=0,
-              q_hs=0, k_hs=0, v_hs=0, q_prescaled=False, scale=None, lse=None):
+              q_hs=0, k_hs=0, v_hs=0, q_prescaled=False, scale=None, lse=None, o_hs=0):
     """q/k/v/out: h16 tensors (any shape); element offsets *_off select a column block inside a fused QKV buffer.
     q_prescaled: q already carries D**-0.5 * log2(e) (attention_q_scale(D) folded into the query projection)."""
     _need_cuda(q, k, v, out)
     es = 2
     p = AttnParams(q=q.data_ptr() + q_off * es, k=k.data_ptr() + k_off * es, v=v.data_ptr() + v_off * es, o=out.data_ptr(),
                    q_bs=q_bs, k_bs=k_bs, v_bs=v_bs, o_bs=o_bs, q_rs=q_rs, k_rs=k_rs, v_rs=v_rs, o_rs=o_rs, B=B, heads=heads, Nq=Nq,
-                   Nkv=Nkv, D=D, scale=float(D) ** -0.5 if scale is None else float(scale), q_hs=q_hs, k_hs=k_hs, v_hs=v_hs, q_prescaled=1 if q_prescaled else 0, lse=lse.data_ptr() if lse is not None else 0)
+                   Nkv=Nkv, D=D, scale=float(D) ** -0.5 if scale is None else float(scale), q_hs=q_hs, k_hs=k_hs, v_hs=v_hs, q_prescaled=1 if q_prescaled else 0, lse=lse.data_ptr() if lse is not None else 0, o_hs=o_hs)
     kind = "temporal" if (Nq <= 32 and Nkv <= 32) else ("cross" if Nkv < 128 and Nq != Nkv else "spatial")
     if PROFILE_SHAPES:
         kind = f"B{B},N{Nq}|" + kind
@@ -541,16 +541,18 @@ def _packing():
     return packing
 
 
-def spatial_chain_c320(dtype, o, t_in, x, stream_w, params, *, res1=None, out_dtype=torch.float32, layout=None):
+def spatial_chain_c320(dtype, o, t_in, x, stream_w, params, *, res1=None, out_dtype=torch.float32, layout=None, o_hw=0):
     """The fused tail of a level-0 spatial transformer block (vv_chain.hip): attn1 out-proj + residual, cross-attention to the text tokens,
-    GEGLU feed-forward, proj_out + block residual in ONE kernel.  o: h16 [M,320]; t_in, x (, res1): fp32 [M,320]."""
+    GEGLU feed-forward, proj_out + block residual in ONE kernel.  o: h16 [M,320] (o_hw = 0), or head-major [M / o_hw, 8, o_hw, 40] as vv_attention writes it
+    with o_hs = o_hw * 40; t_in, x (, res1): fp32 [M,320]."""
     _need_cuda(o, t_in, x, stream_w, params, res1)
     M, Cc = t_in.shape
-    assert o.shape == (M, Cc) and x.shape == (M, Cc) and o.dtype == h16(dtype) and t_in.dtype == x.dtype == torch.float32
+    assert o.numel() == M * Cc and x.shape == (M, Cc) and o.dtype == h16(dtype) and t_in.dtype == x.dtype == torch.float32
+    assert (o.shape == (M, Cc)) if o_hw == 0 else (M % o_hw == 0 and o.is_contiguous())
     out = torch.empty((M, Cc), dtype=out_dtype, device=x.device)
     cp = ChainParams(o=o.data_ptr(), t_in=t_in.data_ptr(), x=x.data_ptr(), res1=res1.data_ptr() if res1 is not None else 0, out=out.data_ptr(),
                      out_dtype=dt_of(out), stream=stream_w.data_ptr(), params=params.data_ptr(), M=M, C=Cc, heads=8, text_len=77,
-                     n_slabs=stream_w.shape[0], n_params=params.numel(), layout=CHAIN_LAYOUT_IDS[layout or _packing().CHAIN_LAYOUT])
+                     n_slabs=stream_w.shape[0], n_params=params.numel(), layout=CHAIN_LAYOUT_IDS[layout or _packing().CHAIN_LAYOUT], o_hw=int(o_hw))
     flops = 2.0 * M * Cc * Cc * (1 + 1 + 1 + 12 + 1) + 4.0 * M * 77 * Cc
     with _Prof("spatial_chain_fused[c320]", flops, M * Cc * (2 + 4 + 4 + out.element_size())):
         _check(lib().vv_spatial_chain_c320(C.byref(cp), dtype, _stream()), "vv_spatial_chain_c320")

@@ -327,13 +327,14 @@ class SelfAttention:
         # DMA of the attention kernel reads whole cache lines (the [token][3C] layout over-fetched 2.6x at D = 40)
         return self.core_qkv(self.qkv(n, out_dtype=self.ctx.h16, split=(self.heads, D, N)), B, N)
 
-    def core_qkv(self, qkv, B, N):
-        """softmax(QK^T)V on a head-major QKV buffer ([frame][q|k|v][head][token][D]) -> h16 [B*N, C]."""
+    def core_qkv(self, qkv, B, N, head_major_out=False):
+        """softmax(QK^T)V on a head-major QKV buffer ([frame][q|k|v][head][token][D]) -> h16 [B*N, C], or (head_major_out) [B, heads, N, D]: every wave
+        then stores whole contiguous 2 D-byte records instead of an 80-byte slice of a 640-byte row (vv_attn_params.o_hs; the fused chain tail reads it)."""
         C, dt, D = self.C, self.ctx.dt, self.C // self.heads
-        o = torch.empty((B * N, C), dtype=self.ctx.h16, device=qkv.device)
+        o = torch.empty((B, self.heads, N, D) if head_major_out else (B * N, C), dtype=self.ctx.h16, device=qkv.device)
         hip.attention(dt, qkv, qkv, qkv, o, B=B, heads=self.heads, Nq=N, Nkv=N, D=D, q_bs=N * 3 * C, k_bs=N * 3 * C,
-                      v_bs=N * 3 * C, o_bs=N * C, q_rs=D, k_rs=D, v_rs=D, o_rs=C, k_off=N * C, v_off=2 * N * C,
-                      q_hs=N * D, k_hs=N * D, v_hs=N * D, q_prescaled=self.prescale_q)
+                      v_bs=N * 3 * C, o_bs=N * C, q_rs=D, k_rs=D, v_rs=D, o_rs=D if head_major_out else C, k_off=N * C, v_off=2 * N * C,
+                      q_hs=N * D, k_hs=N * D, v_hs=N * D, q_prescaled=self.prescale_q, o_hs=N * D if head_major_out else 0)
         return o
 
     def temporal(self, n, res, Fr, HW, res1=None):
@@ -388,6 +389,7 @@ class SpatialTransformer:
     core runs as ONE kernel (csrc/vv_chain.hip: output projection, cross-attention, GEGLU feed-forward, proj_out, all residuals; the token's row
     stays in registers, weights and the per-head text K / V stream through an LDS ring); other widths run layer by layer."""
     FUSED = True          # class-level switch (tests / A-B runs compare both paths on the same weights)
+    HEAD_MAJOR_O = True   # the self-attention core's output in head-major layout between the two fused kernels (round 6: whole 80-byte records per store)
 
     def __init__(self, ctx, name, C, cfg, text_h16):
         self.ctx = ctx
@@ -432,8 +434,9 @@ class SpatialTransformer:
         if self.fused is not None and SpatialTransformer.FUSED and x.dtype == torch.float32:
             t, qkv = hip.spatial_chain_front_c320(self.ctx.dt, x, self.norm.g, self.norm.b, self.norm.groups, self.norm.eps, self.front[0], self.front[1],
                                                   F=F, HW=HW)
-            o = self.attn1.core_qkv(qkv, F, HW)
-            return hip.spatial_chain_c320(self.ctx.dt, o, t, x, self.fused[0], self.fused[1], out_dtype=out_dtype)
+            hm = SpatialTransformer.HEAD_MAJOR_O
+            o = self.attn1.core_qkv(qkv, F, HW, head_major_out=hm)
+            return hip.spatial_chain_c320(self.ctx.dt, o, t, x, self.fused[0], self.fused[1], out_dtype=out_dtype, o_hw=HW if hm else 0)
         h = self.norm(x, F, HW)
         t, _, _ = self.proj_in(h, F, H, W)
         t = self.attn1.spatial(self.n1(t), t, F, HW)
@@ -448,6 +451,7 @@ class MotionModule:
     (csrc/vv_motion.hip: one wave per pixel, trunk and activations in registers, weights streamed through an LDS ring); every other
     shape runs the layer-by-layer path below."""
     FUSED = True          # class-level switch (tests / A-B runs compare both paths on the same weights)
+    HEAD_MAJOR_O = True   # the self-attention core's output in head-major layout between the two fused kernels (round 6: whole 80-byte records per store)
 
     def __init__(self, ctx, name, C, cfg, pe_table):
         self.ctx = ctx

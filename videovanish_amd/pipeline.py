@@ -477,9 +477,14 @@ class DiffuEraserHIP:
         return hip.decode_blend(dec.contiguous(), torch.ones(F, dtype=torch.float32, device=dec.device), acc)
 
     def forward_reference_windows(self, frames, masks2d, priori, max_img_size=960, steps=None, nframes=22, overlap=4, return_float=False,
-                                  progress=None, scheduler="ddim"):
+                                  progress=None, scheduler="ddim", trace=None, key_override=None):
         """The third-party pipeline's own temporal scheme instead of independent chunks (one GPU; DDIM, or TCD as the reference's "2-Step" checkpoint
-        runs it: the re-noising tensors are seeded per step and tiled over the windows like the initial noise).  Same I/O as forward()."""
+        runs it: the re-noising tensors are seeded per step and tiled over the windows like the initial noise).  Same I/O as forward().
+        The key-frame pre-inference hands its result on as QUANTISED uint8 frames (they become known content: image, mask and conditioning latents): the one
+        discontinuity of the path -- a float difference of 1e-6 at a rounding boundary is a 1-level (3.9e-3) difference of that key pixel and, through its
+        re-encoding, a small change of every pixel the windows couple to it.  Measurement hooks for exactly that (tests/test_configs_gpu.py): `trace` (dict)
+        receives the key frames as computed here (`key_u8`, uint8 [nframes,H,W,3], and `key_idx`); `key_override` (uint8 array of the same shape) replaces them
+        -- with the oracle's key frames handed in, what remains is the float error of the path itself."""
         run, dev = self.run, self.ctx.device
         steps = steps or run.steps
         T = len(frames)
@@ -521,6 +526,11 @@ class DiffuEraserHIP:
             pix = self._to_pix01(self.decode(out_pre, nframes, h, w))
             ones = torch.full((nframes, H, W), 255, dtype=torch.uint8, device=dev)
             key_u8 = hip.blur_compose(pix, fr[idx].contiguous(), ones, self.taps)     # all-ones mask: the quantised generated frame
+            if trace is not None:
+                trace.update(key_u8=key_u8.cpu().numpy(), key_idx=[int(i) for i in idx.cpu()])
+            if key_override is not None:
+                key_u8 = torch.from_numpy(np.ascontiguousarray(key_override)).to(dev)
+                assert key_u8.shape == (nframes, H, W, 3) and key_u8.dtype == torch.uint8
             fr[idx] = key_u8                                  # key frames become known content: image replaced, mask cleared,
             mk[idx] = 0                                       # prior latents = their denoised latents
             prior_lat[idx] = out_pre
