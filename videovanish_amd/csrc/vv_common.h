@@ -68,6 +68,26 @@ __device__ __forceinline__ float gelu_f(float x) {
 }
 #endif
 
+// Two exact-erf GELUs at once WITHOUT transcendentals (round 6): gelu(x) = x/2 + |x|/2 * E(|x| / sqrt 2), E(z) = erf(z) on [0, 3.5] as z * Q(w), w = 2 z^2 / 3.5^2 - 1,
+// Q = the degree-12 Chebyshev fit of erf(z) / z in z^2 (monomial coefficients in w, all <= 0.41 in magnitude: well conditioned in fp32), z clamped to 3.5
+// (1 - erf(3.5) = 7.4e-7).  Evaluated in fp32: |error| <= 1.8e-6 over all x (the A&S form above: 4.7e-7; the h16 rounding that follows: 4.9e-4 relative) --
+// tools/gelu_poly_fit.py generates the coefficients and prints the error.  ~20 packed fp32 instructions per PAIR (v_pk_mul / v_pk_fma: two lanes' worth per issue)
+// against ~13 scalar instructions + v_rcp + v_exp per ELEMENT: the GEGLU epilogue of the short-K feed-forward GEMMs spends 30-45 % of its tile time in the
+// activation (K = 640: 760 TFLOP/s against 985 at K = 1280, same kernel: DESIGN 5, round 6).
+__device__ __forceinline__ vv_f32x2 gelu_poly2(vv_f32x2 x) {
+    const vv_f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    vv_f32x2 z = ax * 0.70710678118654752f;
+    z = (vv_f32x2){fminf(z.x, 3.5f), fminf(z.y, 3.5f)};
+    const vv_f32x2 w = __builtin_elementwise_fma(z * z, (vv_f32x2){0.16326530612244897f, 0.16326530612244897f}, (vv_f32x2){-1.0f, -1.0f});
+    vv_f32x2 q = {0.0017835492035374045f, 0.0017835492035374045f};
+#define VV_GP(c) q = __builtin_elementwise_fma(q, w, (vv_f32x2){c, c})
+    VV_GP(-0.004138993564993143f); VV_GP(0.0036422861739993095f); VV_GP(-0.006848857272416353f); VV_GP(0.017900297418236732f);
+    VV_GP(-0.030372897163033485f); VV_GP(0.04461858794093132f); VV_GP(-0.06463798880577087f); VV_GP(0.08848482370376587f);
+    VV_GP(-0.1146334782242775f); VV_GP(0.1467439830303192f); VV_GP(-0.20070014894008636f); VV_GP(0.4038730561733246f);
+#undef VV_GP
+    return __builtin_elementwise_fma(ax * 0.5f, z * q, x * 0.5f);
+}
+
 // host-side error plumbing -------------------------------------------------------------------------------------
 void vv_set_error(const char* fmt, ...);
 #define VV_FAIL(code, ...) do { vv_set_error(__VA_ARGS__); return (code); } while (0)

@@ -59,8 +59,16 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
                     const float bvv[4] = {bv[j / 2].x, bv[j / 2].y, bv[j / 2].z, bv[j / 2].w};
                     const float bgg[4] = {bg[j / 2].x, bg[j / 2].y, bg[j / 2].z, bg[j / 2].w};
                     float o[4];
+#ifdef VV_GELU_SCALAR      // lab: the scalar A&S form (v_rcp + v_exp per element) the epilogue used until round 6
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = (acc[i][j][r] + bvv[r]) * gelu_f(acc[i][j + 1][r] + bgg[r]);
+#else
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const vv_f32x2 ge = gelu_poly2((vv_f32x2){acc[i][j + 1][r] + bgg[r], acc[i][j + 1][r + 1] + bgg[r + 1]});
+                        o[r] = (acc[i][j][r] + bvv[r]) * ge.x; o[r + 1] = (acc[i][j][r + 1] + bvv[r + 1]) * ge.y;
+                    }
+#endif
                     const int64_t oc = (int64_t)m * p.ldo + (nt0 >> 1) + 4 * lq;
                     if (p.out_dtype == VV_F32) *(float4*)((float*)p.out + oc) = make_float4(o[0], o[1], o[2], o[3]);
                     else *(uint2*)((unsigned short*)p.out + oc) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));

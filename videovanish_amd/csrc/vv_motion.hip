@@ -66,6 +66,14 @@ __device__ __forceinline__ vv_f32x2 gelu2(vv_f32x2 x) {
     const vv_f32x2 erfc = q * e;                                       // 1 - erf(|x| / sqrt 2)
     return __builtin_elementwise_fma(ax * 0.5f, (vv_f32x2){1.0f, 1.0f} - erfc, x * 0.5f);      // 0.5 x (1 + sign(x) (1 - erfc))
 }
+// which GELU the fused kernel evaluates: the A&S form above.  gelu_poly2 (vv_common.h: packed fp32 polynomial, no v_rcp / v_exp -- the GEMM kernels' GEGLU epilogue since
+// round 6, +4.5..6.6 % there) was measured here too (-DVV_GELU2_POLY, lab): the motion module LOSES 3 % (3.04 -> 3.13 ms), the chain tail is unchanged -- these kernels
+// run one or two waves per SIMD beside the matrix pipe, the transcendental unit is otherwise idle and the polynomial's 14 extra packed FMAs are not (profiles/r6_gelu_ab.txt)
+#ifdef VV_GELU2_POLY
+#define VV_GELU2 gelu_poly2
+#else
+#define VV_GELU2 gelu2
+#endif
 
 template <typename T>
 __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_params p) {
@@ -342,8 +350,8 @@ __global__ __launch_bounds__(256, 1) void motion_c320_kernel(const vv_motion_par
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float4 bv = *(const float4*)(prm + P_B1 + c * 128 + (2 * i) * 16 + 4 * lg), bg = *(const float4*)(prm + P_B1 + c * 128 + (2 * i + 1) * 16 + 4 * lg);
-                const vv_f32x2 g01 = gelu2((vv_f32x2){g[2 * i + 1][tt][0] + bg.x, g[2 * i + 1][tt][1] + bg.y});
-                const vv_f32x2 g23 = gelu2((vv_f32x2){g[2 * i + 1][tt][2] + bg.z, g[2 * i + 1][tt][3] + bg.w});
+                const vv_f32x2 g01 = VV_GELU2((vv_f32x2){g[2 * i + 1][tt][0] + bg.x, g[2 * i + 1][tt][1] + bg.y});
+                const vv_f32x2 g23 = VV_GELU2((vv_f32x2){g[2 * i + 1][tt][2] + bg.z, g[2 * i + 1][tt][3] + bg.w});
                 hv[i][0] = (g[2 * i][tt][0] + bv.x) * g01.x; hv[i][1] = (g[2 * i][tt][1] + bv.y) * g01.y;
                 hv[i][2] = (g[2 * i][tt][2] + bv.z) * g23.x; hv[i][3] = (g[2 * i][tt][3] + bv.w) * g23.y;
             }
