@@ -102,8 +102,21 @@ typedef struct {
        summed (4/9 of the work): each of the four launches scatters with sc_sy = sc_sx = 2, (sc_oy, sc_ox) = its parity.  Not with GEGLU /
        split_heads / rowvec; runs on the 128-row tiles whatever tile_hint says. */
     int32_t sc_oh, sc_ow, sc_sy, sc_sx, sc_oy, sc_ox;
+    /* ABI 10 -- GroupNorm statistics out of the producing layer (round 6; optional, NULL = off): per-channel partial sums of the layer's FINAL output (after
+       bias, scale and residual) for the GroupNorm that reads it next, so that GroupNorm needs no statistics pass of its own over HBM.
+       gn_partials: fp32 [F][nblk][N][2] = (sum, sum of squares) over the rows of one row block, nblk = vv_conv_gn_partial_blocks(Hout, Wout) row blocks per
+       frame (a row block = the 64 rows one wave of an 8 x 16-pixel tile owns: it never straddles a frame).  Every slot is written by exactly one wave in a fixed
+       order (deterministic; rows outside the image contribute zero); vv_gn_finalize_partials sums them in double.  Honoured ONLY by the 128 x 160 halo-tile 3x3
+       kernel with the staged fp32 epilogue (3x3, stride 1, h16 source, fp32 output, at most the fp32 residual, no rowvec / act / scatter, N % 160 == 0): any
+       other launch with gn_partials != NULL fails with VV_E_UNSUPPORTED rather than leave the buffer unwritten. */
+    float* gn_partials;
 } vv_conv_params;
 int vv_conv_gemm(const vv_conv_params* host_p, int dtype, void* stream);
+int vv_conv_gn_partial_blocks(int Hout, int Wout);
+/* (mean, rstd) [F][groups][2] -- the layout vv_gn_affine / vv_gn_affine_frames and vv_groupnorm_apply_fin read -- from per-channel partials [F][nblk][C][2];
+   pool_frames = 1: one (mean, rstd) per group over the whole clip, replicated per frame.  Double accumulation in a fixed order. */
+int vv_gn_finalize_partials(const float* partials, int F, int nblk, int C, int HW, int groups, float eps, int pool_frames, float* fin, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------------------
  * K2  GroupNorm (+SiLU) and LayerNorm (+positional embedding), fp32 statistics, h16 output.
@@ -123,6 +136,8 @@ typedef struct {
     void* out; int32_t out_dtype;       /* [F*HW][C] h16 (or fp32) */
 } vv_groupnorm_params;
 int vv_groupnorm_nsplit(int HW, int C);
+/* the APPLY pass of vv_groupnorm alone, statistics taken from `fin` ([F][groups][2] mean, rstd) instead of a statistics pass (p.stats_ws is not used) */
+int vv_groupnorm_apply_fin(const vv_groupnorm_params* host_p, const float* fin, int dtype, void* stream);
 int vv_groupnorm(const vv_groupnorm_params* host_p, int dtype, void* stream);
 
 /* statistics half of vv_groupnorm only (out / gamma / beta unused): leaves (mean, rstd) per (frame, group) in

@@ -133,11 +133,11 @@ def test_struct_layouts_match_header(tmp_path):
     """sizeof / offsetof of the three parameter structs as gcc compiles include/vvhip.h == the ctypes mirrors in hip.py."""
     import subprocess
     from videovanish_amd import hip
-    probes = {"vv_conv_params": (hip.ConvParams, ["weight", "bias", "out", "ldo", "act", "split_heads", "split_tokens", "tile_hint", "act_slope"]),
+    probes = {"vv_conv_params": (hip.ConvParams, ["weight", "bias", "out", "ldo", "act", "split_heads", "split_tokens", "tile_hint", "act_slope", "sc_ox", "gn_partials"]),
               "vv_deform_params": (hip.DeformParams, ["x_dtype", "offset", "flow", "max_residue", "col", "B", "deform_groups", "Wo"]),
-              "vv_attn_params": (hip.AttnParams, ["o", "q_rs", "D", "scale", "q_hs", "v_hs", "q_prescaled"]),
+              "vv_attn_params": (hip.AttnParams, ["o", "q_rs", "D", "scale", "q_hs", "v_hs", "q_prescaled", "lse", "o_hs"]),
               "vv_groupnorm_params": (hip.GroupNormParams, ["groups", "eps", "gamma", "stats_ws", "out_dtype"]),
-              "vv_chain_params": (hip.ChainParams, ["out_dtype", "stream", "M", "text_len", "n_params", "layout"])}
+              "vv_chain_params": (hip.ChainParams, ["out_dtype", "stream", "M", "text_len", "n_params", "layout", "o_hw"])}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "vvhip.h"', "int main(void) {"]
     for name, (_, fields) in probes.items():
         src.append(f'  printf("{name} %zu", sizeof({name}));')

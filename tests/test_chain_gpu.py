@@ -106,3 +106,59 @@ def test_head_major_attention_output_is_bit_identical(gpu):
         finally:
             vnn.SpatialTransformer.HEAD_MAJOR_O = True
         assert torch.isfinite(res[0]).all() and torch.equal(res[0], res[1]), (Fr, H, W)
+
+
+def test_groupnorm_partials_from_the_conv_epilogue(gpu):
+    """Round 6: the 128 x 160 halo-tile 3x3 kernel leaves per-channel (sum, sum of squares) partials of its FINAL output (bias + residual
+    included) for the GroupNorm that reads it next (vv_conv_params.gn_partials).  (1) finalized, they give the mean / rstd of the stored tensor (fp64 reference)
+    for ragged image sizes too (rows outside the image count as zero), per frame and pooled; (2) the output itself is bit-identical with and without partials;
+    (3) two launches give identical partials (fixed order, no atomics); (4) a ResBlock + spatial transformer pair computes the same result through the
+    partials as through the statistics pass (to fp32 rounding of the statistics); (5) a launch that cannot honour the request is refused by name."""
+    from videovanish_amd import hip, nn as vnn
+    cfg = UNetConfig()
+    g = torch.Generator().manual_seed(21)
+    ctx = vnn.Ctx("cuda:0", "fp16", 0)
+    for (Fr, H, W, C) in ((2, 90, 160, 320), (3, 45, 80, 640), (2, 37, 50, 320)):
+        conv = vnn.Conv(ctx, "unet.down_blocks.0.resnets.0.conv2", C, C)
+        x = (torch.randn(Fr * H * W, C, generator=g) * 0.7).to(gpu).to(ctx.h16)
+        res = torch.randn(Fr * H * W, C, generator=g).to(gpu)
+        plain, _, _ = conv(x, Fr, H, W, res0=res)
+        out, _, _ = conv(x, Fr, H, W, res0=res, gn_partials=True)
+        out2, _, _ = conv(x, Fr, H, W, res0=res, gn_partials=True)
+        halo_anyway = ((H + 7) // 8) * 8 * ((W + 15) // 16) * 16 * 100 <= H * W * 115      # the dispatcher's own rule for the halo-tile kernel (vv_gemm.hip)
+        if halo_anyway:
+            assert torch.equal(out, plain)                     # the same kernel with the extra epilogue step: the stored tensor is bit-identical
+        else:
+            assert (out - plain).abs().max().item() <= 1e-5 * plain.abs().max().item()      # (37 x 50: the plain launch runs another loader / k order)
+        assert torch.equal(out, out2) and torch.equal(out.vv_gn.part, out2.vv_gn.part)
+        ref = out.double().view(Fr, H * W, 32, C // 32)
+        for pool in (False, True):
+            fin = out.vv_gn.finalize(32, 1e-6, pool_frames=pool).double()
+            dims = (0, 1, 3) if pool else (1, 3)
+            mean = ref.mean(dim=dims, keepdim=True).expand(Fr, 1, 32, 1).reshape(Fr, 32)
+            var = ref.var(dim=dims, unbiased=False, keepdim=True).expand(Fr, 1, 32, 1).reshape(Fr, 32)
+            assert (fin[..., 0] - mean).abs().max().item() <= 2e-6 * max(1.0, mean.abs().max().item()) + 2e-6
+            assert ((fin[..., 1] - (var + 1e-6).rsqrt()).abs() / (var + 1e-6).rsqrt()).max().item() <= 2e-5
+    # (4) the layer pair through both routes
+    text = ctx.dev(torch.randn(77, 768, generator=g), ctx.h16)
+    rb = vnn.ResBlock(ctx, "unet.down_blocks.0.resnets.0", 320, 320, cfg.groups, 1e-5, cfg.temb_dim, h16_mid=True)
+    st = vnn.SpatialTransformer(ctx, "unet.down_blocks.0.attentions.0", 320, cfg, text)
+    Fr, H, W = 2, 48, 64
+    x = torch.randn(Fr * H * W, 320, generator=g).to(gpu)
+    temb = torch.randn(1, cfg.temb_dim, generator=g).to(gpu)
+    outs = []
+    try:
+        for flag in (True, False):
+            vnn.ResBlock.GN_FROM_EPILOGUE = flag          # conv1 -> norm2 inside the block too, conv2 -> the transformer's GroupNorm
+            y = rb(x, Fr, H, W, silu_temb=temb, want_gn=True)
+            assert (getattr(y, "vv_gn", None) is not None) == flag
+            outs.append(st(y, Fr, H, W))
+    finally:
+        vnn.ResBlock.GN_FROM_EPILOGUE = True
+    rel = ((outs[0] - outs[1]).abs().max() / outs[1].abs().max()).item()
+    print(f"spatial transformer through conv-epilogue GroupNorm partials vs statistics pass: rel max {rel:.2e}")
+    assert torch.isfinite(outs[0]).all() and rel <= 1e-3
+    # (5) not the halo-tile kernel: a 1x1 convolution cannot write partials
+    lin = vnn.Conv(ctx, "unet.down_blocks.0.attentions.0.proj_in", 320, 320, k=1)
+    with pytest.raises(RuntimeError, match="gn_partials"):
+        lin(x.to(ctx.h16), Fr, H, W, gn_partials=True)

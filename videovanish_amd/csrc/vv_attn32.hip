@@ -571,8 +571,37 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
         }
         if (attempt == 1 || !__syncthreads_or(active && bad ? 1 : 0)) break;
     }
+    __syncthreads();      // (the second attempt leaves the loop without a barrier: every wave is done reading the tile buffers before one of them reuses its own below)
     if (!active) return;
     // ---- finalize: O[q][d] = O^T[d][q] / l
+    // Head-major output (o_rs == D: the 64 queries of this wave are 64 * 80 contiguous bytes) and a full tile: the O tile goes through LDS -- this wave's own tile
+    // buffer, dead since the loop's last barrier -- and leaves as five fully contiguous 1 KB stores (16 bytes per lane) instead of 8-byte pieces at an 80-byte
+    // stride per instruction (round 6: the pieces left L2 as partial 64-byte bursts; WRITE_SIZE 1.40x the algorithmic bytes even in the head-major layout).
+    if (p.o_rs == D && q0 + 64 <= p.Nq) {
+        unsigned char* mine = wave == 0 ? dK0 : (wave == 1 ? dK1 : (wave == 2 ? dV0 : dV1));
+        if (NW <= 4) {
+#pragma unroll
+            for (int x = 0; x < QB; ++x) {
+                const float inv = 1.0f / (r < 16 ? la[x] : lb[x]);
+                unsigned char* row = mine + (32 * x + r) * (D * 2);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(uint2*)(row + (8 * g + 4 * h) * 2) = make_uint2(pack2<T>(oacc[x][4 * g] * inv, oacc[x][4 * g + 1] * inv), pack2<T>(oacc[x][4 * g + 2] * inv, oacc[x][4 * g + 3] * inv));
+#pragma unroll
+                for (int qt2 = 0; qt2 < 2; ++qt2) {
+                    const float inv2 = 1.0f / (qt2 ? lb[x] : la[x]);
+                    if ((lane >> 4) < 2)
+                        *(uint2*)(mine + (32 * x + 16 * qt2 + (lane & 15)) * (D * 2) + (32 + 4 * (lane >> 4)) * 2) =
+                            make_uint2(pack2<T>(o2[x][qt2][0] * inv2, o2[x][qt2][1] * inv2), pack2<T>(o2[x][qt2][2] * inv2, o2[x][qt2][3] * inv2));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            unsigned char* dst = (unsigned char*)(O + (int64_t)q0 * D);
+#pragma unroll
+            for (int it = 0; it < (64 * D * 2) / 1024; ++it) *(uint4*)(dst + (it * 64 + lane) * 16) = *(const uint4*)(mine + (it * 64 + lane) * 16);
+            return;
+        }
+    }
 #pragma unroll
     for (int x = 0; x < QB; ++x) {
         {

@@ -46,7 +46,7 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gp_t)gptr, (lp_t)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int WR, int WC, int MT, int NT, int MODE, int SPLIT, int BKT, int OCCW = 2>
+template <typename T, int WR, int WC, int MT, int NT, int MODE, int SPLIT, int BKT, int OCCW = 2, bool GN = false>
 __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_params p, const int M, const int tilesM, const int tilesN) {
     constexpr int BM = WR * MT * 16, BN = WC * NT * 16;
     constexpr int CH = BKT / 8;                 // 16-byte chunks per tile row (8 for a 64-wide k tile, 4 for 32)
@@ -412,8 +412,10 @@ __global__ __launch_bounds__(256, OCCW) void conv_gemm_kernel(const vv_conv_para
     // others.  NOT in the loaders held to 128 VGPRs for a fourth block per CU (LIN, FAST9: it spills there, -30 %).  The fp32-operand loader (FAST32: zero
     // convolutions, conv_shortcuts -- HBM-bound fp32-in / fp32-out layers) loses 8-10 % with the lean form alone and GAINS 9-15 % with lean + STAGED (row-major
     // residual reads / stores through a wave-private LDS tile): profiles/r5_epilogue_ab.txt
-    gemm_epilogue<T, MT, NT, MODE == MODE_HALO || (MODE == MODE_FAST32 && NT == 5), (MODE == MODE_HALO || MODE == MODE_FAST32) && NT == 5>(p, acc, wr * MT * 16, n0 + wc * NT * 16, lr, lq, HWo, row_m, stage_bias ? sBias + wc * NT * 16 : nullptr,
-                                                ((HALO || A32) && NT == 5) ? (float*)sA0 + wave * (16 * (NT * 16 + 4)) : nullptr);      // (halo tiles: a strip = 16 consecutive pixels of one image row; the halo buffer is dead after the k loop's last barrier)
+    gemm_epilogue<T, MT, NT, MODE == MODE_HALO || (MODE == MODE_FAST32 && NT == 5), (MODE == MODE_HALO || MODE == MODE_FAST32) && NT == 5, GN>(p, acc, wr * MT * 16, n0 + wc * NT * 16, lr, lq, HWo, row_m, stage_bias ? sBias + wc * NT * 16 : nullptr,
+                                                ((HALO || A32) && NT == 5) ? (float*)sA0 + wave * (16 * (NT * 16 + 4)) : nullptr,      // (halo tiles: a strip = 16 consecutive pixels of one image row; the halo buffer is dead after the k loop's last barrier)
+                                                // GroupNorm partials of the output (round 6): row block = (patch of the frame, wave row): [frame][PH * PW * WR][N][2]
+                                                GN ? p.gn_partials + (((int64_t)tile_m * WR + wr) * p.N + n0 + wc * NT * 16) * 2 : nullptr);
 }
 
 template <typename T, int WR, int WC, int MT, int NT, int MODE>
@@ -465,6 +467,16 @@ int launch_mode(const vv_conv_params& p, int M, hipStream_t st) {
     const bool fast = (p.C0 % 64 == 0) && (p.C1 % 64 == 0) && p.Kpad == p.K;
     static const bool no32 = VV_AB_ENV("VV_GEMM_NO_FAST32");
     constexpr int dt = std::is_same<T, BF16>::value ? VV_BF16 : VV_F16;
+    if (p.gn_partials) {      // GroupNorm partials out of the epilogue: only the 128 x 160 halo-tile kernel with the staged fp32 epilogue writes them (vvhip.h)
+        const bool ok = fast && p.in_dtype != VV_F32 && p.ksize == 3 && (p.ksize_w == 0 || p.ksize_w == 3) && p.pad_t == 1 && p.pad_l == 1 && p.stride == 1 && p.sc_oh == 0 &&
+                        p.Hv == p.Hin && p.Wv == p.Win && p.Hout == p.Hin && p.Wout == p.Win && p.epilogue != VV_EPI_GEGLU && p.Npad % 160 == 0 && (p.N & 3) == 0 && (p.ldo & 3) == 0 &&
+                        p.out_dtype == VV_F32 && p.split_heads <= 0 && !p.rowvec && !p.res1 && p.act == VV_ACT_NONE && (!p.res0 || p.res_dtype == VV_F32);
+        if (!ok) VV_FAIL(VV_E_UNSUPPORTED, "vv_conv_gemm: gn_partials needs the 128 x 160 halo-tile 3x3 kernel with the staged fp32 epilogue (see vvhip.h)");
+        const int tilesM = p.F * ((p.Hin + 7) / 8) * ((p.Win + 15) / 16), tilesN = p.Npad / 160;
+        hipLaunchKernelGGL((conv_gemm_kernel<T, 2, 2, 4, 5, MODE_HALO, 2, 64, 2, true>), dim3(tilesM * tilesN), dim3(256), 0, st, p, M, tilesM, tilesN);      // its own instantiation: the
+        VV_CHECK_LAUNCH("vv_conv_gemm");                                                                                                                          // plain kernel keeps its registers
+        return VV_OK;
+    }
     if (p.tile_hint != 1) {   // compute-bound shapes: the 256-row tile kernel (vv_gemm256.hip)
         const int r = vv_gemm256_try(&p, dt, p.tile_hint >= 2 ? p.tile_hint - 1 : 0, (void*)st);
         if (r > -1000) return r;
@@ -505,6 +517,8 @@ extern "C" int vv_conv_gemm_launch_bf16(const vv_conv_params* pp, int M, void* s
 #if defined(VV_DT_ONLY)
 extern "C" int vv_conv_gemm_launch_bf16(const vv_conv_params* pp, int M, void* stream);
 #endif
+extern "C" int vv_conv_gn_partial_blocks(int Hout, int Wout) { return ((Hout + 7) / 8) * ((Wout + 15) / 16) * 2; }      // 8 x 16 patches x 2 wave rows
+
 extern "C" int vv_conv_gemm(const vv_conv_params* pp, int dtype, void* stream) {
     if (!pp) VV_FAIL(VV_E_ARG, "vv_conv_gemm: null params");
     const vv_conv_params& p = *pp;

@@ -29,9 +29,9 @@ __device__ __forceinline__ void stage_order_pin() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <typename T, int MT, int NT, bool LEAN = false, bool STAGED = false, typename RowMap>
+template <typename T, int MT, int NT, bool LEAN = false, bool STAGED = false, bool GN = false, typename RowMap>
 __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&acc)[MT][NT], const int row0, const int ncol0, const int lr,
-                                              const int lq, const int HWo, RowMap row_m, const float* sbias = nullptr, float* stage = nullptr) {
+                                              const int lq, const int HWo, RowMap row_m, const float* sbias = nullptr, float* stage = nullptr, float* gn_row = nullptr) {
     // ---- epilogue: lane owns out[m][n .. n+3].  All bias / time-embedding / residual loads of one 16-row strip are issued
     // back to back into registers BEFORE their first use (one wait per strip instead of one per load).
     const bool geglu = p.epilogue == VV_EPI_GEGLU;
@@ -84,6 +84,10 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
         // (320 bytes per row for the 80-column wave tile), residual read and store alike.  Same arithmetic, same order: bit-identical.
         constexpr int W = NT * 16, PITCH = W + 4;
         const int lane = lq * 16 + lr;
+        // GroupNorm statistics of the layer's output (vv_conv_params.gn_partials, round 6): lane c sums column c (and c + 64 while < W) of every strip of this
+        // wave's rows -- the final values go back into the wave-private tile (it is row-major and dead after the store) and are read column-wise: fixed order,
+        // no atomics, rows outside the image count as zero.  gn_row = this wave's [N][2] slot, offset to its first column.
+        float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int n = ncol0 + j * 16 + 4 * lq;
@@ -113,8 +117,31 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
             }
             stage_order_pin();
 #pragma unroll
-            for (int q = 0; q < NT; ++q)
-                if (on[q]) *(float4*)((float*)p.out + off[q]) = make_float4(v[q].x + r4[q].x, v[q].y + r4[q].y, v[q].z + r4[q].z, v[q].w + r4[q].w);
+            for (int q = 0; q < NT; ++q) {
+                const float4 o = make_float4(v[q].x + r4[q].x, v[q].y + r4[q].y, v[q].z + r4[q].z, v[q].w + r4[q].w);
+                if (on[q]) *(float4*)((float*)p.out + off[q]) = o;
+                if constexpr (GN) {
+                    const int idx = (q * 64 + lane) * 4, rr = idx / W, cc = idx - rr * W;
+                    *(float4*)(stage + rr * PITCH + cc) = on[q] ? o : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            if constexpr (GN) {
+                stage_order_pin();
+#pragma unroll 4
+                for (int r = 0; r < 16; ++r) {
+                    const float a = stage[r * PITCH + lane];
+                    gs0 += a; gq0 += a * a;
+                    if (W > 64) {
+                        const float b = lane < W - 64 ? stage[r * PITCH + 64 + lane] : 0.f;
+                        gs1 += b; gq1 += b * b;
+                    }
+                }
+                stage_order_pin();
+            }
+        }
+        if constexpr (GN) {
+            if (lane < W && ncol0 + lane < N) *(float2*)(gn_row + 2 * lane) = make_float2(gs0, gq0);
+            if (W > 64 && lane < W - 64 && ncol0 + 64 + lane < N) *(float2*)(gn_row + 2 * (64 + lane)) = make_float2(gs1, gq1);
         }
         return;
     }
@@ -163,9 +190,10 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
                     v[q][0] += a4.x; v[q][1] += a4.y; v[q][2] += a4.z; v[q][3] += a4.w; v[q][4] += b4.x; v[q][5] += b4.y; v[q][6] += b4.z; v[q][7] += b4.w;
                 }
                 if (split) {
-                    int64_t b, tok;
-                    if (snb) { tok = mm / snb; b = mm - tok * snb; } else { b = mm / stok; tok = mm - b * stok; }
-                    off[q] = (b * 3 * p.split_heads * stok + tok) * p.split_dim + colpart0 + cc;
+                    const int mi = (int)mm;      // (32-bit division: a row index is < 2^31; as int64 every (strip, q) paid a ~100-instruction 64-bit division -- round 6)
+                    int b, tok;
+                    if (snb) { tok = mi / snb; b = mi - tok * snb; } else { b = mi / stok; tok = mi - b * stok; }
+                    off[q] = ((int64_t)b * 3 * p.split_heads * stok + tok) * p.split_dim + colpart0 + cc;
                 } else off[q] = mm * p.ldo + ncol0 + cc;
             }
             stage_order_pin();

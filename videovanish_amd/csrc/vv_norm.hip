@@ -293,7 +293,62 @@ int gn_launch(const vv_groupnorm_params& p, hipStream_t st, bool apply = true) {
     return VV_OK;
 }
 
+// (mean, rstd) from per-channel partials [F][nblk][C][2] written by a producing layer's epilogue (vv_conv_params.gn_partials): one block per (group, frame) --
+// or per group when the statistics pool over the clip -- thread t takes items t, t + 256, ... in double, then a fixed-order LDS tree: deterministic.
+__global__ __launch_bounds__(256) void gn_finalize_partials_kernel(const float* part, int F, int nblk, int C, int HW, int groups, float eps, int pool, float* fin) {
+    __shared__ double ss[256], sq[256];
+    const int grp = blockIdx.x, t = threadIdx.x, cpg = C / groups;
+    const int f0 = pool ? 0 : blockIdx.y, nf = pool ? F : 1;
+    const int items = nf * nblk * cpg;
+    double s = 0.0, q = 0.0;
+    for (int i = t; i < items; i += 256) {
+        const int c = i % cpg, b = i / cpg;           // b = (frame - f0) * nblk + row block
+        const float* w = part + (((int64_t)f0 * nblk + b) * C + grp * cpg + c) * 2;
+        s += w[0]; q += w[1];
+    }
+    ss[t] = s; sq[t] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) { ss[t] += ss[t + o]; sq[t] += sq[t + o]; }
+        __syncthreads();
+    }
+    const double n = (double)nf * HW * cpg;
+    const double mean = ss[0] / n;
+    double var = sq[0] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (pool) { for (int f = t; f < F; f += 256) { fin[((int64_t)f * groups + grp) * 2] = (float)mean; fin[((int64_t)f * groups + grp) * 2 + 1] = rstd; } }
+    else if (t == 0) { fin[((int64_t)f0 * groups + grp) * 2] = (float)mean; fin[((int64_t)f0 * groups + grp) * 2 + 1] = rstd; }
+}
+
 }  // namespace
+
+extern "C" int vv_gn_finalize_partials(const float* partials, int F, int nblk, int C, int HW, int groups, float eps, int pool_frames, float* fin, void* stream) {
+    if (!partials || !fin || F <= 0 || nblk <= 0 || C <= 0 || HW <= 0 || groups <= 0 || C % groups) VV_FAIL(VV_E_ARG, "vv_gn_finalize_partials: bad arguments");
+    hipLaunchKernelGGL(gn_finalize_partials_kernel, dim3(groups, pool_frames ? 1 : F), dim3(256), 0, (hipStream_t)stream, partials, F, nblk, C, HW, groups, eps, pool_frames, fin);
+    VV_CHECK_LAUNCH("vv_gn_finalize_partials");
+    return VV_OK;
+}
+
+extern "C" int vv_groupnorm_apply_fin(const vv_groupnorm_params* pp, const float* fin, int dtype, void* stream) {
+    if (!pp || !fin) VV_FAIL(VV_E_ARG, "vv_groupnorm_apply_fin: null pointer");
+    vv_groupnorm_params p = *pp;
+    const int C = p.C0 + p.C1;
+    if (dtype != VV_BF16 && dtype != VV_F16) VV_FAIL(VV_E_ARG, "vv_groupnorm_apply_fin: bad dtype");
+    if (!p.in0 || !p.out || !p.gamma || !p.beta) VV_FAIL(VV_E_ARG, "vv_groupnorm_apply_fin: null pointer");
+    if (p.C0 <= 0 || p.C0 % 8 || p.C1 % 8 || (p.C1 > 0 && !p.in1) || p.groups <= 0 || p.groups > 256 || C % p.groups || C / 8 > 1024) VV_FAIL(VV_E_ARG, "vv_groupnorm_apply_fin: channels / groups");
+    if ((p.in_dtype != VV_F32 && p.in_dtype != dtype) || (p.out_dtype != VV_F32 && p.out_dtype != dtype && p.out_dtype != VV_SPLIT3)) VV_FAIL(VV_E_ARG, "vv_groupnorm_apply_fin: dtype mismatch");
+    if (p.F <= 0 || p.HW <= 0) VV_FAIL(VV_E_ARG, "vv_groupnorm_apply_fin: empty input");
+    const GNGeom g = gn_geom(p.HW, C);
+    // the apply kernel reads (mean, rstd) at stats_ws + F * nsplit * groups * 2 (behind the partials of its own statistics pass): point that address at `fin`
+    p.stats_ws = const_cast<float*>(fin) - (int64_t)p.F * g.nsplit * p.groups * 2;
+    const int threads = (g.threads + 63) / 64 * 64;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VV_BF16) hipLaunchKernelGGL(gn_apply_kernel<BF16>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
+    else hipLaunchKernelGGL(gn_apply_kernel<F16>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
+    VV_CHECK_LAUNCH("vv_groupnorm_apply_fin");
+    return VV_OK;
+}
 
 extern "C" int vv_groupnorm_nsplit(int HW, int C) { return gn_geom(HW, C).nsplit; }
 

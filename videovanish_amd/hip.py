@@ -57,7 +57,8 @@ class ConvParams(C.Structure):
                 ("out_dtype", C.c_int32), ("ldo", C.c_int32), ("epilogue", C.c_int32), ("out_scale", C.c_float), ("ksize_w", C.c_int32),
                 ("act", C.c_int32), ("split_heads", C.c_int32), ("split_dim", C.c_int32), ("split_tokens", C.c_int32),
                 ("tile_hint", C.c_int32), ("act_slope", C.c_float),
-                ("sc_oh", C.c_int32), ("sc_ow", C.c_int32), ("sc_sy", C.c_int32), ("sc_sx", C.c_int32), ("sc_oy", C.c_int32), ("sc_ox", C.c_int32)]
+                ("sc_oh", C.c_int32), ("sc_ow", C.c_int32), ("sc_sy", C.c_int32), ("sc_sx", C.c_int32), ("sc_oy", C.c_int32), ("sc_ox", C.c_int32),
+                ("gn_partials", C.c_void_p)]
 
 
 class DeformParams(C.Structure):
@@ -109,7 +110,7 @@ EXPORTS = ["vv_abi_version", "vv_last_error", "vv_device_count", "vv_device_name
            "vv_avgpool2_f32", "vv_corr_lookup", "vv_raft_ctx_split", "vv_raft_flow_prep", "vv_gru_rh", "vv_gru_update", "vv_add_flow",
            "vv_add_relu_f32", "vv_convex_upsample", "vv_fb_valid", "vv_deform_im2col", "vv_fc_input", "vv_upsample2x_bilinear", "vv_flow_combine", "vv_gather_rows", "vv_fold_patches", "vv_flow_down4", "vv_gen_compose", "vv_gen_input", "vv_prop_fill", "vv_prop_combine", "vv_masked_sum_u8", "vv_u8_to_f32", "vv_u8_is_zero",
            "vv_raft_prep", "vv_split_f32", "vv_pad_channels_f32", "vv_window_average",
-           "vv_groupnorm_stats", "vv_gn_affine", "vv_motion_module_c320", "vv_split3", "vv_spatial_chain_c320", "vv_spatial_chain_front_c320", "vv_gn_affine_frames",
+           "vv_groupnorm_stats", "vv_gn_affine", "vv_conv_gn_partial_blocks", "vv_gn_finalize_partials", "vv_groupnorm_apply_fin", "vv_motion_module_c320", "vv_split3", "vv_spatial_chain_c320", "vv_spatial_chain_front_c320", "vv_gn_affine_frames",
            # SAM 2 (row n4)
            "vv_u8_normalize", "vv_layernorm_ex", "vv_maxpool2x2", "vv_rope_apply", "vv_dwconv", "vv_pixel_shuffle2", "vv_resize_bilinear_f32",
            "vv_mask_mem_input", "vv_act", "vv_prompt_points", "vv_sine_pe_1d", "vv_sam_select", "vv_sam_pick", "vv_select_f32",
@@ -181,8 +182,9 @@ def _need_cuda(*ts):
 def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, Wv=None, Hout=None, Wout=None, ksize=1,
               stride=1, pad_t=0, pad_l=0, bias=None, rowvec=None, res0=None, res1=None, out=None, out_dtype=None,
               epilogue=EPI_NONE, out_scale=1.0, C0=None, C1=0, ksize_w=0, act=ACT_NONE, out_col=0, split_heads=0, split_dim=0, split_tokens=0, tile_hint=0,
-              act_slope=0.0, scatter=None):
-    """Launch vv_conv_gemm.  x0/x1: NHWC activations ([F,Hin,Win,C] or any shape with C last); weight: [Npad,Kpad] h16.
+              act_slope=0.0, scatter=None, gn_partials=False):
+    """Launch vv_conv_gemm.  gn_partials: the layer also leaves per-channel (sum, sum of squares) partials of its output for the GroupNorm that reads it next
+    (vv_conv_params.gn_partials; only the 128 x 160 halo-tile 3x3 kernel can): the returned tensor carries them as `out.vv_gn`.  x0/x1: NHWC activations ([F,Hin,Win,C] or any shape with C last); weight: [Npad,Kpad] h16.
     scatter = (OH, OW, sy, sx, oy, ox): row (f, y, x) of this launch goes to row (f*OH + y*sy + oy)*OW + x*sx + ox of `out` (required; residuals
     are read at the same rows) -- the four parity launches of a convolution over a nearest-2x upsampled image (nn.UpConv2x)."""
     _need_cuda(x0, x1, weight, bias, rowvec, res0, res1, out)      # out_col: write into columns [out_col, out_col+N) of `out`
@@ -214,6 +216,11 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
                    epilogue=epilogue, out_scale=out_scale, ksize_w=ksize_w, act=act, split_heads=split_heads, split_dim=split_dim,
                    split_tokens=split_tokens, tile_hint=tile_hint, act_slope=act_slope,
                    sc_oh=sc[0], sc_ow=sc[1], sc_sy=sc[2], sc_sx=sc[3], sc_oy=sc[4], sc_ox=sc[5])
+    if gn_partials:
+        nblk = lib().vv_conv_gn_partial_blocks(Hout, Wout)
+        part = torch.empty((F, nblk, N, 2), dtype=torch.float32, device=x0.device)
+        p.gn_partials = part.data_ptr()
+        out.vv_gn = GNPartials(part, nblk, F, Hout * Wout, N)
     if PROFILE is not None:
         Npad = weight.shape[0]
         # mirror of launch_t() in vv_gemm.hip (label only): LDS-DMA loaders prefer the 128x128 tile (4 blocks per CU) when N allows
@@ -251,7 +258,22 @@ def conv_gemm(dtype, x0, weight, N, K, *, x1=None, F=1, Hin=1, Win=1, Hv=None, W
     return out
 
 
-def groupnorm(dtype, x0, gamma, beta, groups, eps, *, x1=None, F, HW, silu=False, pool_frames=False, out_dtype=None, act=None):
+class GNPartials:
+    """per-channel (sum, sum of squares) partials [F, nblk, C, 2] of a tensor, written by the epilogue of the layer that produced it (conv_gemm(gn_partials=True))"""
+
+    def __init__(self, part, nblk, F, HW, C):
+        self.part, self.nblk, self.F, self.HW, self.C = part, nblk, F, HW, C
+
+    def finalize(self, groups, eps, pool_frames=False):
+        """-> fin [F, groups, 2] (mean, rstd): vv_gn_finalize_partials (double accumulation, fixed order)"""
+        fin = torch.empty((self.F, groups, 2), dtype=torch.float32, device=self.part.device)
+        _check(lib().vv_gn_finalize_partials(_p(self.part), self.F, self.nblk, self.C, self.HW, groups, _f(eps), int(bool(pool_frames)), _p(fin), _stream()),
+               "vv_gn_finalize_partials")
+        return fin
+
+
+def groupnorm(dtype, x0, gamma, beta, groups, eps, *, x1=None, F, HW, silu=False, pool_frames=False, out_dtype=None, act=None, partials=None):
+    """partials (GNPartials of x0, one source): the statistics pass over HBM is skipped -- (mean, rstd) come from the producer's partial sums."""
     _need_cuda(x0, x1, gamma, beta)
     C0 = x0.shape[-1]
     C1 = x1.shape[-1] if x1 is not None else 0
@@ -267,6 +289,12 @@ def groupnorm(dtype, x0, gamma, beta, groups, eps, *, x1=None, F, HW, silu=False
     p = GroupNormParams(in0=x0.data_ptr(), in1=x1.data_ptr() if x1 is not None else 0, in_dtype=dt_of(x0), C0=C0, C1=C1, F=F, HW=HW,
                         groups=groups, pool_frames=int(pool_frames), eps=eps, gamma=gamma.data_ptr(), beta=beta.data_ptr(),
                         silu=int(act) if act is not None else int(silu), stats_ws=ws.data_ptr(), out=out.data_ptr(), out_dtype=odt)
+    if partials is not None:
+        assert x1 is None and (partials.F, partials.HW, partials.C) == (F, HW, C0), "GroupNorm partials do not describe this tensor"
+        fin = partials.finalize(groups, eps, pool_frames)
+        with _Prof("groupnorm", 0.0, F * HW * Ctot * (x0.element_size() + (6 if odt == SPLIT3 else out.element_size()))):
+            _check(lib().vv_groupnorm_apply_fin(C.byref(p), _p(fin), dtype, _stream()), "vv_groupnorm_apply_fin")
+        return out
     with _Prof("groupnorm", 0.0, F * HW * Ctot * (2 * x0.element_size() + (6 if odt == SPLIT3 else out.element_size()))):
         _check(lib().vv_groupnorm(C.byref(p), dtype, _stream()), "vv_groupnorm")
     return out
@@ -559,21 +587,26 @@ def spatial_chain_c320(dtype, o, t_in, x, stream_w, params, *, res1=None, out_dt
     return out
 
 
-def spatial_chain_front_c320(dtype, x, gamma, beta, groups, eps, stream_w, params, *, F, HW):
+def spatial_chain_front_c320(dtype, x, gamma, beta, groups, eps, stream_w, params, *, F, HW, partials=None):
     """The fused front of a level-0 spatial transformer block (vv_chain.hip): per-frame GroupNorm statistics -> per-channel affine -> ONE kernel for
     GroupNorm apply + proj_in + LayerNorm + the fused q|k|v projection.  Returns (t fp32 [M,320] = the block's residual stream, qkv h16 head-major
     [F][3][8][HW][40])."""
     _need_cuda(x, gamma, beta, stream_w, params)
     M, Cc = x.shape
     assert M == F * HW and x.dtype == torch.float32
-    nsplit = lib().vv_groupnorm_nsplit(HW, Cc)
-    ws = torch.empty(F * (nsplit + 1) * groups * 2, dtype=torch.float32, device=x.device)
-    gp = GroupNormParams(in0=x.data_ptr(), in1=0, in_dtype=dt_of(x), C0=Cc, C1=0, F=F, HW=HW, groups=groups, pool_frames=0, eps=eps,
-                         gamma=gamma.data_ptr(), beta=beta.data_ptr(), silu=0, stats_ws=ws.data_ptr(), out=0, out_dtype=F32)
-    with _Prof("groupnorm", 0.0, F * HW * Cc * x.element_size()):
-        _check(lib().vv_groupnorm_stats(C.byref(gp), dtype, _stream()), "vv_groupnorm_stats")
     aff = torch.empty((F, 2, Cc), dtype=torch.float32, device=x.device)
-    fin = ws.data_ptr() + F * nsplit * groups * 2 * 4
+    if partials is not None:      # the producing convolution left per-channel partial sums of x (conv_gemm(gn_partials=True)): no statistics pass over HBM
+        assert (partials.F, partials.HW, partials.C) == (F, HW, Cc), "GroupNorm partials do not describe this tensor"
+        fin_t = partials.finalize(groups, eps)
+        fin = fin_t.data_ptr()
+    else:
+        nsplit = lib().vv_groupnorm_nsplit(HW, Cc)
+        ws = torch.empty(F * (nsplit + 1) * groups * 2, dtype=torch.float32, device=x.device)
+        gp = GroupNormParams(in0=x.data_ptr(), in1=0, in_dtype=dt_of(x), C0=Cc, C1=0, F=F, HW=HW, groups=groups, pool_frames=0, eps=eps,
+                             gamma=gamma.data_ptr(), beta=beta.data_ptr(), silu=0, stats_ws=ws.data_ptr(), out=0, out_dtype=F32)
+        with _Prof("groupnorm", 0.0, F * HW * Cc * x.element_size()):
+            _check(lib().vv_groupnorm_stats(C.byref(gp), dtype, _stream()), "vv_groupnorm_stats")
+        fin = ws.data_ptr() + F * nsplit * groups * 2 * 4
     _check(lib().vv_gn_affine_frames(C.c_void_p(fin), _p(gamma), _p(beta), Cc, groups, F, _p(aff), _stream()), "vv_gn_affine_frames")
     t = torch.empty((M, Cc), dtype=torch.float32, device=x.device)
     qkv = torch.empty((F, 3, 8, HW, Cc // 8), dtype=h16(dtype), device=x.device)

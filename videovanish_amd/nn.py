@@ -93,7 +93,7 @@ class Conv:
         self.b = ctx.dev(bias_t.float()) if bias_t is not None else None
 
     def __call__(self, x0, F, H, W, x1=None, stride=1, Hv=None, Wv=None, Hout=None, Wout=None, pad=None, bias=True, rowvec=None,
-                 res0=None, res1=None, out_dtype=torch.float32, out=None, scale=1.0, bias_override=None):
+                 res0=None, res1=None, out_dtype=torch.float32, out=None, scale=1.0, bias_override=None, gn_partials=False):
         k = self.k
         pad = (k // 2) if pad is None else pad
         Hv = H if Hv is None else Hv
@@ -112,7 +112,7 @@ class Conv:
                                  out_scale=scale), Hout, Wout
         return hip.conv_gemm(self.ctx.dt, x0, self.w, self.cout, self.K, x1=x1, F=F, Hin=H, Win=W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout,
                              ksize=k, stride=stride, pad_t=pad, pad_l=pad, bias=b, rowvec=rowvec, res0=res0, res1=res1, out=out,
-                             out_dtype=out_dtype, epilogue=hip.EPI_GEGLU if self.geglu else hip.EPI_NONE, out_scale=scale), Hout, Wout
+                             out_dtype=out_dtype, epilogue=hip.EPI_GEGLU if self.geglu else hip.EPI_NONE, out_scale=scale, gn_partials=gn_partials), Hout, Wout
 
 
 class UpConv2x:
@@ -227,9 +227,9 @@ class GroupNorm:
         g, b = ctx.src.norm(name, C)
         self.g, self.b = ctx.dev(g), ctx.dev(b)
 
-    def __call__(self, x0, F, HW, x1=None, silu=False, pool_frames=False):
+    def __call__(self, x0, F, HW, x1=None, silu=False, pool_frames=False, partials=None):
         return hip.groupnorm(self.ctx.dt, x0, self.g, self.b, self.groups, self.eps, x1=x1, F=F, HW=HW, silu=silu, pool_frames=pool_frames,
-                             out_dtype=self.out_dtype)
+                             out_dtype=self.out_dtype, partials=partials)
 
 
 class LayerNorm:
@@ -250,6 +250,9 @@ class ResBlock:
     # parity -- predicted on the CPU (tools/parity_h16_conv1.py: rms +1.5 % at full width), measured on the GPU: rms +1.8 % at c1, +6.7 % at 50 steps full width, and the smoke clip's
     # per-pixel maximum 8.3e-4 -> 1.015e-3, over the 1e-3 bound (profiles/r5_h16_mid_ab.txt).  The switch stays for the A/B (tools/bench_with.py ResBlock.H16_MID=1).
     H16_MID = False
+    # conv2 leaves per-channel partial sums of the block's output for the GroupNorm of the spatial transformer that follows (vv_conv_params.gn_partials, round 6):
+    # that GroupNorm then needs no statistics pass over HBM.  Only where conv2 runs on the 128 x 160 halo-tile kernel anyway (C = 320 / 640 at 720p-class sizes).
+    GN_FROM_EPILOGUE = True
 
     def __init__(self, ctx, name, cin, cout, groups, eps, temb_dim=None, precise=False, precise_temb=False, h16_mid=False):
         self.ctx, self.cin, self.cout = ctx, cin, cout
@@ -269,7 +272,13 @@ class ResBlock:
         res = self.conv1.b.view(1, -1) if S == 1 else self.conv1.b.view(1, -1).repeat(S, 1)
         return self.temb(silu_temb, res0=res)
 
-    def __call__(self, x0, F, H, W, x1=None, silu_temb=None, res1=None, out_dtype=torch.float32):
+    def wants_gn_partials(self, H, W, res1, out_dtype):
+        """conv2 can emit the GroupNorm partials of the block's output: the shapes the dispatcher sends to the 128 x 160 halo-tile kernel"""
+        cover = ((H + 7) // 8) * 8 * ((W + 15) // 16) * 16
+        return (ResBlock.GN_FROM_EPILOGUE and self.cout in (320, 640) and not self.conv2.precise and res1 is None and out_dtype == torch.float32
+                and cover * 100 <= H * W * 115 and H * W >= 2048)
+
+    def __call__(self, x0, F, H, W, x1=None, silu_temb=None, res1=None, out_dtype=torch.float32, want_gn=False):
         HW = H * W
         h = self.norm1(x0, F, HW, x1=x1, silu=True)
         b1 = None
@@ -279,13 +288,16 @@ class ResBlock:
                 b1 = silu_temb[id(self)]
             else:
                 b1 = self.temb_bias(silu_temb).view(-1)
-        h, _, _ = self.conv1(h, F, H, W, bias_override=b1, out_dtype=self.ctx.h16 if (self.h16_mid and ResBlock.H16_MID) else torch.float32)
-        h = self.norm2(h, F, HW, silu=True)
+        mid16 = self.h16_mid and ResBlock.H16_MID
+        h, _, _ = self.conv1(h, F, H, W, bias_override=b1, out_dtype=self.ctx.h16 if mid16 else torch.float32,
+                             gn_partials=not mid16 and not self.conv1.precise and self.wants_gn_partials(H, W, None, torch.float32))      # conv1's output feeds norm2 only
+        h = self.norm2(h, F, HW, silu=True, partials=getattr(h, "vv_gn", None))
         if self.short is not None:
             xs, _, _ = self.short(x0, F, H, W, x1=x1)
         else:
             xs = x0
-        out, _, _ = self.conv2(h, F, H, W, res0=xs, res1=res1, out_dtype=out_dtype)
+        out, _, _ = self.conv2(h, F, H, W, res0=xs, res1=res1, out_dtype=out_dtype,
+                               gn_partials=bool(want_gn) and self.wants_gn_partials(H, W, res1, out_dtype))
         return out
 
 
@@ -431,13 +443,14 @@ class SpatialTransformer:
 
     def __call__(self, x, F, H, W, out_dtype=torch.float32):
         HW = H * W
+        gn = getattr(x, "vv_gn", None)      # partial sums of x left by the convolution that produced it (ResBlock.GN_FROM_EPILOGUE)
         if self.fused is not None and SpatialTransformer.FUSED and x.dtype == torch.float32:
             t, qkv = hip.spatial_chain_front_c320(self.ctx.dt, x, self.norm.g, self.norm.b, self.norm.groups, self.norm.eps, self.front[0], self.front[1],
-                                                  F=F, HW=HW)
+                                                  F=F, HW=HW, partials=gn)
             hm = SpatialTransformer.HEAD_MAJOR_O
             o = self.attn1.core_qkv(qkv, F, HW, head_major_out=hm)
             return hip.spatial_chain_c320(self.ctx.dt, o, t, x, self.fused[0], self.fused[1], out_dtype=out_dtype, o_hw=HW if hm else 0)
-        h = self.norm(x, F, HW)
+        h = self.norm(x, F, HW, partials=gn)
         t, _, _ = self.proj_in(h, F, H, W)
         t = self.attn1.spatial(self.n1(t), t, F, HW)
         t = self.attn2(self.n2(t), t, F, HW)

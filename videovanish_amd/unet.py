@@ -138,7 +138,7 @@ class _Backbone:
         L = len(self.cfg.block_out)
         for i, layers in enumerate(self.down):
             for (r, a, m) in layers:
-                x = r(x, F, H, W, silu_temb=st)
+                x = r(x, F, H, W, silu_temb=st, want_gn=a is not None)      # (its output feeds the spatial transformer's GroupNorm)
                 if a is not None:
                     x = a(x, F, H, W)
                 if m is not None:
@@ -154,7 +154,7 @@ class _Backbone:
         return x, skips, (H, W)
 
     def run_mid(self, x, F, H, W, st):
-        x = self.mid_r0(x, F, H, W, silu_temb=st)
+        x = self.mid_r0(x, F, H, W, silu_temb=st, want_gn=True)
         x = self.mid_a(x, F, H, W)
         if self.mid_m is not None:
             x = self.mid_m(x, F, H, W)
@@ -175,7 +175,7 @@ class _Backbone:
                 # the output of a block's last layer feeds only MFMA A operands (upsampler conv, BrushNet zero conv):
                 # store it as h16 (same operand values, half the bytes, LDS-DMA fast path downstream)
                 od = self.ctx.h16 if (li == len(layers) - 1 and i < L - 1 and not (last == "a" and au is not None)) else f32
-                x = r(x, F, H, W, x1=s, silu_temb=st, res1=au if last == "r" else None, out_dtype=od if last == "r" else f32)
+                x = r(x, F, H, W, x1=s, silu_temb=st, res1=au if last == "r" else None, out_dtype=od if last == "r" else f32, want_gn=a is not None)
                 if a is not None:
                     x = a(x, F, H, W, out_dtype=od if last == "a" else f32)
                     if last == "a" and au is not None:
