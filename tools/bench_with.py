@@ -8,7 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 args = sys.argv[1:]
 split = args.index("--") if "--" in args else len(args)
-from videovanish_amd import nn as vnn, unet as vunet      # noqa: E402
+from videovanish_amd import hip as _hip, nn as vnn, unet as vunet      # noqa: E402
+if os.environ.get("VV_LIB_PATH"):
+    _hip._LIB_PATH = os.environ["VV_LIB_PATH"]      # (lab) another build of the library
 for item in args[:split]:
     path, val = item.split("=")
     cls, attr = path.split(".")

@@ -128,8 +128,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40_kernel(const vv_attn_para
     {
         const unsigned one2 = (unsigned)T::from_f32(1.0f) * 0x10001u;
         const uint4 ones = make_uint4(one2, one2, one2, one2), zero = make_uint4(0, 0, 0, 0);
-        for (int i = t; i < (TILE + KONES) / 16; i += NT) { *(uint4*)(dK0 + i * 16) = i < TILE / 16 ? zero : ones; *(uint4*)(dK1 + i * 16) = i < TILE / 16 ? zero : ones; }
-        for (int i = t; i < (TILE + VONES) / 16; i += NT) { *(uint4*)(dV0 + i * 16) = i < TILE / 16 ? zero : ones; *(uint4*)(dV1 + i * 16) = i < TILE / 16 ? zero : ones; }
+        // (two loops per region, not `i < TILE / 16 ? zero : ones`: hipcc turned that select into a 32-byte SCRATCH array indexed by the condition -- every thread of the
+        //  launch wrote and re-read it: 0.12 GB of HBM writes per level-0 launch, 29 % of the kernel's WRITE_SIZE; found in round 6 through private_segment_fixed_size = 48)
+        for (int i = t; i < TILE / 16; i += NT) { *(uint4*)(dK0 + i * 16) = zero; *(uint4*)(dK1 + i * 16) = zero; *(uint4*)(dV0 + i * 16) = zero; *(uint4*)(dV1 + i * 16) = zero; }
+        for (int i = TILE / 16 + t; i < (TILE + KONES) / 16; i += NT) { *(uint4*)(dK0 + i * 16) = ones; *(uint4*)(dK1 + i * 16) = ones; }
+        for (int i = TILE / 16 + t; i < (TILE + VONES) / 16; i += NT) { *(uint4*)(dV0 + i * 16) = ones; *(uint4*)(dV1 + i * 16) = ones; }
     }
     __syncthreads();
 
@@ -391,8 +394,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn40q2_kernel(const vv_attn_pa
     {
         const unsigned one2 = (unsigned)T::from_f32(1.0f) * 0x10001u;
         const uint4 ones = make_uint4(one2, one2, one2, one2), zero = make_uint4(0, 0, 0, 0);
-        for (int i = t; i < (TILE + KONES) / 16; i += NT) { *(uint4*)(dK0 + i * 16) = i < TILE / 16 ? zero : ones; *(uint4*)(dK1 + i * 16) = i < TILE / 16 ? zero : ones; }
-        for (int i = t; i < (TILE + VONES) / 16; i += NT) { *(uint4*)(dV0 + i * 16) = i < TILE / 16 ? zero : ones; *(uint4*)(dV1 + i * 16) = i < TILE / 16 ? zero : ones; }
+        // (two loops per region, not `i < TILE / 16 ? zero : ones`: hipcc turned that select into a 32-byte SCRATCH array indexed by the condition -- every thread of the
+        //  launch wrote and re-read it: 0.12 GB of HBM writes per level-0 launch, 29 % of the kernel's WRITE_SIZE; found in round 6 through private_segment_fixed_size = 48)
+        for (int i = t; i < TILE / 16; i += NT) { *(uint4*)(dK0 + i * 16) = zero; *(uint4*)(dK1 + i * 16) = zero; *(uint4*)(dV0 + i * 16) = zero; *(uint4*)(dV1 + i * 16) = zero; }
+        for (int i = TILE / 16 + t; i < (TILE + KONES) / 16; i += NT) { *(uint4*)(dK0 + i * 16) = ones; *(uint4*)(dK1 + i * 16) = ones; }
+        for (int i = TILE / 16 + t; i < (TILE + VONES) / 16; i += NT) { *(uint4*)(dV0 + i * 16) = ones; *(uint4*)(dV1 + i * 16) = ones; }
     }
     __syncthreads();
 

@@ -77,7 +77,12 @@ __device__ __forceinline__ void gemm_epilogue(const vv_conv_params& p, f32x4 (&a
         }
         return;
     }
-    if (LEAN && STAGED && vec && stage && p.out_dtype == VV_F32 && p.split_heads <= 0 && !p.rowvec && !p.res1 && p.act == VV_ACT_NONE && (!p.res0 || r0f32)) {
+#ifdef VV_NO_STAGE_F32      // lab: the fp32 strips stay in the accumulator layout (the form before round 5's second session) -- the in-pipeline A/B of the staged form, profiles/r6_stage_f32_pipeline_ab.txt
+    constexpr bool STAGE_F32 = false;
+#else
+    constexpr bool STAGE_F32 = true;
+#endif
+    if (STAGE_F32 && LEAN && STAGED && vec && stage && p.out_dtype == VV_F32 && p.split_heads <= 0 && !p.rowvec && !p.res1 && p.act == VV_ACT_NONE && (!p.res0 || r0f32)) {
         // STAGED form of the lean path (fp32 trunk out, at most the fp32 residual: the out-projections and FF outputs of levels 1 / 2 -- streaming kernels, 60 % of
         // their time in this epilogue).  In the accumulator layout a wave instruction touches 16 rows x 64 bytes: half a cache line per row and request.  A strip
         // (16 rows x W columns) goes through a wave-private LDS tile instead and comes back row-major: each instruction then covers 256 / W rows x W * 4 contiguous bytes
