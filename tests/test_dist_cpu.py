@@ -342,3 +342,25 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--frames", "64"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's own N > 1 form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
+    (dry run, gloo): the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) is honoured as is -- bench.py does NOT spawn ranks of its own
+    under it -- one JSON line from rank 0, the frames of the one-rank line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--height", "16", "--width", "24", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    two = lines[0]
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and two["collective_backend"] == "gloo" and two["scaling"] == "weak" and len(two["per_rank"]) == 2
+    _, one = _bench_no_launcher(["--gpus", "1", "--dry-run", "--height", "16", "--width", "24", "--steps", "4", "--warmup", "1"])
+    assert two["frame_sha256_16"] == one[-1]["frame_sha256_16"]
