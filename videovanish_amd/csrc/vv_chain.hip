@@ -908,12 +908,9 @@ __global__ __launch_bounds__(512, 2) void chain_front_rs_c320_kernel(const vv_ch
         const int64_t fr = rows[tt] / p.HW, tk = rows[tt] - fr * p.HW;
         tokbase[tt] = fr * (3 * (int64_t)p.HW * CC) + tk * CD;
     }
-    // Stores of the QKV phase: block by block (4 stores per wave and 64-channel block).  The 80-byte record of a (token, head) -- 40 channels that straddle row
-    // blocks and the two waves of a pair -- therefore reaches L2 in 32-byte pieces microseconds apart and leaves as partial 64-byte bursts: 1.574 GB written for
-    // 0.885 GB of QKV (profiles/r5_final_pmc_traffic.json).  Round 6 built the remedy -- one `which` (q, k or v = 320 channels = 5 blocks) held packed in 40
-    // registers and stored in ONE burst (lab form, -DVV_FRONT_BURST) -- and measured it SLOWER (0.767 against 0.747 ms, three interleaved rounds, with plain
-    // vmcnt(6) waits and with waits that leave the stores in flight alike: profiles/r6_front_store_ab.txt): the kernel is not waiting for its stores, and the
-    // burst costs more issue slots than the wasted bytes cost time.  The product keeps the block-by-block form.
+    // Stores of the QKV phase: block by block (4 stores per wave and 64-channel block).  The kernel writes 1.574 GB per 32-frame launch against 1.475 GB algorithmic (t fp32 0.590 GB +
+    // qkv 0.885 GB): 1.07x -- round 5's "1.78x" divided by the QKV bytes alone.  Round 6 built a one-burst form anyway (one `which` = q, k or v = 5 blocks held packed in 40 registers
+    // and stored together; lab form, -DVV_FRONT_BURST) and measured it 3 % SLOWER with no fewer bytes written (profiles/r6_front_store_ab.txt): the product keeps this form.
 #ifdef VV_FRONT_BURST
     auto qkv_which = [&](const int which, auto tail) {
         uint2 hold[5][2][2];
