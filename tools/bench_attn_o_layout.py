@@ -5,6 +5,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from videovanish_amd import hip, nn as vnn
+if os.environ.get("VV_LIB_PATH"):
+    hip._LIB_PATH = os.environ["VV_LIB_PATH"]      # (lab) another build of the library
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 heads, N, D = 8, 14400, 40
