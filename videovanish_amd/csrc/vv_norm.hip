@@ -154,12 +154,12 @@ __global__ __launch_bounds__(256) void gn_finalize_pooled_kernel(const vv_groupn
 }
 
 template <typename T>
-__global__ void gn_apply_kernel(const vv_groupnorm_params p, const GNGeom g) {
+__global__ void gn_apply_kernel(const vv_groupnorm_params p, const GNGeom g, const float* fin_all /* [F][groups][2] (mean, rstd) */) {
     const int t = threadIdx.x, split = blockIdx.x, f = blockIdx.y;
     if (t >= g.threads) return;
     const int C = p.C0 + p.C1, cpg = C / p.groups;
     const int chunk = t % g.C8, r0 = t / g.C8;
-    const float* fin = p.stats_ws + (int64_t)p.F * g.nsplit * p.groups * 2 + (int64_t)f * p.groups * 2;
+    const float* fin = fin_all + (int64_t)f * p.groups * 2;
     float a[8], b[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -288,7 +288,7 @@ int gn_launch(const vv_groupnorm_params& p, hipStream_t st, bool apply = true) {
     hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), (size_t)2 * g.krows * C * sizeof(float), st, p, g);
     if (p.pool_frames) hipLaunchKernelGGL(gn_finalize_pooled_kernel, dim3(p.groups), dim3(256), 0, st, p, g);
     else hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.F), dim3(256), 0, st, p, g);
-    if (apply) hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
+    if (apply) hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g, (const float*)(p.stats_ws + (int64_t)p.F * g.nsplit * p.groups * 2));
     VV_CHECK_LAUNCH("vv_groupnorm");
     return VV_OK;
 }
@@ -332,7 +332,7 @@ extern "C" int vv_gn_finalize_partials(const float* partials, int F, int nblk, i
 
 extern "C" int vv_groupnorm_apply_fin(const vv_groupnorm_params* pp, const float* fin, int dtype, void* stream) {
     if (!pp || !fin) VV_FAIL(VV_E_ARG, "vv_groupnorm_apply_fin: null pointer");
-    vv_groupnorm_params p = *pp;
+    const vv_groupnorm_params& p = *pp;
     const int C = p.C0 + p.C1;
     if (dtype != VV_BF16 && dtype != VV_F16) VV_FAIL(VV_E_ARG, "vv_groupnorm_apply_fin: bad dtype");
     if (!p.in0 || !p.out || !p.gamma || !p.beta) VV_FAIL(VV_E_ARG, "vv_groupnorm_apply_fin: null pointer");
@@ -340,12 +340,10 @@ extern "C" int vv_groupnorm_apply_fin(const vv_groupnorm_params* pp, const float
     if ((p.in_dtype != VV_F32 && p.in_dtype != dtype) || (p.out_dtype != VV_F32 && p.out_dtype != dtype && p.out_dtype != VV_SPLIT3)) VV_FAIL(VV_E_ARG, "vv_groupnorm_apply_fin: dtype mismatch");
     if (p.F <= 0 || p.HW <= 0) VV_FAIL(VV_E_ARG, "vv_groupnorm_apply_fin: empty input");
     const GNGeom g = gn_geom(p.HW, C);
-    // the apply kernel reads (mean, rstd) at stats_ws + F * nsplit * groups * 2 (behind the partials of its own statistics pass): point that address at `fin`
-    p.stats_ws = const_cast<float*>(fin) - (int64_t)p.F * g.nsplit * p.groups * 2;
     const int threads = (g.threads + 63) / 64 * 64;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == VV_BF16) hipLaunchKernelGGL(gn_apply_kernel<BF16>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
-    else hipLaunchKernelGGL(gn_apply_kernel<F16>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g);
+    if (dtype == VV_BF16) hipLaunchKernelGGL(gn_apply_kernel<BF16>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g, fin);
+    else hipLaunchKernelGGL(gn_apply_kernel<F16>, dim3(g.nsplit, p.F), dim3(threads), 0, st, p, g, fin);
     VV_CHECK_LAUNCH("vv_groupnorm_apply_fin");
     return VV_OK;
 }
