@@ -363,6 +363,11 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
         if constexpr (D == 256) {
             if ((int64_t)p.B * p.heads * ((p.Nq + 127) / 128) <= 128) return attn_launch<T, D, 1, 64, 8, true>(p, st);
         }
+        // d = 160 spatial self-attention (level 2: 32 frames x 8 heads x 920 tokens at 720p): eight waves of 16 queries share a block's K / V tile loads --
+        // 0.372 -> 0.325 ms (+14.5 %) against four waves of 32 queries; four waves of 16: 0.329; 32-key tiles: 0.509 (round 6, profiles/r6_attn160_ab.txt)
+        if constexpr (D == 160) {
+            if (p.Nq >= 256 && p.Nkv >= 256) return attn_launch<T, D, 1, 64, 8, true>(p, st);
+        }
         return attn_launch<T, D, 2, 64, 4, true>(p, st);
     }
 }
