@@ -347,6 +347,9 @@ int attn_launch(const vv_attn_params& p, hipStream_t st) {
 template <typename T, int D>
 int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
     if constexpr (D >= 512) {
+        // (round 6: eight waves of 16 queries instead of four -- the waves share the block's 32-key K / V tiles: the VAE mid attention, 4 frames x 14400 tokens, 4.32 -> 3.58 ms;
+        //  profiles/r6_attn160_ab.txt)
+        if (p.Nq >= 256) return attn_launch<T, D, 1, 32, 8, false>(p, st);
         return attn_launch<T, D, 1, 32, 4, false>(p, st);
     } else {
         // short sequences (temporal attention over <=32 frames, tiny test shapes): one wave per block, 32-key tiles
@@ -365,8 +368,9 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
         }
         // d = 160 spatial self-attention (level 2: 32 frames x 8 heads x 920 tokens at 720p): eight waves of 16 queries share a block's K / V tile loads --
         // 0.372 -> 0.325 ms (+14.5 %) against four waves of 32 queries; four waves of 16: 0.329; 32-key tiles: 0.509 (round 6, profiles/r6_attn160_ab.txt)
+        // (... and the level-2 cross attention to the 77 text tokens: 0.089 -> 0.076 ms; d = 80 cross attention: no gain, unchanged)
         if constexpr (D == 160) {
-            if (p.Nq >= 256 && p.Nkv >= 256) return attn_launch<T, D, 1, 64, 8, true>(p, st);
+            if (p.Nq >= 256) return attn_launch<T, D, 1, 64, 8, true>(p, st);
         }
         return attn_launch<T, D, 2, 64, 4, true>(p, st);
     }
