@@ -353,6 +353,9 @@ int attn_dispatch(const vv_attn_params& p, hipStream_t st) {
         return attn_launch<T, D, 1, 32, 4, false>(p, st);
     } else {
         // short sequences (temporal attention over <=32 frames, tiny test shapes): one wave per block, 32-key tiles
+        // (round 6: at d = 160 two waves of 16 queries share the one 32-key tile of a temporal attention: 0.0865 -> 0.072 ms at 32 frames x 920 pixels; d = 80: +2 %, unchanged;
+        //  profiles/r6_attn160_ab.txt)
+        if (D >= 128 && p.Nq <= 32 && p.Nkv <= 32 && p.Nq > 16) return attn_launch<T, D, 1, 32, 2, true>(p, st);
         if (p.Nq <= 32 && p.Nkv <= 32) return attn_launch<T, D, 2, 32, 1, true>(p, st);
         if constexpr (D <= 80) {
             // default for d <= 64: K/V by LDS-DMA, double buffered, 3 waves/SIMD (d = 80 would spill: stays register staged)
